@@ -1,0 +1,183 @@
+/*
+ * hlm_hip.h -- C ABI of libhlm_hip.so, the MI355X (gfx950) implementation of the
+ * per-hillslope adaptive Dormand-Prince RK45 path of PrincetonUniversity/Tiger_HLM_GPU.
+ *
+ * Plain C: pointers, sizes, POD structs; no C++/torch types cross this boundary.
+ * Every entry point returns 0 on success and a non-zero hlm_status otherwise;
+ * hlm_last_error() then holds a message (thread-local).  Nothing throws.
+ * Numerical trouble is DATA (stiff[] flags), never an error -- as in the reference.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the
+ * reference's src/).  The header-only C++ mirror of the reference's template API
+ * (rk45_api::setModelParameters<M>, run_rk45<M>, ...) lives in include/hlm/ and
+ * forwards to these functions.
+ *
+ * Threading: like the reference (global devParams + forcing symbols) the model
+ * registry and forcing registration are process-global state; one integration may be
+ * in flight per device.  hlm_rk45_integrate_device() itself is re-entrant (all state
+ * is in the job struct).
+ */
+#ifndef HLM_HIP_H
+#define HLM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HLM_ABI_VERSION 1
+#define HLM_NEQ 5           /* Model204::N_EQ, models/model_204.hpp:19 */
+#define HLM_MAX_FORCINGS 16 /* I_O/forcing_data.h:5 */
+
+#define HLM_UID_DUMMY 0 /* DummyModel (README.md:41-42, rhs: model_dummy_python.ipynb:65-89) */
+#define HLM_UID_204 204 /* Model204::UID, models/model_204.hpp:18 */
+
+typedef enum {
+    HLM_SUCCESS = 0,
+    HLM_ERR_INVALID_ARGUMENT = 1,
+    HLM_ERR_UNKNOWN_MODEL = 2,
+    HLM_ERR_HIP = 3,        /* a HIP runtime call failed (rk45_api.hpp:86-108,150-153) */
+    HLM_ERR_NO_DEVICE = 4,
+    HLM_ERR_STATE = 5       /* e.g. launch before setup / forcings not registered */
+} hlm_status;
+
+/* per-system status in stiff[]: 0/1 as rk45_kernel.cu:160-170; 2 = attempt cap reached
+ * (build's guard against the slope-jump livelock of rk45_kernel.cu:133-136). */
+#define HLM_SYS_OK 0
+#define HLM_SYS_STIFF 1
+#define HLM_SYS_CAPPED 2
+
+/* math mode: 0 = strict (IEEE divide, OCML pow: same operation structure as the
+ * reference, FMA-contracted like nvcc's default); 1 = fast (reciprocal multiplies,
+ * specialised x^(2/3) and x^(1/5); within the stated parity tolerance). */
+#define HLM_MATH_STRICT 0
+#define HLM_MATH_FAST 1
+
+/* I_O/parameters_loader.hpp:19-37: 2 x long + 15 x double = 136 B, field order is ABI
+ * (the reference memcpy's it to the device, main.cpp:400, and MPI_Sends it raw, :303). */
+typedef struct hlm_spatial_params {
+    long stream;
+    long next_stream;
+    double c1, infil, perco, Hu, lat, sw, ss, n_mann, slope, L, A_h, alpha3, alpha4,
+        melt_f, temp_thr;
+} hlm_spatial_params;
+
+/* ---- library / device ------------------------------------------------------------ */
+int hlm_abi_version(void);
+const char* hlm_last_error(void);
+int hlm_device_count(int* count);
+int hlm_set_device(int device); /* main.cpp:314-319 cudaSetDevice */
+int hlm_device_synchronize(void);
+
+/* Device memory the CALLER owns, as main.cpp:392-404 (d_sp) and :552-557 (d_forc_ptr)
+ * do with cudaMalloc/cudaMemcpy. */
+int hlm_device_malloc(void** dptr, size_t bytes);
+int hlm_device_free(void* dptr);
+int hlm_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int hlm_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes);
+
+/* ---- model registry (model_registry.hpp:12-13, model_registry.cpp:18-60) ---------- */
+/* p = {initialStep, rtol, atol, safety, minScale, maxScale} (model_204.hpp:22-30).
+ * Replaces cudaMemcpyToSymbol(devParams). */
+int hlm_set_model_parameters(int uid, const double p[6]);
+int hlm_get_model_parameters(int uid, double p[6]);
+/* Build features (not in the reference): fixed-step mode (h > 0 turns the controller
+ * off; 0 restores adaptive), per-system attempt cap (0 = default 2^24), math mode. */
+int hlm_set_fixed_step(int uid, double h);
+int hlm_set_attempt_cap(uint32_t cap);
+int hlm_set_math_mode(int mode);
+
+/* ---- forcing symbols (I_O/forcing_data.cu:5-10; uploads at main.cpp:559-574) -------
+ * d_forc: DEVICE pointer, float [sum_j nT[j]][ld] forcing-major then time then column
+ * (main.cpp:527-549 with ld = num_systems and column = system).  dt_hours/nT: HOST
+ * arrays of length nforc.  The caller keeps ownership of d_forc.
+ * d_col (nullable DEVICE int32 [num_systems]) selects a column per system so that a
+ * compact per-grid-cell table can be used instead of the per-stream expansion; NULL
+ * means column = system (the reference layout). */
+int hlm_set_forcings(const float* d_forc, const double* dt_hours, const uint64_t* nT,
+                     int nforc, int64_t ld, const int32_t* d_col);
+int hlm_clear_forcings(void);
+
+/* ---- three-phase host API (rk45_api.hpp:63-116, :120-154, :159-270) --------------- */
+typedef struct hlm_gpu_buffers {
+    double* d_y0_all;      /* [ns][neq] */
+    double* d_y_final_all; /* [ns][neq] */
+    double* d_query_times; /* [nq] */
+    double* d_dense_all;   /* [ns][nq][neq] -- already in the host-facing order */
+    int32_t* d_stiff;      /* [ns] */
+    uint32_t* d_n_attempt; /* [ns] attempted RK45 steps (build's step counter) */
+    uint32_t* d_n_accept;  /* [ns] */
+    int num_systems;
+    int num_queries;
+} hlm_gpu_buffers;
+
+/* setup_gpu_buffers<M>: allocate the device buffers, copy h_y0 and h_query_times. */
+int hlm_setup_gpu_buffers(const double* h_y0, int num_systems, const double* h_query_times,
+                          int num_queries, hlm_gpu_buffers* out);
+/* launch_rk45_kernel<M>: integrate all systems on the current device and synchronise.
+ * d_sp: DEVICE pointer to num_systems hlm_spatial_params (may be NULL for the
+ * DummyModel).  Uses the registered parameters and forcings. */
+int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double tf,
+                           const void* d_sp);
+/* retrieve_and_free<M>: D2H of final states (h_final [ns][neq]) and dense output
+ * (h_dense [ns][nq][neq] = index (s*nq+q)*neq+c, rk45_api.hpp:255-267), then free.
+ * h_stiff / h_n_attempt / h_n_accept are optional (NULL to skip).  The Radau relaunch
+ * of rk45_api.hpp:189-247 is out of scope: flagged systems keep
+ * zero rows, exactly what the reference's host receives (its copy precedes Radau). */
+int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense,
+                          int32_t* h_stiff, uint32_t* h_n_attempt, uint32_t* h_n_accept);
+/* run_rk45<M> (rk45_api.hpp:273-313): the three phases composed. */
+int hlm_run_rk45(int uid, const double* h_y0, int num_systems, double t0, double tf,
+                 const double* h_query_times, int num_queries, const void* d_sp,
+                 double* h_final, double* h_dense, int32_t* h_stiff,
+                 uint32_t* h_n_attempt, uint32_t* h_n_accept);
+
+/* ---- device-resident core (everything above is built on this) --------------------- */
+typedef struct hlm_device_job {
+    int uid;
+    int num_systems;
+    int num_queries;
+    double t0, tf;
+    /* inputs, all DEVICE pointers */
+    const double* d_y0;      /* [ns][5] AoS (rk45_kernel.cu:45) */
+    const double* d_query;   /* [nq] ascending */
+    const void* d_sp;        /* [ns] x 136 B */
+    const float* d_forc;     /* see hlm_set_forcings */
+    const int32_t* d_forc_col;
+    int64_t forc_ld;
+    double forc_dt_hours[HLM_MAX_FORCINGS];
+    uint64_t forc_nT[HLM_MAX_FORCINGS];
+    int nforc;
+    /* solver knobs */
+    double params[6];
+    double fixed_step;
+    uint32_t attempt_cap;
+    int math_mode;
+    /* outputs, DEVICE pointers; every slot is written (never-reached slots get 0,
+     * matching the zeros in the reference's artifacts, SURVEY A.1 note 11) */
+    double* d_y_final;       /* [ns][5] */
+    double* d_dense;         /* [ns][nq][5]; may be NULL when nq == 0 */
+    int32_t* d_stiff;        /* [ns] */
+    uint32_t* d_n_attempt;   /* [ns] nullable */
+    uint32_t* d_n_accept;    /* [ns] nullable */
+} hlm_device_job;
+
+/* Enqueue the integration on `hip_stream` (a hipStream_t, NULL = default stream) of the
+ * current device.  Asynchronous: returns after the launch. */
+int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream);
+
+/* Kernel timing helper for bench.py: runs the job `iters` times on `hip_stream`,
+ * bracketing EACH launch with HIP events on that stream; ms[i] receives the elapsed
+ * milliseconds of launch i. */
+int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms);
+
+/* Static facts about the compiled kernels (for DESIGN.md / bench output). */
+int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs,
+                    int* lds_bytes, int* max_threads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HLM_HIP_H */

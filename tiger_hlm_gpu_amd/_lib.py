@@ -1,0 +1,110 @@
+"""ctypes binding of libhlm_hip.so (include/hlm_hip.h).
+
+The library is built in-tree by ``tiger_hlm_gpu_amd/csrc/Makefile`` (see
+``__graft_entry__.build``).  There is no fallback: if the shared object is missing the
+import of any compute entry point raises, and every call that needs a device fails with
+``HlmError`` when no HIP device is present.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libhlm_hip.so")
+
+HLM_NEQ = 5
+HLM_MAX_FORCINGS = 16
+UID_DUMMY = 0
+UID_204 = 204
+MATH_STRICT = 0
+MATH_FAST = 1
+SYS_OK, SYS_STIFF, SYS_CAPPED = 0, 1, 2
+
+
+class HlmError(RuntimeError):
+    """Raised for a non-zero hlm_status (the reference throws std::runtime_error,
+    rk45_api.hpp:86-108,150-153; model_registry.cpp:33-38)."""
+
+    def __init__(self, code, msg):
+        super().__init__(f"hlm_status {code}: {msg}")
+        self.code = code
+
+
+class GpuBuffers(C.Structure):
+    """hlm_gpu_buffers -- the tuple setup_gpu_buffers returns (rk45_api.hpp:110-115)."""
+    _fields_ = [
+        ("d_y0_all", C.c_void_p), ("d_y_final_all", C.c_void_p), ("d_query_times", C.c_void_p),
+        ("d_dense_all", C.c_void_p), ("d_stiff", C.c_void_p), ("d_n_attempt", C.c_void_p),
+        ("d_n_accept", C.c_void_p), ("num_systems", C.c_int), ("num_queries", C.c_int),
+    ]
+
+
+class DeviceJob(C.Structure):
+    """hlm_device_job"""
+    _fields_ = [
+        ("uid", C.c_int), ("num_systems", C.c_int), ("num_queries", C.c_int),
+        ("t0", C.c_double), ("tf", C.c_double),
+        ("d_y0", C.c_void_p), ("d_query", C.c_void_p), ("d_sp", C.c_void_p),
+        ("d_forc", C.c_void_p), ("d_forc_col", C.c_void_p), ("forc_ld", C.c_int64),
+        ("forc_dt_hours", C.c_double * HLM_MAX_FORCINGS), ("forc_nT", C.c_uint64 * HLM_MAX_FORCINGS),
+        ("nforc", C.c_int),
+        ("params", C.c_double * 6), ("fixed_step", C.c_double), ("attempt_cap", C.c_uint32),
+        ("math_mode", C.c_int),
+        ("d_y_final", C.c_void_p), ("d_dense", C.c_void_p), ("d_stiff", C.c_void_p),
+        ("d_n_attempt", C.c_void_p), ("d_n_accept", C.c_void_p),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/hlm_hip.h declares
+SIGNATURES = {
+    "hlm_abi_version": (C.c_int, []),
+    "hlm_last_error": (C.c_char_p, []),
+    "hlm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "hlm_set_device": (C.c_int, [C.c_int]),
+    "hlm_device_synchronize": (C.c_int, []),
+    "hlm_device_malloc": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "hlm_device_free": (C.c_int, [C.c_void_p]),
+    "hlm_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hlm_memcpy_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "hlm_set_model_parameters": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "hlm_get_model_parameters": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "hlm_set_fixed_step": (C.c_int, [C.c_int, C.c_double]),
+    "hlm_set_attempt_cap": (C.c_int, [C.c_uint32]),
+    "hlm_set_math_mode": (C.c_int, [C.c_int]),
+    "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
+                                   C.c_int64, C.c_void_p]),
+    "hlm_clear_forcings": (C.c_int, []),
+    "hlm_setup_gpu_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(GpuBuffers)]),
+    "hlm_launch_rk45_kernel": (C.c_int, [C.c_int, C.POINTER(GpuBuffers), C.c_double, C.c_double, C.c_void_p]),
+    "hlm_retrieve_and_free": (C.c_int, [C.POINTER(GpuBuffers), C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.c_void_p, C.c_void_p]),
+    "hlm_run_rk45": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int,
+                               C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hlm_rk45_integrate_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p]),
+    "hlm_rk45_time_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    "hlm_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
+                                  C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load libhlm_hip.so (once).  Raises ImportError when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C tiger_hlm_gpu_amd/csrc)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise HlmError(rc, lib().hlm_last_error().decode("utf-8", "replace"))

@@ -1,0 +1,243 @@
+"""Python mirror of the reference's host API (namespace rk45_api), calling libhlm_hip.so
+through the C ABI only.
+
+  set_model_parameters(Model, p)      model_registry.hpp:12-13 / model_registry.cpp:18-60
+  setup_gpu_buffers(Model, y0, q)     rk45_api.hpp:63-116
+  launch_rk45_kernel(Model, bufs, ..) rk45_api.hpp:120-154
+  retrieve_and_free(Model, bufs)      rk45_api.hpp:159-270
+  run_rk45(Model, y0, t0, tf, q, d_sp) rk45_api.hpp:273-313
+
+plus the device-resident entry (integrate_device) that bench.py and the multi-GPU path
+use with torch-owned HBM buffers.  torch is plumbing only (device memory, streams).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import DeviceJob, GpuBuffers, HlmError, check, lib
+from .models import SP_DTYPE, Parameters
+
+
+def _uid(model):
+    return model if isinstance(model, int) else model.UID
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+# ---- device helpers ---------------------------------------------------------------------
+def device_count():
+    n = C.c_int(0)
+    rc = lib().hlm_device_count(C.byref(n))
+    return n.value if rc == 0 else 0
+
+
+def set_device(dev):
+    check(lib().hlm_set_device(int(dev)))
+
+
+class DeviceBuffer:
+    """Caller-owned device allocation (what main.cpp:392-404 does for d_sp)."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p(0)
+        check(lib().hlm_device_malloc(C.byref(p), int(nbytes)))
+        self.ptr = p.value or 0
+        self.nbytes = int(nbytes)
+
+    @classmethod
+    def from_host(cls, arr):
+        arr = np.ascontiguousarray(arr)
+        b = cls(arr.nbytes)
+        check(lib().hlm_memcpy_h2d(b.ptr, arr.ctypes.data, arr.nbytes))
+        return b
+
+    def to_host(self, dtype, shape):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib().hlm_memcpy_d2h(out.ctypes.data, self.ptr, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(lib().hlm_device_free(self.ptr))
+            self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def upload_spatial_params(sp):
+    """H2D of the 136-byte AoS records (main.cpp:392-404)."""
+    sp = np.ascontiguousarray(sp, dtype=SP_DTYPE)
+    return DeviceBuffer.from_host(sp)
+
+
+# ---- registry ------------------------------------------------------------------------------
+def set_model_parameters(model, p):
+    """rk45_api::setModelParameters<Model>(p)."""
+    if isinstance(p, Parameters):
+        p = p.as_tuple()
+    arr = (C.c_double * 6)(*[float(x) for x in p])
+    check(lib().hlm_set_model_parameters(_uid(model), arr))
+
+
+def get_model_parameters(model):
+    arr = (C.c_double * 6)()
+    check(lib().hlm_get_model_parameters(_uid(model), arr))
+    return Parameters(*list(arr))
+
+
+def set_fixed_step(model, h):
+    check(lib().hlm_set_fixed_step(_uid(model), float(h)))
+
+
+def set_attempt_cap(cap):
+    check(lib().hlm_set_attempt_cap(int(cap)))
+
+
+def set_math_mode(mode):
+    check(lib().hlm_set_math_mode(int(mode)))
+
+
+class Forcings:
+    """Device-resident forcing block + metadata (the reference's c_forc_dt / c_forc_nT /
+    d_forc_data / nForc symbols, forcing_data.cu:5-10)."""
+
+    def __init__(self, data, dt_hours, nT, ld, col=None):
+        data = np.ascontiguousarray(data, dtype=np.float32)
+        self.dt_hours = [float(x) for x in dt_hours]
+        self.nT = [int(x) for x in nT]
+        self.ld = int(ld)
+        assert data.size == sum(self.nT) * self.ld, (data.size, self.nT, self.ld)
+        self.buf = DeviceBuffer.from_host(data)
+        self.col = None if col is None else DeviceBuffer.from_host(np.ascontiguousarray(col, dtype=np.int32))
+
+    def register(self):
+        n = len(self.nT)
+        dt = (C.c_double * n)(*self.dt_hours)
+        nt = (C.c_uint64 * n)(*self.nT)
+        check(lib().hlm_set_forcings(self.buf.ptr, dt, nt, n, self.ld, self.col.ptr if self.col else None))
+
+    def free(self):
+        check(lib().hlm_clear_forcings())
+        self.buf.free()
+        if self.col:
+            self.col.free()
+
+
+def set_forcings(data, dt_hours, nT, ld, col=None):
+    f = Forcings(data, dt_hours, nT, ld, col)
+    f.register()
+    return f
+
+
+def clear_forcings():
+    check(lib().hlm_clear_forcings())
+
+
+# ---- three-phase API ---------------------------------------------------------------------------
+def setup_gpu_buffers(model, h_y0, h_query_times):
+    y0 = np.ascontiguousarray(h_y0, dtype=np.float64).reshape(-1)
+    q = np.ascontiguousarray(h_query_times if h_query_times is not None else [], dtype=np.float64).reshape(-1)
+    ns = y0.size // model.N_EQ
+    b = GpuBuffers()
+    check(lib().hlm_setup_gpu_buffers(_ptr(y0) if ns else None, ns, _ptr(q) if q.size else None, q.size, C.byref(b)))
+    return b
+
+
+def launch_rk45_kernel(model, bufs, t0, tf, d_sp):
+    sp_ptr = d_sp.ptr if isinstance(d_sp, DeviceBuffer) else d_sp
+    check(lib().hlm_launch_rk45_kernel(_uid(model), C.byref(bufs), float(t0), float(tf), sp_ptr))
+
+
+def retrieve_and_free(model, bufs, with_info=False):
+    ns, nq, neq = bufs.num_systems, bufs.num_queries, model.N_EQ
+    final = np.empty(ns * neq)
+    dense = np.empty(ns * nq * neq)
+    stiff = np.empty(ns, dtype=np.int32)
+    na = np.empty(ns, dtype=np.uint32)
+    nacc = np.empty(ns, dtype=np.uint32)
+    check(lib().hlm_retrieve_and_free(C.byref(bufs), _ptr(final), _ptr(dense) if dense.size else None,
+                                      _ptr(stiff), _ptr(na), _ptr(nacc)))
+    if with_info:
+        return final, dense, {"stiff": stiff, "n_attempt": na, "n_accept": nacc}
+    return final, dense
+
+
+def run_rk45(model, h_y0, t0, tf, h_query_times, d_sp, with_info=False):
+    """std::pair<FinalType, DenseType> run_rk45<Model>(h_y0, t0, tf, h_query_times, d_sp):
+    first = y_final[s*N_EQ+i]; second = dense[(s*nq+q)*N_EQ+c]."""
+    y0 = np.ascontiguousarray(h_y0, dtype=np.float64).reshape(-1)
+    q = np.ascontiguousarray(h_query_times if h_query_times is not None else [], dtype=np.float64).reshape(-1)
+    neq = model.N_EQ
+    ns, nq = y0.size // neq, q.size
+    final = np.empty(ns * neq)
+    dense = np.empty(ns * nq * neq)
+    stiff = np.empty(ns, dtype=np.int32)
+    na = np.empty(ns, dtype=np.uint32)
+    nacc = np.empty(ns, dtype=np.uint32)
+    sp_ptr = d_sp.ptr if isinstance(d_sp, DeviceBuffer) else d_sp
+    check(lib().hlm_run_rk45(_uid(model), _ptr(y0) if ns else None, ns, float(t0), float(tf),
+                             _ptr(q) if nq else None, nq, sp_ptr, _ptr(final) if ns else None,
+                             _ptr(dense) if dense.size else None, _ptr(stiff), _ptr(na), _ptr(nacc)))
+    if with_info:
+        return final, dense, {"stiff": stiff, "n_attempt": na, "n_accept": nacc}
+    return final, dense
+
+
+# ---- device-resident path (torch tensors as HBM buffers) ------------------------------------------
+def make_device_job(model, *, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_hours=(), forc_nT=(),
+                    forc_ld=0, forc_col=None, params=None, fixed_step=0.0, attempt_cap=0,
+                    math_mode=_lib.MATH_STRICT, y_final, dense=None, stiff, n_attempt=None, n_accept=None):
+    """Fill an hlm_device_job from torch CUDA tensors (or raw int device pointers)."""
+    def dp(t):
+        if t is None:
+            return None
+        return t if isinstance(t, int) else t.data_ptr()
+
+    j = DeviceJob()
+    j.uid = _uid(model)
+    ns = y0.numel() // model.N_EQ if not isinstance(y0, int) else None
+    j.num_systems = ns
+    j.num_queries = 0 if query is None else query.numel()
+    j.t0, j.tf = float(t0), float(tf)
+    j.d_y0, j.d_query, j.d_sp = dp(y0), dp(query), dp(sp)
+    j.d_forc, j.d_forc_col, j.forc_ld = dp(forc), dp(forc_col), int(forc_ld)
+    j.nforc = len(forc_nT)
+    for k, (dt, nt) in enumerate(zip(forc_dt_hours, forc_nT)):
+        j.forc_dt_hours[k] = float(dt)
+        j.forc_nT[k] = int(nt)
+    p = (params if params is not None else Parameters())
+    p = p.as_tuple() if isinstance(p, Parameters) else tuple(float(x) for x in p)
+    for k in range(6):
+        j.params[k] = p[k]
+    j.fixed_step, j.attempt_cap, j.math_mode = float(fixed_step), int(attempt_cap), int(math_mode)
+    j.d_y_final, j.d_dense, j.d_stiff = dp(y_final), dp(dense), dp(stiff)
+    j.d_n_attempt, j.d_n_accept = dp(n_attempt), dp(n_accept)
+    return j
+
+
+def integrate_device(job, stream=None):
+    """Enqueue on ``stream`` (a torch.cuda.Stream, a raw hipStream_t int, or None)."""
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    check(lib().hlm_rk45_integrate_device(C.byref(job), s))
+
+
+def time_device(job, iters, stream=None):
+    """Per-launch kernel milliseconds measured with HIP events on the launch stream."""
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    ms = (C.c_float * iters)()
+    check(lib().hlm_rk45_time_device(C.byref(job), s, iters, ms))
+    return list(ms)
+
+
+def kernel_info(model, dense=False, math_mode=_lib.MATH_STRICT):
+    v, s, l, m = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
+    check(lib().hlm_kernel_info(_uid(model), int(dense), int(math_mode), C.byref(v), C.byref(s), C.byref(l), C.byref(m)))
+    return {"vgprs": v.value, "lds_bytes": l.value, "max_threads": m.value}

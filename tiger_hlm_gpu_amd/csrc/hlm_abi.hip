@@ -1,0 +1,486 @@
+// libhlm_hip.so: the C ABI of include/hlm_hip.h on top of the gfx950 RK45 kernels.
+// Host side mirrors the reference's rk45_api (src/solver/rk45_api.hpp:53-315) and model
+// registry (src/model_registry.cpp:18-60); no oracle / CPU fallback exists in here --
+// without a HIP device every compute entry point fails with HLM_ERR_NO_DEVICE/HIP.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+
+#include "hlm_hip.h"
+#include "hlm_rk45_kernel.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HLM_HIP_TRY(expr)                                                                 \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess)                                                             \
+            return fail(HLM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));      \
+    } while (0)
+
+// ---- process-global registry: the reference's devParams (model_204_global.cu:42) and
+// forcing symbols (forcing_data.cu:5-10), kept host-side and passed as kernel arguments.
+struct ModelState {
+    int uid;
+    double p[6];
+    double fixed_step;
+};
+std::mutex g_mu;
+ModelState g_models[2] = {
+    {HLM_UID_DUMMY, {0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0}, 0.0},  // model_204.hpp:22-30 defaults
+    {HLM_UID_204, {0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0}, 0.0},
+};
+uint32_t g_cap = 1u << 24;
+int g_math = HLM_MATH_STRICT;
+
+struct ForcingState {
+    const float* d_forc = nullptr;
+    const int32_t* d_col = nullptr;
+    int64_t ld = 0;
+    double dt_h[HLM_MAX_FORCINGS] = {};
+    uint64_t nT[HLM_MAX_FORCINGS] = {};
+    int nforc = 0;
+} g_forc;
+
+ModelState* find_model(int uid)
+{
+    for (auto& m : g_models)
+        if (m.uid == uid) return &m;
+    return nullptr;
+}
+
+using KernelFn = void (*)(const hlm::Rk45Args);
+
+template <class Model>
+KernelFn pick_kernel(int math, bool dense, bool fixed)
+{
+    using namespace hlm;
+    if (math == HLM_MATH_FAST) {
+        if (dense) return fixed ? rk45_multi_kernel<Model, MATH_FAST, true, true>
+                                : rk45_multi_kernel<Model, MATH_FAST, true, false>;
+        return fixed ? rk45_multi_kernel<Model, MATH_FAST, false, true>
+                     : rk45_multi_kernel<Model, MATH_FAST, false, false>;
+    }
+    if (dense) return fixed ? rk45_multi_kernel<Model, MATH_STRICT, true, true>
+                            : rk45_multi_kernel<Model, MATH_STRICT, true, false>;
+    return fixed ? rk45_multi_kernel<Model, MATH_STRICT, false, true>
+                 : rk45_multi_kernel<Model, MATH_STRICT, false, false>;
+}
+
+KernelFn pick(int uid, int math, bool dense, bool fixed)
+{
+    if (uid == HLM_UID_204) return pick_kernel<hlm::Model204Dev>(math, dense, fixed);
+    if (uid == HLM_UID_DUMMY) return pick_kernel<hlm::DummyDev>(math, dense, fixed);
+    return nullptr;
+}
+
+int validate_job(const hlm_device_job* j)
+{
+    if (!j) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
+    if (j->uid != HLM_UID_204 && j->uid != HLM_UID_DUMMY)
+        return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", j->uid);
+    if (j->num_systems < 0 || j->num_queries < 0)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "negative num_systems/num_queries");
+    if (j->num_systems == 0) return HLM_SUCCESS;
+    if (!j->d_y0 || !j->d_y_final || !j->d_stiff)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "d_y0 / d_y_final / d_stiff must not be NULL");
+    if (j->num_queries > 0 && (!j->d_query || !j->d_dense))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "num_queries > 0 needs d_query and d_dense");
+    if (j->uid == HLM_UID_204 && !j->d_sp)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs d_sp (SpatialParams)");
+    if (j->nforc < 0 || j->nforc > HLM_MAX_FORCINGS)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "nforc %d outside [0,%d]", j->nforc, HLM_MAX_FORCINGS);
+    if (j->nforc > 0) {
+        if (!j->d_forc) return fail(HLM_ERR_INVALID_ARGUMENT, "nforc > 0 needs d_forc");
+        if (j->forc_ld <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "forc_ld must be > 0");
+        if (!j->d_forc_col && j->forc_ld < j->num_systems)
+            return fail(HLM_ERR_INVALID_ARGUMENT,
+                        "forc_ld (%lld) < num_systems (%d) without a column map",
+                        (long long)j->forc_ld, j->num_systems);
+        for (int k = 0; k < j->nforc; ++k) {
+            if (j->forc_nT[k] == 0) return fail(HLM_ERR_INVALID_ARGUMENT, "forc_nT[%d] == 0", k);
+            if (!(j->forc_dt_hours[k] > 0.0))
+                return fail(HLM_ERR_INVALID_ARGUMENT, "forc_dt_hours[%d] must be > 0", k);
+        }
+    }
+    if (j->math_mode != HLM_MATH_STRICT && j->math_mode != HLM_MATH_FAST)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "math_mode %d", j->math_mode);
+    if (j->fixed_step < 0.0) return fail(HLM_ERR_INVALID_ARGUMENT, "fixed_step < 0");
+    return HLM_SUCCESS;
+}
+
+hlm::Rk45Args make_args(const hlm_device_job* j)
+{
+    hlm::Rk45Args a;
+    std::memset(&a, 0, sizeof(a));
+    a.y0 = j->d_y0;
+    a.query = j->d_query;
+    a.sp = j->d_sp;
+    a.forc = j->d_forc;
+    a.forc_col = j->d_forc_col;
+    a.forc_ld = j->forc_ld;
+    unsigned long long base = 0;
+    for (int k = 0; k < j->nforc; ++k) {
+        if (k < 2) {
+            a.forc_dtmin[k] = j->forc_dt_hours[k] * 60.0;  // rk45_kernel.cu:90
+            a.forc_nT[k] = j->forc_nT[k];
+            a.forc_base[k] = base;
+        }
+        base += (unsigned long long)j->forc_nT[k] * (unsigned long long)j->forc_ld;
+    }
+    a.nforc = j->nforc;
+    a.ns = j->num_systems;
+    a.nq = j->num_queries;
+    a.t0 = j->t0;
+    a.tf = j->tf;
+    a.h0 = j->params[0];
+    a.rtol = j->params[1];
+    a.atol = j->params[2];
+    a.safety = j->params[3];
+    a.min_scale = j->params[4];
+    a.max_scale = j->params[5];
+    a.fixed_step = j->fixed_step;
+    a.cap = j->attempt_cap ? j->attempt_cap : (1u << 24);
+    a.y_final = j->d_y_final;
+    a.dense = j->d_dense;
+    a.stiff = j->d_stiff;
+    a.n_attempt = j->d_n_attempt;
+    a.n_accept = j->d_n_accept;
+    return a;
+}
+
+int launch(const hlm_device_job* j, hipStream_t stream)
+{
+    const bool dense = j->num_queries > 0;
+    const bool fixed = j->fixed_step > 0.0;
+    KernelFn fn = pick(j->uid, j->math_mode, dense, fixed);
+    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
+    const hlm::Rk45Args a = make_args(j);
+    const unsigned blocks = (unsigned)((j->num_systems + hlm::WAVE - 1) / hlm::WAVE);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a);
+    HLM_HIP_TRY(hipGetLastError());
+    return HLM_SUCCESS;
+}
+
+int fill_job_from_registry(hlm_device_job* j, int uid)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ModelState* m = find_model(uid);
+    if (!m) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    j->uid = uid;
+    std::memcpy(j->params, m->p, sizeof(m->p));
+    j->fixed_step = m->fixed_step;
+    j->attempt_cap = g_cap;
+    j->math_mode = g_math;
+    j->d_forc = g_forc.d_forc;
+    j->d_forc_col = g_forc.d_col;
+    j->forc_ld = g_forc.ld;
+    j->nforc = g_forc.nforc;
+    std::memcpy(j->forc_dt_hours, g_forc.dt_h, sizeof(g_forc.dt_h));
+    std::memcpy(j->forc_nT, g_forc.nT, sizeof(g_forc.nT));
+    return HLM_SUCCESS;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hlm_abi_version(void) { return HLM_ABI_VERSION; }
+const char* hlm_last_error(void) { return g_err; }
+
+int hlm_device_count(int* count)
+{
+    if (!count) return fail(HLM_ERR_INVALID_ARGUMENT, "count is NULL");
+    *count = 0;
+    hipError_t e = hipGetDeviceCount(count);
+    if (e != hipSuccess) {
+        *count = 0;
+        return fail(HLM_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e));
+    }
+    return HLM_SUCCESS;
+}
+
+int hlm_set_device(int device)
+{
+    HLM_HIP_TRY(hipSetDevice(device));
+    return HLM_SUCCESS;
+}
+
+int hlm_device_synchronize(void)
+{
+    HLM_HIP_TRY(hipDeviceSynchronize());
+    return HLM_SUCCESS;
+}
+
+int hlm_device_malloc(void** dptr, size_t bytes)
+{
+    if (!dptr) return fail(HLM_ERR_INVALID_ARGUMENT, "dptr is NULL");
+    *dptr = nullptr;
+    if (bytes == 0) return HLM_SUCCESS;
+    HLM_HIP_TRY(hipMalloc(dptr, bytes));
+    return HLM_SUCCESS;
+}
+
+int hlm_device_free(void* dptr)
+{
+    if (dptr) HLM_HIP_TRY(hipFree(dptr));
+    return HLM_SUCCESS;
+}
+
+int hlm_memcpy_h2d(void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return HLM_SUCCESS;
+    if (!dst || !src) return fail(HLM_ERR_INVALID_ARGUMENT, "NULL pointer in h2d copy");
+    HLM_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return HLM_SUCCESS;
+}
+
+int hlm_memcpy_d2h(void* dst, const void* src, size_t bytes)
+{
+    if (bytes == 0) return HLM_SUCCESS;
+    if (!dst || !src) return fail(HLM_ERR_INVALID_ARGUMENT, "NULL pointer in d2h copy");
+    HLM_HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return HLM_SUCCESS;
+}
+
+// ---- registry ------------------------------------------------------------------------
+int hlm_set_model_parameters(int uid, const double p[6])
+{
+    if (!p) return fail(HLM_ERR_INVALID_ARGUMENT, "p is NULL");
+    std::lock_guard<std::mutex> lk(g_mu);
+    ModelState* m = find_model(uid);
+    if (!m) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    if (!(p[0] > 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "initialStep must be > 0");
+    if (!(p[1] >= 0.0) || !(p[2] >= 0.0) || !(p[1] + p[2] > 0.0))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "rtol/atol must be >= 0 and not both 0");
+    if (!(p[4] > 0.0) || !(p[5] >= p[4]))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "need 0 < minScale <= maxScale");
+    std::memcpy(m->p, p, sizeof(m->p));
+    return HLM_SUCCESS;
+}
+
+int hlm_get_model_parameters(int uid, double p[6])
+{
+    if (!p) return fail(HLM_ERR_INVALID_ARGUMENT, "p is NULL");
+    std::lock_guard<std::mutex> lk(g_mu);
+    ModelState* m = find_model(uid);
+    if (!m) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    std::memcpy(p, m->p, sizeof(m->p));
+    return HLM_SUCCESS;
+}
+
+int hlm_set_fixed_step(int uid, double h)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    ModelState* m = find_model(uid);
+    if (!m) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    if (!(h >= 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "fixed step must be >= 0");
+    m->fixed_step = h;
+    return HLM_SUCCESS;
+}
+
+int hlm_set_attempt_cap(uint32_t cap)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_cap = cap ? cap : (1u << 24);
+    return HLM_SUCCESS;
+}
+
+int hlm_set_math_mode(int mode)
+{
+    if (mode != HLM_MATH_STRICT && mode != HLM_MATH_FAST)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "math mode %d", mode);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_math = mode;
+    return HLM_SUCCESS;
+}
+
+int hlm_set_forcings(const float* d_forc, const double* dt_hours, const uint64_t* nT, int nforc,
+                     int64_t ld, const int32_t* d_col)
+{
+    if (nforc < 0 || nforc > HLM_MAX_FORCINGS)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "nforc %d outside [0,%d]", nforc, HLM_MAX_FORCINGS);
+    if (nforc > 0 && (!d_forc || !dt_hours || !nT || ld <= 0))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "forcings need d_forc, dt_hours, nT and ld > 0");
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_forc = ForcingState{};
+    g_forc.d_forc = d_forc;
+    g_forc.d_col = d_col;
+    g_forc.ld = ld;
+    g_forc.nforc = nforc;
+    for (int k = 0; k < nforc; ++k) {
+        g_forc.dt_h[k] = dt_hours[k];
+        g_forc.nT[k] = nT[k];
+    }
+    return HLM_SUCCESS;
+}
+
+int hlm_clear_forcings(void)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_forc = ForcingState{};
+    return HLM_SUCCESS;
+}
+
+// ---- device-resident core --------------------------------------------------------------
+int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream)
+{
+    int rc = validate_job(job);
+    if (rc != HLM_SUCCESS) return rc;
+    if (job->num_systems == 0) return HLM_SUCCESS;
+    return launch(job, static_cast<hipStream_t>(hip_stream));
+}
+
+int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms)
+{
+    if (iters < 0 || (iters > 0 && !ms)) return fail(HLM_ERR_INVALID_ARGUMENT, "iters/ms");
+    int rc = validate_job(job);
+    if (rc != HLM_SUCCESS) return rc;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    hipEvent_t e0, e1;
+    HLM_HIP_TRY(hipEventCreate(&e0));
+    HLM_HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < iters; ++i) {
+        HLM_HIP_TRY(hipEventRecord(e0, s));
+        if (job->num_systems > 0) {
+            rc = launch(job, s);
+            if (rc != HLM_SUCCESS) break;
+        }
+        HLM_HIP_TRY(hipEventRecord(e1, s));
+        HLM_HIP_TRY(hipEventSynchronize(e1));
+        HLM_HIP_TRY(hipEventElapsedTime(&ms[i], e0, e1));
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
+int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs, int* lds_bytes,
+                    int* max_threads)
+{
+    KernelFn fn = pick(uid, math_mode, dense != 0, false);
+    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    hipFuncAttributes at;
+    HLM_HIP_TRY(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fn)));
+    if (vgprs) *vgprs = at.numRegs;
+    if (sgprs) *sgprs = 0;
+    if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
+    if (max_threads) *max_threads = at.maxThreadsPerBlock;
+    return HLM_SUCCESS;
+}
+
+// ---- three-phase host API ----------------------------------------------------------------
+int hlm_setup_gpu_buffers(const double* h_y0, int ns, const double* h_q, int nq, hlm_gpu_buffers* out)
+{
+    if (!out) return fail(HLM_ERR_INVALID_ARGUMENT, "out is NULL");
+    std::memset(out, 0, sizeof(*out));
+    if (ns < 0 || nq < 0) return fail(HLM_ERR_INVALID_ARGUMENT, "negative sizes");
+    if ((ns > 0 && !h_y0) || (nq > 0 && !h_q)) return fail(HLM_ERR_INVALID_ARGUMENT, "NULL host input");
+    out->num_systems = ns;
+    out->num_queries = nq;
+    const size_t b_state = sizeof(double) * (size_t)ns * HLM_NEQ;
+    const size_t b_q = sizeof(double) * (size_t)nq;
+    const size_t b_dense = b_state * (size_t)nq;
+    hipError_t e = hipSuccess;
+    auto alloc = [&](void** p, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMalloc(p, bytes);
+    };
+    alloc((void**)&out->d_y0_all, b_state);
+    alloc((void**)&out->d_y_final_all, b_state);
+    alloc((void**)&out->d_query_times, b_q);
+    alloc((void**)&out->d_dense_all, b_dense);
+    alloc((void**)&out->d_stiff, sizeof(int32_t) * (size_t)ns);
+    alloc((void**)&out->d_n_attempt, sizeof(uint32_t) * (size_t)ns);
+    alloc((void**)&out->d_n_accept, sizeof(uint32_t) * (size_t)ns);
+    if (e == hipSuccess && b_state) e = hipMemcpy(out->d_y0_all, h_y0, b_state, hipMemcpyHostToDevice);
+    if (e == hipSuccess && b_q) e = hipMemcpy(out->d_query_times, h_q, b_q, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(out->d_y0_all); (void)hipFree(out->d_y_final_all); (void)hipFree(out->d_query_times);
+        (void)hipFree(out->d_dense_all); (void)hipFree(out->d_stiff); (void)hipFree(out->d_n_attempt);
+        (void)hipFree(out->d_n_accept);
+        std::memset(out, 0, sizeof(*out));
+        return fail(HLM_ERR_HIP, "setup_gpu_buffers: %s", hipGetErrorString(e));
+    }
+    return HLM_SUCCESS;
+}
+
+int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double tf, const void* d_sp)
+{
+    if (!b) return fail(HLM_ERR_INVALID_ARGUMENT, "buffers are NULL");
+    hlm_device_job j;
+    std::memset(&j, 0, sizeof(j));
+    int rc = fill_job_from_registry(&j, uid);
+    if (rc != HLM_SUCCESS) return rc;
+    j.num_systems = b->num_systems;
+    j.num_queries = b->num_queries;
+    j.t0 = t0;
+    j.tf = tf;
+    j.d_y0 = b->d_y0_all;
+    j.d_query = b->d_query_times;
+    j.d_sp = d_sp;
+    j.d_y_final = b->d_y_final_all;
+    j.d_dense = b->d_dense_all;
+    j.d_stiff = b->d_stiff;
+    j.d_n_attempt = b->d_n_attempt;
+    j.d_n_accept = b->d_n_accept;
+    rc = hlm_rk45_integrate_device(&j, nullptr);
+    if (rc != HLM_SUCCESS) return rc;
+    HLM_HIP_TRY(hipDeviceSynchronize());  // rk45_api.hpp:150
+    return HLM_SUCCESS;
+}
+
+int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense, int32_t* h_stiff,
+                          uint32_t* h_n_attempt, uint32_t* h_n_accept)
+{
+    if (!b) return fail(HLM_ERR_INVALID_ARGUMENT, "buffers are NULL");
+    const size_t ns = (size_t)b->num_systems, nq = (size_t)b->num_queries;
+    hipError_t e = hipSuccess;
+    auto d2h = [&](void* dst, const void* src, size_t bytes) {
+        if (e == hipSuccess && dst && src && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    };
+    d2h(h_final, b->d_y_final_all, sizeof(double) * ns * HLM_NEQ);
+    d2h(h_dense, b->d_dense_all, sizeof(double) * ns * nq * HLM_NEQ);
+    d2h(h_stiff, b->d_stiff, sizeof(int32_t) * ns);
+    d2h(h_n_attempt, b->d_n_attempt, sizeof(uint32_t) * ns);
+    d2h(h_n_accept, b->d_n_accept, sizeof(uint32_t) * ns);
+    (void)hipFree(b->d_y0_all); (void)hipFree(b->d_y_final_all); (void)hipFree(b->d_query_times);
+    (void)hipFree(b->d_dense_all); (void)hipFree(b->d_stiff); (void)hipFree(b->d_n_attempt);
+    (void)hipFree(b->d_n_accept);
+    std::memset(b, 0, sizeof(*b));
+    if (e != hipSuccess) return fail(HLM_ERR_HIP, "retrieve_and_free: %s", hipGetErrorString(e));
+    return HLM_SUCCESS;
+}
+
+int hlm_run_rk45(int uid, const double* h_y0, int ns, double t0, double tf, const double* h_q, int nq,
+                 const void* d_sp, double* h_final, double* h_dense, int32_t* h_stiff,
+                 uint32_t* h_n_attempt, uint32_t* h_n_accept)
+{
+    hlm_gpu_buffers b;
+    int rc = hlm_setup_gpu_buffers(h_y0, ns, h_q, nq, &b);
+    if (rc != HLM_SUCCESS) return rc;
+    rc = hlm_launch_rk45_kernel(uid, &b, t0, tf, d_sp);
+    if (rc != HLM_SUCCESS) {
+        char keep[sizeof(g_err)];
+        std::memcpy(keep, g_err, sizeof(keep));
+        (void)hlm_retrieve_and_free(&b, nullptr, nullptr, nullptr, nullptr, nullptr);
+        std::memcpy(g_err, keep, sizeof(keep));
+        return rc;
+    }
+    return hlm_retrieve_and_free(&b, h_final, h_dense, h_stiff, h_n_attempt, h_n_accept);
+}
+
+}  // extern "C"

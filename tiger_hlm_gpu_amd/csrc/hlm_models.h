@@ -1,0 +1,157 @@
+// Device-side model plug-ins for the RK45 kernel (one struct per Model::UID).
+//
+// A device model provides
+//   UID, NF (how many forcings rhs reads), struct Local (per-system constants kept in
+//   VGPRs for the whole integration), load(sp, sys) and rhs<MATH>(P, y, F0, F1, dydt).
+// This is the device half of the reference's plug-in concept (Model::UID / SP_TYPE /
+// rhs, reference src/models/model_204.hpp:15-115); the host half is include/hlm/models/.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hlm_hip.h"
+
+namespace hlm {
+
+constexpr int MATH_STRICT = HLM_MATH_STRICT;
+constexpr int MATH_FAST = HLM_MATH_FAST;
+
+// x^(2/3) for the Manning term.  STRICT: OCML pow (<1 ulp, same call the reference makes
+// through libdevice).  FAST: cbrt(x)^2 -- x < 0 must stay NaN like pow() so that
+// fmin(1.0, NaN) == 1.0 keeps the reference's behaviour for a negative surface store
+// (SURVEY A.1 note 6).
+template <int MATH>
+__device__ __forceinline__ double pow_two_thirds(double x)
+{
+    if constexpr (MATH == MATH_STRICT) {
+        return pow(x, 2.0 / 3.0);
+    } else {
+        const double c = cbrt(x);
+        const double r = c * c;
+        return x < 0.0 ? __builtin_nan("") : r;
+    }
+}
+
+// ------------------------------------------------------------------------------------
+// Model 204: snow / static / surface / gravitational / aquifer stores.
+// Reference: src/models/model_204.hpp:43-114; parameter record
+// src/I_O/parameters_loader.hpp:19-37 (136-byte AoS, read once per system here).
+// ------------------------------------------------------------------------------------
+struct Model204Dev {
+    static constexpr int UID = HLM_UID_204;
+    static constexpr int NF = 2;  // F[0] = rainfall, F[1] = temperature (:82-83)
+
+    struct Local {
+        double infil, perco, Hu, L, A_h, alpha3, alpha4, melt_f, temp_thr;
+        double inv_n;       // 1.0 / n_mann   (same operation as :103, hoisted: bit-identical)
+        double sqrt_slope;  // sqrt(slope)    (idem)
+        // FAST mode only: reciprocals replacing the per-call divides
+        double inv_Hu, L_over_A60, inv_alpha3, inv_alpha4;
+    };
+
+    template <int MATH>
+    static __device__ __forceinline__ Local load(const void* sp_base, int sys)
+    {
+        const hlm_spatial_params& S = static_cast<const hlm_spatial_params*>(sp_base)[sys];
+        Local P;
+        P.infil = S.infil;
+        P.perco = S.perco;
+        P.Hu = S.Hu;
+        P.L = S.L;
+        P.A_h = S.A_h;
+        P.alpha3 = S.alpha3;
+        P.alpha4 = S.alpha4;
+        P.melt_f = S.melt_f;
+        P.temp_thr = S.temp_thr;
+        P.inv_n = 1.0 / S.n_mann;
+        P.sqrt_slope = sqrt(S.slope);
+        if constexpr (MATH == MATH_FAST) {
+            P.inv_Hu = 1.0 / S.Hu;
+            P.L_over_A60 = S.L / S.A_h * 60.0;
+            // the reference drains only when alpha >= 1 (:110,:113)
+            P.inv_alpha3 = S.alpha3 >= 1.0 ? 1.0 / S.alpha3 : 0.0;
+            P.inv_alpha4 = S.alpha4 >= 1.0 ? 1.0 / S.alpha4 : 0.0;
+        } else {
+            P.inv_Hu = P.L_over_A60 = P.inv_alpha3 = P.inv_alpha4 = 0.0;
+        }
+        return P;
+    }
+
+    template <int MATH>
+    static __device__ __forceinline__ void rhs(const Local& P, const double (&y)[HLM_NEQ],
+                                               double rainfall, double temperature,
+                                               double (&dydt)[HLM_NEQ])
+    {
+        const double h_snow = y[0], h_stat = y[1], h_surf = y[2], h_grav = y[3], h_aq = y[4];
+
+        // snow (:87-91)
+        const double snowmelt =
+            (temperature >= P.temp_thr) ? fmin(h_snow, temperature * P.melt_f) : 0.0;
+        const double x1 = rainfall + snowmelt;
+        dydt[0] = rainfall - snowmelt;
+
+        // static (:94-98)
+        const double x2 = fmax(0.0, x1 + h_stat - P.Hu);
+        const double d1 = x1 - x2;
+        const double Emax = fmin(0.1 * temperature, h_stat);
+        double s;
+        if constexpr (MATH == MATH_FAST) s = h_stat * P.inv_Hu; else s = h_stat / P.Hu;
+        dydt[1] = d1 - s * Emax;
+
+        // surface (:101-105).  pow(0, 2/3) == 0 exactly, hence alfa2 == 0, w == 0 and
+        // dydt[2] == d2 - 0: a dry surface store skips the transcendental bit-exactly;
+        // a wave whose 64 hillslopes are all dry skips it entirely (s_cbranch_execz).
+        const double x3 = fmin(x2, P.infil);
+        const double d2 = x2 - x3;
+        double out2 = d2;
+        if (h_surf != 0.0) {
+            const double alfa2 = P.inv_n * pow_two_thirds<MATH>(h_surf) * P.sqrt_slope;
+            double w;
+            if constexpr (MATH == MATH_FAST) w = fmin(1.0, alfa2 * P.L_over_A60);
+            else w = fmin(1.0, alfa2 * P.L / P.A_h * 60.0);
+            out2 = d2 - h_surf * w;
+        }
+        dydt[2] = out2;
+
+        // gravitational (:108-110) and aquifer (:113)
+        const double x4 = fmin(x3, P.perco);
+        const double d3 = x3 - x4;
+        if constexpr (MATH == MATH_FAST) {
+            dydt[3] = d3 - h_grav * P.inv_alpha3;
+            dydt[4] = x4 - h_aq * P.inv_alpha4;
+        } else {
+            dydt[3] = d3 - (P.alpha3 >= 1.0 ? h_grav / P.alpha3 : 0.0);
+            dydt[4] = x4 - (P.alpha4 >= 1.0 ? h_aq / P.alpha4 : 0.0);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// DummyModel: the 5-equation linear test system of the reference's README; its source
+// is absent from the tree, the RHS is the notebook's (model_dummy_python.ipynb:65-89,
+// the code cell: I2 = 0.6*H1).  No parameters, no forcing.
+// ------------------------------------------------------------------------------------
+struct DummyDev {
+    static constexpr int UID = HLM_UID_DUMMY;
+    static constexpr int NF = 0;
+    struct Local {};
+
+    template <int MATH>
+    static __device__ __forceinline__ Local load(const void*, int) { return Local{}; }
+
+    template <int MATH>
+    static __device__ __forceinline__ void rhs(const Local&, const double (&y)[HLM_NEQ],
+                                               double, double, double (&dydt)[HLM_NEQ])
+    {
+        const double H0 = y[0], H1 = y[1], H3 = y[3];
+        const double Y0 = 0.5 * H0, X2 = 0.3 * H1, I2 = 0.6 * H1, I3 = 0.4 * H3;
+        dydt[0] = 1.0 - Y0;
+        dydt[1] = 1.2 + Y0 - X2 - 0.4 - I2;
+        dydt[2] = X2 - 0.2;
+        dydt[3] = I2 - I3 - 0.3;
+        dydt[4] = I3 - 0.1;
+    }
+};
+
+}  // namespace hlm

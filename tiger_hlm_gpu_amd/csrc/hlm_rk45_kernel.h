@@ -1,0 +1,315 @@
+// The hot path: per-hillslope adaptive Dormand-Prince RK45 with dense output and
+// stiffness flagging, one wavefront lane per ODE system (CDNA4 / gfx950, wave64).
+//
+// Restates reference src/solver/rk45_kernel.cu:17-176 (loop), rk45_step_dense.cuh:33-145
+// (step), :171-244 (dense interpolant), event_detector.cuh:46-53 (slope-jump norm).
+// See DESIGN.md "Kernel" for the register/LDS/HBM plan.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hlm_hip.h"
+#include "hlm_models.h"
+#include "hlm_tableau.h"
+
+namespace hlm {
+
+constexpr int NEQ = HLM_NEQ;
+constexpr int WAVE = 64;
+
+// Kernel arguments (kernarg segment -> SGPRs; everything here is wave-uniform).
+struct Rk45Args {
+    const double* y0;       // [ns][5]
+    const double* query;    // [nq]
+    const void* sp;         // [ns] x 136 B
+    const float* forc;      // [sum nT][ld]
+    const int32_t* forc_col;
+    long long forc_ld;
+    double forc_dtmin[2];          // dt_hours * 60 (rk45_kernel.cu:90), only the NF<=2 used rows
+    unsigned long long forc_nT[2];
+    unsigned long long forc_base[2];  // sum_{k<j} nT_k * ld (rk45_kernel.cu:101-104)
+    int nforc;
+    int ns, nq;
+    double t0, tf;
+    double h0, rtol, atol, safety, min_scale, max_scale;  // Model::Parameters
+    double fixed_step;
+    uint32_t cap;
+    double* y_final;     // [ns][5]
+    double* dense;       // [ns][nq][5]
+    int32_t* stiff;
+    uint32_t* n_attempt;
+    uint32_t* n_accept;
+};
+
+// y + sum c_j * k_j accumulated left to right with one FMA per term, the order the
+// reference's "acc += h*a*k" loop uses (rk45_step_dense.cuh:96-101).
+__device__ __forceinline__ double lc(double acc) { return acc; }
+template <class... Rest>
+__device__ __forceinline__ double lc(double acc, double c, double k, Rest... rest)
+{
+    return lc(__builtin_fma(c, k, acc), rest...);
+}
+
+// 1/x for the FAST error ratio: v_rcp_f64 seed (~2^-26) + one Newton step.
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+
+// (1/x)^(1/5) for the step-size controller, rk45_kernel.cu:151,156:
+// pow(1.0/(err+1e-16), 0.2).  STRICT keeps the divide and OCML pow.
+template <int MATH>
+__device__ __forceinline__ double inv_fifth_root(double x)
+{
+    if constexpr (MATH == MATH_STRICT) {
+        return pow(1.0 / x, 0.2);
+    } else {
+        // f32 exp2/log2 seed for z = x^(-1/5), then two Newton steps on z^-5 = x:
+        // z <- z * (6 - x z^5) / 5.  x is in [1e-16, huge]; the seed is good to ~1e-6,
+        // each step squares the relative error.
+        const float xf = (float)x;
+        double z = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(xf));
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double z2 = z * z;
+            const double z5 = z2 * z2 * z;
+            z = z * __builtin_fma(-x, z5, 6.0) * 0.2;
+        }
+        return z;
+    }
+}
+
+// zero-order-hold forcing index, rk45_kernel.cu:90-98
+__device__ __forceinline__ unsigned long long forcing_index(double t, double dtmin,
+                                                            unsigned long long nT)
+{
+    const double r = t / dtmin;
+    return (r < 0.0) ? 0ull : (r >= (double)nT ? nT - 1ull : (unsigned long long)r);
+}
+
+template <class Model, int MATH, bool DENSE, bool FIXED>
+__global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
+{
+    using namespace dp;
+    // XCD-aware block -> hillslope-chunk map: workgroups are dealt round-robin over the
+    // 8 XCDs, so give each XCD one contiguous range of hillslopes (neighbouring
+    // hillslopes share forcing rows -> they hit in that XCD's L2).  Bijective for any
+    // grid size (cdna guide T1).
+    const unsigned nblk = gridDim.x, orig = blockIdx.x;
+    const unsigned xcd = orig & 7u, qd = nblk >> 3, rm = nblk & 7u;
+    const unsigned blk = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + (orig >> 3);
+    const int sys = (int)(blk * WAVE + threadIdx.x);
+    if (sys >= A.ns) return;
+
+    const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
+
+    double y[NEQ];
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
+
+    // forcing column of this hillslope and the currently held samples
+    [[maybe_unused]] size_t fcol = 0;
+    [[maybe_unused]] unsigned long long fidx0 = ~0ull, fidx1 = ~0ull;
+    double F0 = 0.0, F1 = 0.0;
+    const bool use_f0 = Model::NF > 0 && A.nforc > 0;
+    const bool use_f1 = Model::NF > 1 && A.nforc > 1;
+    if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
+
+    double t = A.t0;
+    double h = FIXED ? A.fixed_step : A.h0;
+    const double tf = A.tf;
+    int next_q = 0;
+    double* dense_row = nullptr;
+    double tq_next = 0.0;
+    if constexpr (DENSE) {
+        dense_row = A.dense + (size_t)sys * (size_t)A.nq * NEQ;
+        // queries at or before t0 are never produced (rk45_kernel.cu:141): their slot is 0
+        while (next_q < A.nq && A.query[next_q] <= t) {
+#pragma unroll
+            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * NEQ + c] = 0.0;
+            ++next_q;
+        }
+        tq_next = next_q < A.nq ? A.query[next_q] : __builtin_inf();
+    }
+
+    int reject_count = 0;
+    int status = HLM_SYS_OK;
+    uint32_t n_attempt = 0, n_accept = 0;
+    bool t_moved = true;  // forcing must be (re)sampled at the step's start time
+
+    while (t < tf && status == HLM_SYS_OK) {
+        if (n_attempt >= A.cap) { status = HLM_SYS_CAPPED; break; }
+        if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
+
+        // forcing gather at the START time of the step, held for all stages
+        // (rk45_kernel.cu:85-106).  t only changes on an accepted step, so the index is
+        // recomputed then, and the 4-byte load is issued only when the index moved.
+        if constexpr (Model::NF > 0) {
+            if (t_moved) {
+                if (use_f0) {
+                    const unsigned long long i0 = forcing_index(t, A.forc_dtmin[0], A.forc_nT[0]);
+                    if (i0 != fidx0) {
+                        fidx0 = i0;
+                        F0 = (double)A.forc[A.forc_base[0] + i0 * (size_t)A.forc_ld + fcol];
+                    }
+                }
+                if (use_f1) {
+                    const unsigned long long i1 = forcing_index(t, A.forc_dtmin[1], A.forc_nT[1]);
+                    if (i1 != fidx1) {
+                        fidx1 = i1;
+                        F1 = (double)A.forc[A.forc_base[1] + i1 * (size_t)A.forc_ld + fcol];
+                    }
+                }
+                t_moved = false;
+            }
+        }
+
+        ++n_attempt;
+        // ---- 7 stages (no FSAL: k0 is recomputed every attempt, rk45_kernel.cu:114) ----
+        double k0[NEQ], k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
+        Model::template rhs<MATH>(P, y, F0, F1, k0);
+        {
+            const double a10 = h * A10;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a10, k0[i]);
+            Model::template rhs<MATH>(P, yt, F0, F1, k1);
+        }
+        {
+            const double a20 = h * A20, a21 = h * A21;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a20, k0[i], a21, k1[i]);
+            Model::template rhs<MATH>(P, yt, F0, F1, k2);
+        }
+        {
+            const double a30 = h * A30, a31 = h * A31, a32 = h * A32;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]);
+            Model::template rhs<MATH>(P, yt, F0, F1, k3);
+        }
+        {
+            const double a40 = h * A40, a41 = h * A41, a42 = h * A42, a43 = h * A43;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i)
+                yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]);
+            Model::template rhs<MATH>(P, yt, F0, F1, k4);
+        }
+        {
+            const double a50 = h * A50, a51 = h * A51, a52 = h * A52, a53 = h * A53, a54 = h * A54;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i)
+                yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
+            Model::template rhs<MATH>(P, yt, F0, F1, k5);
+        }
+        const double hb0 = h * B0, hb2 = h * B2, hb3 = h * B3, hb4 = h * B4, hb5 = h * B5;
+        {
+            // stage 6 state: row 6 of a is b (rk45_step_dense.cuh:66-68)
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i)
+                yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
+            Model::template rhs<MATH>(P, yt, F0, F1, k6);
+        }
+        // 5th-order solution (rk45_step_dense.cuh:111-117).  b[6] = 0, so it is the same
+        // chain of operations as the stage-6 state: identical bits, reuse it.
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) yn[i] = yt[i];
+
+        [[maybe_unused]] double fac = 1.0;
+        if constexpr (!FIXED) {
+            // scaled infinity-norm error (rk45_step_dense.cuh:123-142); "ratio > max"
+            // comparisons ignore NaN components exactly like the reference.
+            const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5,
+                         he6 = h * E6;
+            double err = 0.0;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) {
+                const double y_err =
+                    lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                const double ymax = fmax(fabs(y[i]), fabs(yn[i]));
+                const double tol = __builtin_fma(A.rtol, ymax, A.atol);
+                double ratio;
+                if constexpr (MATH == MATH_FAST) ratio = fabs(y_err) * fast_rcp(tol);
+                else ratio = fabs(y_err / tol);
+                if (ratio > err) err = ratio;
+            }
+            // step-size factor shared by the accept and the reject branch
+            // (rk45_kernel.cu:151,156)
+            fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);
+
+            if (err <= 1.0) {
+                reject_count = 0;
+                // slope-jump detector (rk45_kernel.cu:132-136, event_detector.cuh:46-53)
+                double jump = 0.0;
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) {
+                    const double f = fabs(k0[i] - k1[i]);
+                    if (f > jump) jump = f;
+                }
+                if (jump > SLOPE_JUMP_THRESH) {
+                    h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
+                    continue;
+                }
+            } else {
+                // rejected (rk45_kernel.cu:153-163)
+                ++reject_count;
+                double f = fmin(fac, 1.0);
+                f = fmin(fmax(f, A.min_scale), A.max_scale);
+                h *= f;
+                if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) status = HLM_SYS_STIFF;
+                continue;
+            }
+        }
+
+        // ---- accepted step (always, in fixed-step mode) ----
+        const double t1 = t + h;
+        if constexpr (DENSE) {
+            if (tq_next <= t1) {
+                // Q_m = sum_j P[j][m] k_j once per step (the reference recomputes the same
+                // values for every query, rk45_step_dense.cuh:222-231); Q_0 = k0.
+                double Q1[NEQ], Q2[NEQ], Q3[NEQ];
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) {
+                    Q1[i] = lc(P01 * k0[i], P21, k2[i], P31, k3[i], P41, k4[i], P51, k5[i], P61, k6[i]);
+                    Q2[i] = lc(P02 * k0[i], P22, k2[i], P32, k3[i], P42, k4[i], P52, k5[i], P62, k6[i]);
+                    Q3[i] = lc(P03 * k0[i], P23, k2[i], P33, k3[i], P43, k4[i], P53, k5[i], P63, k6[i]);
+                }
+                do {
+                    const double th = (tq_next - t) / h;  // rk45_kernel.cu:142
+                    const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
+                    double* o = dense_row + (size_t)next_q * NEQ;
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) {
+                        const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
+                        o[i] = __builtin_fma(h, poly, y[i]);  // rk45_step_dense.cuh:235-243
+                    }
+                    ++next_q;
+                    tq_next = next_q < A.nq ? A.query[next_q] : __builtin_inf();
+                } while (tq_next <= t1);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) y[i] = yn[i];
+        t = t1;
+        t_moved = true;
+        ++n_accept;
+        if constexpr (FIXED) h = A.fixed_step;
+        else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+    }
+
+    if (A.n_attempt) A.n_attempt[sys] = n_attempt;
+    if (A.n_accept) A.n_accept[sys] = n_accept;
+    const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170
+    A.stiff[sys] = flagged ? status : HLM_SYS_OK;
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
+    if constexpr (DENSE) {
+        // a flagged system never reaches its remaining queries: zero rows
+        for (; next_q < A.nq; ++next_q) {
+#pragma unroll
+            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * NEQ + c] = 0.0;
+        }
+    }
+}
+
+}  // namespace hlm

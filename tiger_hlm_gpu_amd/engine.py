@@ -1,0 +1,98 @@
+"""Device-resident driver for one GPU's shard of hillslopes.
+
+Holds the shard's inputs and outputs in HBM as torch tensors (torch = allocator and
+stream plumbing only) and runs the HIP path through the C ABI
+(hlm_rk45_integrate_device).  Used by bench.py, __graft_entry__.smoke() and the GPU
+tests; raises if the HIP library or a device is missing -- there is no CPU fallback.
+"""
+import numpy as np
+import torch
+
+from . import _lib, api
+from .models import Parameters, SP_DTYPE
+
+
+class ShardEngine:
+    def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
+                 math_mode=_lib.MATH_STRICT, fixed_step=0.0, attempt_cap=0):
+        _lib.lib()  # fail loudly if the extension is not built
+        if not torch.cuda.is_available():
+            raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
+        self.model = model
+        self.device = torch.device(device)
+        self.t0, self.tf = float(t0), float(tf)
+        self.params = params if params is not None else Parameters()
+        self.math_mode, self.fixed_step, self.attempt_cap = math_mode, fixed_step, attempt_cap
+        y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
+        self.ns = y0.shape[0]
+        dev = self.device
+        self.y0 = torch.from_numpy(y0).to(dev)
+        self.sp = None
+        if sp is not None:
+            sp = np.ascontiguousarray(sp, dtype=SP_DTYPE)
+            assert sp.shape == (self.ns,)
+            self.sp = torch.from_numpy(sp.view(np.uint8).reshape(self.ns, SP_DTYPE.itemsize)).to(dev)
+        self.query = None
+        if query is not None and len(query) > 0:
+            self.query = torch.from_numpy(np.ascontiguousarray(query, dtype=np.float64)).to(dev)
+        self.nq = 0 if self.query is None else self.query.numel()
+        self.forc = self.forc_col = None
+        self.forc_dt, self.forc_nT, self.forc_ld = (), (), 0
+        self.y_final = torch.empty((self.ns, model.N_EQ), dtype=torch.float64, device=dev)
+        self.dense = (torch.empty((self.ns, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
+                      if self.nq else None)
+        self.stiff = torch.empty(self.ns, dtype=torch.int32, device=dev)
+        self.n_attempt = torch.empty(self.ns, dtype=torch.int32, device=dev)  # uint32 bits
+        self.n_accept = torch.empty(self.ns, dtype=torch.int32, device=dev)
+
+    # -- forcings ------------------------------------------------------------------------
+    def set_forcings_per_stream(self, block, dt_hours, nT):
+        """Reference layout float[sum nT][ns] (main.cpp:527-549); ``block`` may be a numpy
+        array or a CUDA tensor already in HBM."""
+        if not torch.is_tensor(block):
+            block = torch.from_numpy(np.ascontiguousarray(block, dtype=np.float32))
+        self.forc = block.to(self.device).contiguous().view(-1)
+        assert self.forc.numel() == sum(nT) * self.ns
+        self.forc_dt, self.forc_nT, self.forc_ld, self.forc_col = tuple(dt_hours), tuple(nT), self.ns, None
+
+    def set_forcings_per_cell(self, tables, cells, dt_hours, nT):
+        """Compact per-grid-cell tables float[sum nT][ncell] + column index per hillslope."""
+        tab = np.concatenate([np.asarray(t, dtype=np.float32) for t in tables], axis=0)
+        self.forc = torch.from_numpy(np.ascontiguousarray(tab)).to(self.device).view(-1)
+        self.forc_ld = tab.shape[1]
+        self.forc_col = torch.from_numpy(np.ascontiguousarray(cells, dtype=np.int32)).to(self.device)
+        self.forc_dt, self.forc_nT = tuple(dt_hours), tuple(nT)
+
+    def expand_forcings_on_device(self, tables, cells, dt_hours, nT):
+        """Build the reference's per-stream layout in HBM from per-cell tables (what
+        main.cpp:541-548 does on the host)."""
+        cols = torch.from_numpy(np.ascontiguousarray(cells, dtype=np.int64)).to(self.device)
+        parts = [torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).to(self.device).index_select(1, cols)
+                 for t in tables]
+        self.set_forcings_per_stream(torch.cat(parts, dim=0), dt_hours, nT)
+
+    # -- run -------------------------------------------------------------------------------
+    def job(self):
+        return api.make_device_job(
+            self.model, y0=self.y0, t0=self.t0, tf=self.tf, query=self.query, sp=self.sp,
+            forc=self.forc, forc_dt_hours=self.forc_dt, forc_nT=self.forc_nT, forc_ld=self.forc_ld,
+            forc_col=self.forc_col, params=self.params, fixed_step=self.fixed_step,
+            attempt_cap=self.attempt_cap, math_mode=self.math_mode, y_final=self.y_final,
+            dense=self.dense, stiff=self.stiff, n_attempt=self.n_attempt, n_accept=self.n_accept)
+
+    def integrate(self, stream=None):
+        """Enqueue one pass of the hot path on ``stream`` (default: torch's current stream)."""
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        api.integrate_device(self.job(), s)
+
+    def total_attempts(self):
+        return int(self.n_attempt.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+
+    def results(self):
+        """Host copies: dict(y_final[ns,5], dense[ns,nq,5] or None, stiff, n_attempt, n_accept)."""
+        torch.cuda.synchronize(self.device)
+        u32 = lambda t: t.cpu().numpy().view(np.uint32)
+        return {"y_final": self.y_final.cpu().numpy(),
+                "dense": None if self.dense is None else self.dense.cpu().numpy(),
+                "stiff": self.stiff.cpu().numpy(), "n_attempt": u32(self.n_attempt),
+                "n_accept": u32(self.n_accept)}

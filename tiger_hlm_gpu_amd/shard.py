@@ -1,0 +1,43 @@
+"""Hillslope sharding across the GPUs of one node + the end-of-run gather.
+
+The path is embarrassingly parallel (no channel routing exists in the reference:
+``next_stream`` is loaded but never used), so each rank integrates one contiguous slice
+and there is NO collective during integration.  The slice rule is the reference's
+rank-0 split, src/main.cpp:275-307 (``baseChunk + (r <= remainder)``), with every rank
+owning a GPU (the reference keeps rank 0 idle).  The only exchange is the gather of
+final states / flags / step counters to rank 0 (RCCL over xGMI when the backend is
+"nccl"; "gloo" in the CPU tests).
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(total, world_size, rank):
+    """(start, count) of rank's contiguous slice: first ``total % world_size`` ranks get
+    one extra row (main.cpp:275-307)."""
+    base, rem = divmod(int(total), int(world_size))
+    count = base + (1 if rank < rem else 0)
+    start = rank * base + min(rank, rem)
+    return start, count
+
+
+def gather_to_root(local, total, group=None, root=0):
+    """Gather per-rank slices (dim 0 = hillslopes of this rank, in shard_bounds order)
+    to ``root``.  Returns the [total, ...] tensor on root, None elsewhere.  Slices may
+    differ by one row, so they are padded to the largest slice for the collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    counts = [shard_bounds(total, world, r)[1] for r in range(world)]
+    cmax = max(counts)
+    pad = local
+    if local.shape[0] != cmax:
+        pad = torch.zeros((cmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
+    pad = pad.contiguous()
+    if rank == root:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.gather(pad, gather_list=bufs, dst=root, group=group)
+        return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+    dist.gather(pad, gather_list=None, dst=root, group=group)
+    return None
