@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Headline benchmark: hillslope-ODE-steps/s of the per-hillslope RK45 path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" of this harness is ONE PASS of the hot path (the whole adaptive integration of
+every hillslope of the shard over the whole time window) on inputs already resident in
+HBM.  The metric counts attempted RK45 steps (accepted + rejected + slope-jump-discarded,
+7 RHS evaluations each) summed over all hillslopes of all ranks, divided by wall time.
+
+Workload (BASELINE.json configs[2]): Model 204, 1 000 000 synthetic
+hillslopes PER GPU (weak scaling; contiguous shards, no data-path collective), hourly
+precipitation + daily 2 m temperature over 30 days on a 32x32 forcing grid expanded to the
+reference's per-stream device layout, rtol 1e-6, atol 1e-9, initialStep 0.01, no dense
+output.  At the end of every pass the final states, flags and step counters are gathered
+to rank 0 (RCCL over xGMI) -- the only exchange of the path.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+import tiger_hlm_gpu_amd as H
+from tiger_hlm_gpu_amd import synth
+from tiger_hlm_gpu_amd.engine import ShardEngine
+from tiger_hlm_gpu_amd.shard import gather_to_root, shard_bounds
+
+# SURVEY 8d / BASELINE.md section 3: algorithmic work per unit
+F_STEP_204 = 606.0        # FP64 flops per attempted step, Model 204
+F_DENSE_Q = 280.0         # per accepted step that contains a query (Q = P^T k)
+F_DENSE_EVAL = 45.0       # per query
+B_SYS = 176.0             # y0 40 + 11 used params 88 + final 40 + stiff 4 + counter 4
+PEAK_HBM_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+PEAK_FP64_VALU_TFLOPS = 78.6  # = 1/2 of the 157.3 TF FP32 vector peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--ns-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--days", type=int, default=30)
+    ap.add_argument("--math", choices=["strict", "fast"], default="fast")
+    ap.add_argument("--layout", choices=["per-stream", "per-cell"], default="per-stream")
+    ap.add_argument("--dense-stride", type=float, default=0.0,
+                    help="minutes between dense queries (0 = no dense output)")
+    ap.add_argument("--no-variants", action="store_true", help="skip the wet-surface variant pass")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    return ap.parse_args()
+
+
+def usable_cores():
+    """CPU threads this process may really use (affinity mask and cgroup quota)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
+
+
+def build_engine(args, rank, world, wet, math=None):
+    ns = args.ns_per_gpu
+    total = ns * world
+    start, count = shard_bounds(total, world, rank)
+    sp = synth.model204_params(start, count)
+    y0 = synth.model204_y0(count, wet_surface=wet)
+    cells = synth.cell_of_system(start, count)
+    pr, t2m, dt, nT = synth.forcing_tables(days=args.days)
+    tf = args.days * 1440.0
+    q = synth.minute_queries(0.0, tf, args.dense_stride) if args.dense_stride > 0 else None
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q,
+                      math_mode=H.MATH_FAST if (math or args.math) == "fast" else H.MATH_STRICT,
+                      device=f"cuda:{torch.cuda.current_device()}")
+    if args.layout == "per-stream":
+        eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    else:
+        eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+    return eng, total
+
+
+def one_pass(eng, total, world):
+    """The hot path over one batch + the end-of-run gather (the path's only exchange)."""
+    eng.integrate()
+    if world > 1:
+        gather_to_root(eng.y_final, total)
+        gather_to_root(eng.stiff, total)
+        gather_to_root(eng.n_attempt, total)
+
+
+def timed_passes(eng, total, world, warmup, steps):
+    dev = eng.device
+    for _ in range(warmup):
+        one_pass(eng, total, world)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    # HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for i in range(steps):
+        ev[i][0].record()
+        eng.integrate()
+        ev[i][1].record()
+        if world > 1:
+            gather_to_root(eng.y_final, total)
+            gather_to_root(eng.stiff, total)
+            gather_to_root(eng.n_attempt, total)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    wall = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    if world > 1:
+        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        wall = float(w.item())
+    return wall, kernel_ms
+
+
+def cpu_baseline(args):
+    """The oracle (CPU restatement, kind "port") on a bounded sample of the SAME workload:
+    chunks of 2048 hillslopes of the dry C3 shard until ~cpu_seconds of CPU work."""
+    from oracle import oracle as O
+    O.build()
+    cores = usable_cores()
+    pr, t2m, dt, nT = synth.forcing_tables(days=args.days)
+    tf = args.days * 1440.0
+    chunk, done, steps, t_used = 2048, 0, 0, 0.0
+    while t_used < args.cpu_seconds and done < 64 * chunk:
+        sp = synth.model204_params(done, chunk)
+        cells = synth.cell_of_system(done, chunk)
+        forc = synth.expand_per_stream(pr, t2m, cells)
+        y0 = synth.model204_y0(chunk)
+        t = time.perf_counter()
+        r = O.run(O.UID_204, y0, 0.0, tf, sp=sp, forc=forc, forc_dt_h=dt, forc_nT=nT, nthreads=cores)
+        t_used += time.perf_counter() - t
+        steps += int(r["n_attempt"].astype(np.int64).sum())
+        done += chunk
+    return {"value": steps / t_used, "unit": "hillslope-ODE-steps/s", "cores": cores, "kind": "port",
+            "sample": f"first {done} hillslopes of the same C3 shard, {args.days} days, "
+                      f"{steps} attempted steps in {t_used:.1f} s (oracle/hlm_oracle.c, gcc -O2 -fopenmp)"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    eng, total = build_engine(args, rank, world, wet=False)
+    wall, kernel_ms = timed_passes(eng, total, world, args.warmup, args.steps)
+    attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=eng.device)
+    flagged = torch.tensor([float((eng.stiff != 0).sum().item())], dtype=torch.float64, device=eng.device)
+    if world > 1:
+        dist.all_reduce(attempts)
+        dist.all_reduce(flagged)
+    attempts_all = float(attempts.item())          # over all ranks, per pass
+    value = attempts_all * args.steps / wall
+    ms_per_step = 1e3 * wall / args.steps
+
+    # dominant (only) kernel on this rank: rk45_multi_kernel<Model204Dev,...>
+    k_ms = float(np.mean(kernel_ms))
+    local_attempts = eng.total_attempts()
+    nq = eng.nq
+    forc_bytes = 4.0 * sum(eng.forc_nT) * (eng.ns if args.layout == "per-stream" else eng.forc_ld)
+    algo_bytes = eng.ns * B_SYS + forc_bytes + 40.0 * eng.ns * nq
+    n_accept = int(eng.n_accept.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+    algo_flops = local_attempts * F_STEP_204 + (F_DENSE_EVAL * eng.ns * nq if nq else 0.0) \
+        + (F_DENSE_Q * min(n_accept, eng.ns * nq) if nq else 0.0)
+    hbm_gbs = algo_bytes / (k_ms * 1e-3) / 1e9
+    valu_tf = algo_flops / (k_ms * 1e-3) / 1e12
+
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "hillslope-ODE-steps/sec", "value": value, "unit": "hillslope-ODE-steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "C3: Model 204, %d hillslopes/GPU (%d total), %d-day window, hourly pr + daily t2m "
+                               "on a 32x32 grid (%s layout), rtol 1e-6 atol 1e-9 h0 0.01, %s, math=%s"
+                               % (eng.ns, total, args.days, args.layout,
+                                  "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})",
+                                  args.math),
+                   "hillslopes_per_gpu": eng.ns, "parallelism": f"shard{world}"},
+        # The kernel is an FP64 per-lane ODE integrator: its binding roofline is the FP64
+        # vector ALU, not HBM and not MFMA (north_star: "no MFMA").  Both are reported:
+        # "roofline" = HBM as BASELINE.json's north_star asks (algorithmic bytes / kernel
+        # time), "roofline_valu_fp64" = the compute roofline that actually bounds it.
+        "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                     "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_ms,
+                     "kernel": "hlm::rk45_multi_kernel<Model204Dev>"},
+        "roofline_valu_fp64": {"bound": "valu_fp64", "achieved": valu_tf, "peak": PEAK_FP64_VALU_TFLOPS,
+                               "unit": "TFLOP/s", "frac": valu_tf / PEAK_FP64_VALU_TFLOPS,
+                               "algorithmic_flops_per_step": F_STEP_204},
+        "attempts_per_pass": attempts_all, "attempts_per_hillslope": attempts_all / total,
+        "flagged_fraction": float(flagged.item()) / total, "kernel_ms_each": kernel_ms,
+    }
+
+    if not args.no_variants and rank == 0 and world == 1:
+        # extra single passes of the same shard: wet surface store (the Manning x^(2/3)
+        # term live in all 7 stages of every step) and the other math mode
+        del eng
+        torch.cuda.empty_cache()
+        other = "strict" if args.math == "fast" else "fast"
+        for name, wet, math in (("variant_wet_surface", True, args.math),
+                                ("variant_%s_math" % other, False, other),
+                                ("variant_%s_math_wet_surface" % other, True, other)):
+            engv, _ = build_engine(args, rank, world, wet=wet, math=math)
+            wallv, kms = timed_passes(engv, total, 1, 1, 1)
+            av = engv.total_attempts()
+            out[name] = {"value": av / wallv, "unit": "hillslope-ODE-steps/s", "kernel_ms": kms[0], "math": math,
+                         "attempts_per_hillslope": av / engv.ns,
+                         "flagged_fraction": float((engv.stiff != 0).sum().item()) / engv.ns,
+                         "valu_fp64_frac": av * F_STEP_204 / (kms[0] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS}
+            del engv
+            torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args)
+        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

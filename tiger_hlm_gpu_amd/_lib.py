@@ -96,6 +96,14 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} not found: build the HIP extension first "
                 "(python -c 'import __graft_entry__ as g; g.build()' or make -C tiger_hlm_gpu_amd/csrc)")
+        # torch bundles its own libamdhip64/libhsa-runtime64.  Whichever HIP runtime is
+        # mapped first serves every later DT_NEEDED of that soname, and two runtimes in one
+        # process cannot both own the device: load torch's first so that the library and
+        # torch (device memory, streams, torch.distributed) share ONE runtime.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)  # AttributeError here = header/library mismatch

@@ -17,18 +17,33 @@ namespace hlm {
 constexpr int MATH_STRICT = HLM_MATH_STRICT;
 constexpr int MATH_FAST = HLM_MATH_FAST;
 
-// x^(2/3) for the Manning term.  STRICT: OCML pow (<1 ulp, same call the reference makes
-// through libdevice).  FAST: cbrt(x)^2 -- x < 0 must stay NaN like pow() so that
-// fmin(1.0, NaN) == 1.0 keeps the reference's behaviour for a negative surface store
-// (SURVEY A.1 note 6).
+// x^(2/3) for the Manning term (model_204.hpp:103).
+// STRICT: OCML pow (<1 ulp; the reference makes the same call through libdevice).
+// FAST:   x * x^(-1/3) with w = x^(-1/3) from a division-free Newton iteration
+//         w <- w (4 - x w^3) / 3 (quadratic; relative error e -> 2 e^2) started from an
+//         f32 exp2/log2 seed on the frexp-split argument, so the whole double range works
+//         (a draining surface store decays algebraically towards 1e-11 and below).
+//         Result within ~2 ulp of pow().  x < 0 must stay NaN like pow() so that
+//         fmin(1.0, NaN) == 1.0 keeps the reference's behaviour for a negative surface
+//         store (SURVEY A.1 note 6); x == 0 never reaches here (caller's exact shortcut).
 template <int MATH>
 __device__ __forceinline__ double pow_two_thirds(double x)
 {
     if constexpr (MATH == MATH_STRICT) {
         return pow(x, 2.0 / 3.0);
     } else {
-        const double c = cbrt(x);
-        const double r = c * c;
+        const int e = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^e, m in [0.5, 1)
+        const float m = (float)__builtin_amdgcn_frexp_mant(x);
+        const float lg = (float)e + __builtin_amdgcn_logf(m);  // log2(x), abs err ~1e-4 at most
+        const float v = lg * (-1.0f / 3.0f);
+        const float vi = __builtin_rintf(v);
+        double w = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(v - vi), (int)vi);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const double w3 = w * w * w;
+            w = w * __builtin_fma(-x, w3, 4.0) * (1.0 / 3.0);
+        }
+        const double r = x * w;
         return x < 0.0 ? __builtin_nan("") : r;
     }
 }

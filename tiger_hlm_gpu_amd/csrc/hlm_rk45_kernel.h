@@ -109,9 +109,14 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
 
-    // forcing column of this hillslope and the currently held samples
+    // Forcing: zero-order hold sampled at the START time of a step and held for all its
+    // stages (rk45_kernel.cu:85-106).  Each lane keeps the held samples F0/F1 and the time
+    // tb at which its sample index next changes; the index (an f64 divide) and the 4-byte
+    // load are redone only when an accepted step carries t past tb -- about once per
+    // forcing interval instead of twice per attempt.  (floor(t/dt) == idx for t < tb up to
+    // a final-ulp tie of the quotient, a measure-zero difference from the reference.)
     [[maybe_unused]] size_t fcol = 0;
-    [[maybe_unused]] unsigned long long fidx0 = ~0ull, fidx1 = ~0ull;
+    [[maybe_unused]] double tb0 = -__builtin_inf(), tb1 = -__builtin_inf();
     double F0 = 0.0, F1 = 0.0;
     const bool use_f0 = Model::NF > 0 && A.nforc > 0;
     const bool use_f1 = Model::NF > 1 && A.nforc > 1;
@@ -137,39 +142,42 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
     int reject_count = 0;
     int status = HLM_SYS_OK;
     uint32_t n_attempt = 0, n_accept = 0;
-    bool t_moved = true;  // forcing must be (re)sampled at the step's start time
+    bool t_moved = true;   // forcing must be (re)sampled at the step's start time
+    // k0 = rhs(t, y, F) is recomputed by the reference on every attempt (no FSAL,
+    // rk45_kernel.cu:114).  It is a pure function of (t, y, F): after a reject or a
+    // slope-jump retry none of them changed, and after an accepted step k6 was evaluated at
+    // exactly (t + 1.0*h, y_new, F), so whenever the held forcing samples did not change
+    // the previous value IS the reference's k0, bit for bit.  have_k0 tracks that.
+    bool have_k0 = false;
+    double k0[NEQ];
 
     while (t < tf && status == HLM_SYS_OK) {
         if (n_attempt >= A.cap) { status = HLM_SYS_CAPPED; break; }
         if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
 
-        // forcing gather at the START time of the step, held for all stages
-        // (rk45_kernel.cu:85-106).  t only changes on an accepted step, so the index is
-        // recomputed then, and the 4-byte load is issued only when the index moved.
         if constexpr (Model::NF > 0) {
             if (t_moved) {
-                if (use_f0) {
+                if (use_f0 && !(t < tb0)) {
                     const unsigned long long i0 = forcing_index(t, A.forc_dtmin[0], A.forc_nT[0]);
-                    if (i0 != fidx0) {
-                        fidx0 = i0;
-                        F0 = (double)A.forc[A.forc_base[0] + i0 * (size_t)A.forc_ld + fcol];
-                    }
+                    tb0 = (i0 + 1ull < A.forc_nT[0]) ? (double)(i0 + 1ull) * A.forc_dtmin[0] : __builtin_inf();
+                    F0 = (double)A.forc[A.forc_base[0] + i0 * (size_t)A.forc_ld + fcol];
+                    have_k0 = false;
                 }
-                if (use_f1) {
+                if (use_f1 && !(t < tb1)) {
                     const unsigned long long i1 = forcing_index(t, A.forc_dtmin[1], A.forc_nT[1]);
-                    if (i1 != fidx1) {
-                        fidx1 = i1;
-                        F1 = (double)A.forc[A.forc_base[1] + i1 * (size_t)A.forc_ld + fcol];
-                    }
+                    tb1 = (i1 + 1ull < A.forc_nT[1]) ? (double)(i1 + 1ull) * A.forc_dtmin[1] : __builtin_inf();
+                    F1 = (double)A.forc[A.forc_base[1] + i1 * (size_t)A.forc_ld + fcol];
+                    have_k0 = false;
                 }
                 t_moved = false;
             }
         }
 
         ++n_attempt;
-        // ---- 7 stages (no FSAL: k0 is recomputed every attempt, rk45_kernel.cu:114) ----
-        double k0[NEQ], k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
-        Model::template rhs<MATH>(P, y, F0, F1, k0);
+        // ---- 7 stages -------------------------------------------------------------------
+        double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
+        if (!have_k0) Model::template rhs<MATH>(P, y, F0, F1, k0);
+        have_k0 = true;  // stays valid through a reject / slope-jump retry
         {
             const double a10 = h * A10;
 #pragma unroll
@@ -289,7 +297,10 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
             }
         }
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i) y[i] = yn[i];
+        for (int i = 0; i < NEQ; ++i) {
+            y[i] = yn[i];
+            k0[i] = k6[i];  // = rhs(t1, y_new, F): next attempt's k0 unless the forcing moves
+        }
         t = t1;
         t_moved = true;
         ++n_accept;
