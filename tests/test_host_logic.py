@@ -1,0 +1,170 @@
+"""CPU tests of the host side: C-ABI export surface, registry/error behaviour without a
+GPU, parameter/lookup readers, synthetic generators, shard rule.  No compute calls."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    hdr = open(os.path.join(ROOT, "include", "hlm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(hlm_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_library_exports_every_declared_symbol(hlm):
+    names = _declared_functions()
+    assert len(names) == 23
+    lib = C.CDLL(hlm.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
+    # and the python binding covers exactly the header
+    assert sorted(hlm._lib.SIGNATURES) == names
+    assert hlm._lib.lib().hlm_abi_version() == 1
+
+
+def test_struct_layouts_match_header(hlm):
+    assert hlm.SP_DTYPE.itemsize == 136  # parameters_loader.hpp:19-37
+    assert [n for n in hlm.SP_DTYPE.names][:4] == ["stream", "next_stream", "c1", "infil"]
+    assert C.sizeof(hlm._lib.GpuBuffers) == 7 * 8 + 2 * 4
+    j = hlm._lib.DeviceJob
+    assert j.forc_dt_hours.offset % 8 == 0 and j.params.size == 48
+
+
+def test_registry_roundtrip_and_validation_without_gpu(hlm):
+    api = hlm.api
+    p0 = api.get_model_parameters(hlm.Model204)
+    assert p0.as_tuple() == (0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0)  # model_204.hpp:22-30
+    api.set_model_parameters(hlm.Model204, (1e-6, 1e-5, 1e-8, 0.8, 0.1, 5.0))
+    assert api.get_model_parameters(hlm.Model204).as_tuple() == (1e-6, 1e-5, 1e-8, 0.8, 0.1, 5.0)
+    assert api.get_model_parameters(hlm.DummyModel).as_tuple() == p0.as_tuple()  # per-model state
+    api.set_model_parameters(hlm.Model204, p0)
+    with pytest.raises(hlm.HlmError) as e:
+        api.set_model_parameters(999, p0)
+    assert e.value.code == 2 and "999" in str(e.value)
+    with pytest.raises(hlm.HlmError) as e:
+        api.set_model_parameters(hlm.Model204, (0.0, 1e-6, 1e-9, 0.9, 0.2, 10.0))
+    assert e.value.code == 1
+    with pytest.raises(hlm.HlmError):
+        api.set_math_mode(7)
+    api.set_math_mode(hlm.MATH_STRICT)
+    api.set_attempt_cap(0)
+    api.set_fixed_step(hlm.DummyModel, 0.0)
+
+
+def test_compute_fails_loudly_without_device(hlm):
+    """No CPU fallback: on a box without a HIP device every compute entry errors."""
+    if hlm.api.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(hlm.HlmError) as e:
+        hlm.api.run_rk45(hlm.DummyModel, np.ones(5), 0.0, 1.0, None, None)
+    assert e.value.code in (3, 4)
+    with pytest.raises(hlm.HlmError):
+        hlm.api.DeviceBuffer(64)
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    with pytest.raises(RuntimeError):
+        ShardEngine(hlm.DummyModel, np.ones((1, 5)), 0.0, 1.0)
+
+
+def test_product_never_imports_the_oracle():
+    for base in ("tiger_hlm_gpu_amd", "include", "tools"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hpp", ".hip", ".cpp")):
+                    txt = open(os.path.join(dp, f)).read()
+                    assert "hlm_oracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+# ---- readers -------------------------------------------------------------------------------
+def test_load_spatial_params_matches_reference_conversions(hlm, golden):
+    sp = hlm.load_spatial_params(golden["small_test_csv"])
+    assert sp.shape == (10,)
+    r = sp[0]
+    assert r["stream"] == 420555774 and r["next_stream"] == 420556801
+    c1 = 0.001 / 60.0
+    assert r["c1"] == c1 and r["infil"] == 4 * c1 and r["perco"] == 1.6 * c1      # :57,:92-95
+    assert r["alpha3"] == 2 * 24.0 * 60.0 and r["alpha4"] == 55 * 24.0 * 60.0      # :98-101
+    assert r["Hu"] == 178 and r["n_mann"] == 0.1 and r["slope"] == 0.02
+    assert r["L"] == 0.304 and r["A_h"] == 0.158 and r["lat"] == 40.32239583333335
+    assert r["melt_f"] == 3.7 and r["temp_thr"] == 0 and r["sw"] == 0.11 and r["ss"] == 0.33
+    assert sp[9]["A_h"] == 1.5450000000000004
+
+
+def test_load_spatial_params_errors(hlm, tmp_path):
+    with pytest.raises(RuntimeError, match="Failed to open parameter file"):
+        hlm.load_spatial_params(str(tmp_path / "nope.csv"))
+    p = tmp_path / "empty.csv"
+    p.write_text("")
+    with pytest.raises(RuntimeError, match="Empty parameter file"):
+        hlm.load_spatial_params(str(p))
+    p = tmp_path / "missing.csv"
+    p.write_text("stream,next_stream,hu\n1,2,3\n")
+    with pytest.raises(RuntimeError, match="Missing column 'i2'"):
+        hlm.load_spatial_params(str(p))
+    hdr = "stream,next_stream,drainage_area_km2,length_km,area_sqkm,centroid_lon,centroid_lat,hu,i2,i3,sw,ss,n,slope,res_ss,res_gw,melt,t_thres"
+    p = tmp_path / "short.csv"
+    p.write_text(hdr + "\n1,2,3\n")
+    with pytest.raises(RuntimeError, match="too few fields"):
+        hlm.load_spatial_params(str(p))
+    p = tmp_path / "blank.csv"
+    p.write_text(hdr + "\n\n1,2,0.1,0.2,0.1,-75,40,178,4,1.6,0.11,0.33,0.1,0.02,2,55,3.7,0\n\n")
+    assert hlm.load_spatial_params(str(p)).shape == (1,)  # blank lines skipped (:62)
+
+
+def test_lookup_mapper(hlm, tmp_path):
+    p = tmp_path / "lk.csv"
+    p.write_text("stream,lat_index,lon_index\n420555774,28,39\n7,1,2\n")
+    lm = hlm.LookupMapper(str(p))
+    assert lm.load()
+    assert lm.get_lat_lon(420555774) == (28, 39) and lm.get_lat_lon(7) == (1, 2)
+    assert lm.get_lat_lon(12345) == (-1, -1)  # forcing_loader.cpp:54-60
+    assert not hlm.LookupMapper(str(tmp_path / "absent.csv")).load()
+
+
+def test_host_rhs_mirror_matches_oracle(hlm, oracle, golden):
+    sp = hlm.load_spatial_params(golden["small_test_csv"])
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        y = rng.uniform(0, 5, 5) * rng.choice([1.0, 1e-3])
+        F = [float(np.float32(rng.uniform(0, 1e-3))), float(np.float32(rng.uniform(-5, 15)))]
+        a = hlm.Model204.rhs(0.0, y, sp[0], F)
+        b = oracle.rhs(oracle.UID_204, y, sp[:1], F)
+        assert np.allclose(a, b, rtol=1e-14, atol=0)
+        assert np.allclose(hlm.DummyModel.rhs(0.0, y), oracle.rhs(oracle.UID_DUMMY, y), rtol=1e-15)
+    # main.cpp:615-631 evaluates the guess at y = 0, which always yields 1e-6
+    assert hlm.initial_step_guess(hlm.Model204, np.zeros(5), sp[0], [0.001, 1.0]) == 1e-6
+
+
+# ---- synthetic inputs and sharding ---------------------------------------------------------------
+def test_synth_is_deterministic_and_shard_invariant():
+    from tiger_hlm_gpu_amd import synth
+    whole = synth.model204_params(0, 1000)
+    again = synth.model204_params(0, 1000)
+    assert np.array_equal(whole.view(np.uint8), again.view(np.uint8))
+    part = synth.model204_params(300, 200)
+    assert np.array_equal(whole[300:500].view(np.uint8), part.view(np.uint8))
+    assert np.array_equal(synth.cell_of_system(0, 5000)[1234:2234], synth.cell_of_system(1234, 1000))
+    assert 50 <= whole["Hu"].min() and whole["Hu"].max() <= 300
+    pr, t2m, dt, nT = synth.forcing_tables(days=3)
+    assert pr.shape == (72, 1024) and t2m.shape == (3, 1024) and nT == (72, 3) and dt == (1.0, 24.0)
+    assert pr.dtype == np.float32 and 0.10 < (pr > 0).mean() < 0.20 and t2m.min() >= 0.5
+    q = synth.minute_queries(0.0, 2880.0, 60.0)
+    assert q[0] == 0.0 and q[-1] == 2880.0 and len(q) == 49  # main.cpp:653-656
+    assert np.allclose(synth.dummy_query_times(5.0, 10000)[[0, -1]], [0.00049995, 4.9995])
+
+
+@pytest.mark.parametrize("total,world", [(10, 3), (1000000, 8), (7, 8), (0, 4), (64, 1)])
+def test_shard_bounds_is_the_reference_split(total, world):
+    """main.cpp:275-307: baseChunk + (r <= remainder ? 1 : 0), contiguous, in order."""
+    from tiger_hlm_gpu_amd.shard import shard_bounds
+    base, rem = divmod(total, world)
+    start = 0
+    for r in range(world):
+        s, c = shard_bounds(total, world, r)
+        assert s == start and c == base + (1 if (r + 1) <= rem else 0)
+        start += c
+    assert start == total
