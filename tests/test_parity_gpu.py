@@ -259,3 +259,62 @@ def test_dense_endpoint_consistency_large(gpu):
     assert np.all(np.isfinite(got["dense"]))
     assert_parity(got["dense"][:, -1, :], got["y_final"], "dense(tf) vs final")
     assert np.all(got["dense"][:, 0, :] == 0.0)
+
+
+# ---- the C++ driver (rk45_solver) over the header-only template API ------------------------------
+def _read_csv(path):
+    lines = open(path).read().splitlines()
+    return lines[0], [ln.split(",") for ln in lines[1:]]
+
+
+def test_cpp_driver_c1_dummy_csv_layout_and_values(gpu, oracle, golden, tmp_path):
+    """BASELINE config 1: DummyModel, 64 systems, t 0 -> 5, final.csv / dense.csv through
+    tools/rk45_solver (C++17, rk45_api::run_rk45<DummyModel> -> C ABI)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "rk45_solver")
+    assert os.path.exists(exe), "build() must have produced tools/rk45_solver"
+    f, d = str(tmp_path / "final.csv"), str(tmp_path / "dense.csv")
+    subprocess.run([exe, "--out-final", f, "--out-dense", d, "--quiet"], check=True, timeout=300)
+    hdr, rows = _read_csv(f)
+    assert hdr == "Var0,Var1,Var2,Var3,Var4" and len(rows) == 64            # src/final.csv:1
+    gold = open(os.path.join(ROOT, "tests", "golden", "g1_dummy_final.csv")).read().splitlines()[1]
+    assert all(",".join(r) == gold for r in rows)                              # "1.91791,1.90017,..."
+    hdr, rows = _read_csv(d)
+    cols = hdr.split(",")
+    assert cols[0] == "time" and cols[1] == "Var0_sys0" and cols[6] == "Var0_sys1" and len(cols) == 1 + 64 * 5
+    assert len(rows) == 10000
+    from tiger_hlm_gpu_amd import synth
+    q = synth.dummy_query_times(5.0, 10000)
+    ref = oracle.run(oracle.UID_DUMMY, np.ones((1, 5)), 0.0, 5.0, query=q)
+    same = sum(rows[i][1:6] == [fmt6(v) for v in ref["dense"][0, i]] for i in range(10000))
+    assert same >= 9990  # printed text equals the CPU oracle's except at 6th-digit rounding ties
+    assert [r[0] for r in rows] == [fmt6(t) for t in q]
+    assert all(r[1:6] == r[6:11] for r in rows[::500])
+
+
+def test_cpp_driver_model204_g2(gpu, golden, tmp_path):
+    """G2 through the driver: params CSV -> loadSpatialParams -> constant stub forcings ->
+    setModelParameters<Model204> -> run_rk45<Model204> -> 204-era CSV layout."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "rk45_solver")
+    f, d = str(tmp_path / "final.csv"), str(tmp_path / "dense.csv")
+    out = subprocess.run([exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "2880",
+                          "--query-stride", "60", "--scipy-h0", "--out-final", f, "--out-dense", d],
+                         check=True, timeout=300, capture_output=True, text=True).stdout
+    import json
+    info = json.loads(out.strip().splitlines()[-1])
+    assert info["initial_step"] == 1e-6 and info["num_systems"] == 10 and info["flagged"] == 0
+    hdr, rows = _read_csv(f)
+    assert hdr == "h_snow,var1,var2,var3,var4" and len(rows) == 10          # src/final_204_a.csv:1
+    vals = np.array(rows, dtype=float)
+    assert np.allclose(vals, golden["g2_final"], rtol=1e-5, atol=1e-9)        # 6 printed digits
+    hdr, rows = _read_csv(d)
+    assert hdr.startswith("time,var0_sys0,var1_sys0") and len(rows) == 49
+    assert rows[0][0] == "0.00000000" and rows[0][1] == "0.000000000"         # src/dense_204_a.csv:2
+    assert rows[1][0] == "60.00000000"
+    got60 = np.array(rows[1][1:6], dtype=float)
+    assert np.allclose(got60, golden["g2_dense_sys0"][60], rtol=0, atol=6e-10 + 1e-6 * 5)

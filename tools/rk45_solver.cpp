@@ -1,0 +1,211 @@
+// rk45_solver -- host driver of the MI355X hillslope engine (drop-in for the reference's
+// src/main.cpp:255-828 executable of the same name, minus MPI / NetCDF):
+//   load SpatialParams CSV -> Stream<Model> records -> upload d_sp -> forcing block ->
+//   setModelParameters<Model> -> run_rk45<Model> -> final.csv / dense.csv.
+// Everything the reference hard-codes (paths main.cpp:272,371,495; y0 :376; t0/tf :610-611;
+// tolerances :621; query grid :653-656) is a command-line option with the reference's value
+// as default.  All GPU work goes through include/hlm/*.hpp -> libhlm_hip.so (C ABI).
+//
+//   rk45_solver                         DummyModel, 64 systems, t 0..5, nq 10000  (README.md:88-93)
+//   rk45_solver --model 204 --params data/small_test.csv --tf 2880 --query-stride 60
+#include <array>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "hlm/forcing.hpp"
+#include "hlm/model_registry.hpp"
+#include "hlm/models/model_204.hpp"
+#include "hlm/models/model_dummy.hpp"
+#include "hlm/output_csv.hpp"
+#include "hlm/rk45_api.hpp"
+#include "hlm/stream.hpp"
+
+namespace {
+
+struct Options {
+    std::string model = "dummy";
+    std::string params;
+    int num_systems = 64;
+    double t0 = 0.0, tf = -1.0;
+    int nq = -1;
+    double query_stride = -1.0;
+    double rain = 0.001, temp = 1.0;  // the reference's stub forcings, model_204.hpp:76-77
+    double initial_step = -1.0, rtol = 1e-6, atol = 1e-9;
+    bool scipy_h0 = false;
+    std::string math = "strict";
+    std::string out_final = "final.csv", out_dense = "dense.csv";
+    int device = 0;
+    bool quiet = false;
+};
+
+[[noreturn]] void usage(const char* msg)
+{
+    if (msg) std::fprintf(stderr, "rk45_solver: %s\n", msg);
+    std::fprintf(stderr,
+                 "usage: rk45_solver [--model dummy|204] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
+                 "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
+                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast]\n"
+                 "                   [--out-final F] [--out-dense F] [--device D] [--quiet]\n");
+    std::exit(msg ? 2 : 0);
+}
+
+Options parse(int argc, char** argv)
+{
+    Options o;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char* {
+            if (i + 1 >= argc) usage(("missing value for " + a).c_str());
+            return argv[++i];
+        };
+        if (a == "--model") o.model = val();
+        else if (a == "--params") o.params = val();
+        else if (a == "--num-systems") o.num_systems = std::atoi(val());
+        else if (a == "--t0") o.t0 = std::atof(val());
+        else if (a == "--tf") o.tf = std::atof(val());
+        else if (a == "--nq") o.nq = std::atoi(val());
+        else if (a == "--query-stride") o.query_stride = std::atof(val());
+        else if (a == "--rain") o.rain = std::atof(val());
+        else if (a == "--temp") o.temp = std::atof(val());
+        else if (a == "--initial-step") o.initial_step = std::atof(val());
+        else if (a == "--scipy-h0") o.scipy_h0 = true;
+        else if (a == "--rtol") o.rtol = std::atof(val());
+        else if (a == "--atol") o.atol = std::atof(val());
+        else if (a == "--math") o.math = val();
+        else if (a == "--out-final") o.out_final = val();
+        else if (a == "--out-dense") o.out_dense = val();
+        else if (a == "--device") o.device = std::atoi(val());
+        else if (a == "--quiet") o.quiet = true;
+        else if (a == "-h" || a == "--help") usage(nullptr);
+        else usage(("unknown option " + a).c_str());
+    }
+    return o;
+}
+
+// SciPy-style first step of the reference driver (main.cpp:615-631).  The reference
+// evaluates it at y = 0 for system 0, which makes d0 = 0 and the guess 1e-6 for every run;
+// the same happens here when --scipy-h0 is given.
+template <class Model>
+double scipy_initial_step(const SpatialParams* sp, const float* F, int nForc, double rtol, double atol)
+{
+    constexpr int N = Model::N_EQ;
+    double y[N] = {0, 0, 0, 0, 0}, f[N];
+    Model::rhs(0.0, y, f, N, 0, sp, F, nForc);
+    double d0 = 0, d1 = 0;
+    for (int i = 0; i < N; ++i) {
+        const double sc = atol + rtol * std::fabs(y[i]);
+        d0 += (y[i] / sc) * (y[i] / sc);
+        d1 += (f[i] / sc) * (f[i] / sc);
+    }
+    return std::fmax(1e-6, 0.01 * std::sqrt(d0) / (std::sqrt(d1) + 1e-16));
+}
+
+template <class Model>
+int run(const Options& o, hlm_io::CsvStyle style)
+{
+    constexpr int N_EQ = Model::N_EQ;
+    const bool is204 = Model::UID == HLM_UID_204;
+
+    // ---- streams ---------------------------------------------------------------------------
+    std::vector<SpatialParams> spatial;
+    if (!o.params.empty()) spatial = loadSpatialParams(o.params);
+    else if (is204) usage("--model 204 needs --params <csv>");
+    else spatial.assign((size_t)o.num_systems, SpatialParams{});
+    const std::array<double, N_EQ> y0_common =
+        is204 ? std::array<double, N_EQ>{0.01, 3.0, 0.0, 5.0, 0.2}   // main.cpp:376
+              : std::array<double, N_EQ>{1.0, 1.0, 1.0, 1.0, 1.0};
+    std::vector<Stream<Model>> streams;
+    streams.reserve(spatial.size());
+    for (const auto& sp : spatial) streams.emplace_back(sp, y0_common);
+    const int ns = (int)streams.size();
+
+    const double t0 = o.t0;
+    const double tf = o.tf > 0 ? o.tf : (is204 ? 2 * 24.0 * 60.0 : 5.0);  // main.cpp:610-611 / README
+
+    // ---- device: parameters and forcings ---------------------------------------------------------
+    rk45_api::detail::check(hlm_set_device(o.device), "hlm_set_device");
+    SpatialParams* d_sp = rk45_api::device_upload(spatial.data(), spatial.size());
+    float* d_forc = nullptr;
+    ForcingBlock fb;
+    if (is204) {
+        // constant rain / temperature held over the window, in the reference's flattened
+        // [forcing][time][stream] layout with hourly and daily sampling (main.cpp:513-549)
+        fb.ld = ns;
+        const size_t n_hours = (size_t)std::ceil((tf - t0) / 60.0), n_days = (size_t)std::ceil((tf - t0) / 1440.0);
+        fb.add_constant((float)o.rain, n_hours ? n_hours : 1, 1.0);
+        fb.add_constant((float)o.temp, n_days ? n_days : 1, 24.0);
+        d_forc = rk45_api::device_upload(fb.data.data(), fb.data.size());
+        rk45_api::set_forcings(d_forc, fb.dt_hours, fb.nT, fb.ld);
+    } else {
+        rk45_api::detail::check(hlm_clear_forcings(), "hlm_clear_forcings");
+    }
+
+    // ---- solver parameters (main.cpp:615-641) ---------------------------------------------------------
+    typename Model::Parameters hp;
+    hp.rtol = o.rtol;
+    hp.atol = o.atol;
+    if (o.initial_step > 0) hp.initialStep = o.initial_step;
+    else if (o.scipy_h0) hp.initialStep = scipy_initial_step<Model>(spatial.data(), fb.data.data(), (int)fb.nT.size(), o.rtol, o.atol);
+    rk45_api::setModelParameters<Model>(hp);
+    rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
+
+    // ---- initial state and query grid --------------------------------------------------------------------
+    std::vector<double> h_y0((size_t)ns * N_EQ);
+    for (int s = 0; s < ns; ++s)
+        for (int i = 0; i < N_EQ; ++i) h_y0[(size_t)s * N_EQ + i] = streams[s].y0[i];
+    std::vector<double> h_query_times;
+    if (o.query_stride > 0 || (is204 && o.nq < 0)) {
+        const double stride = o.query_stride > 0 ? o.query_stride : 60.0;
+        for (double t = t0; t <= tf; t += stride) h_query_times.push_back(t);  // main.cpp:653-656
+    } else {
+        const int nq = o.nq >= 0 ? o.nq : 10000;
+        for (int q = 0; q < nq; ++q) h_query_times.push_back(t0 + (tf - t0) * (q + 1) / double(nq + 1));  // src/dense.csv grid
+    }
+
+    // ---- integrate ---------------------------------------------------------------------------------------------
+    const auto w0 = std::chrono::steady_clock::now();
+    auto [h_y_final, h_dense] = rk45_api::run_rk45<Model>(h_y0, t0, tf, h_query_times, d_sp);
+    const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
+    const rk45_api::RunInfo info = rk45_api::last_run_info();
+
+    hlm_io::write_final_csv(o.out_final, h_y_final, ns, N_EQ, style);
+    hlm_io::write_dense_csv(o.out_dense, h_dense, h_query_times, ns, N_EQ, style);
+
+    unsigned long long attempts = 0;
+    int flagged = 0;
+    for (int s = 0; s < ns; ++s) {
+        attempts += info.n_attempt.empty() ? 0 : info.n_attempt[s];
+        flagged += info.stiff[s] != 0;
+    }
+    if (!o.quiet)
+        std::printf("{\"model\": %d, \"num_systems\": %d, \"num_queries\": %zu, \"t0\": %g, \"tf\": %g, "
+                    "\"initial_step\": %g, \"attempted_steps\": %llu, \"flagged\": %d, \"run_rk45_seconds\": %.6f, "
+                    "\"final\": \"%s\", \"dense\": \"%s\"}\n",
+                    (int)Model::UID, ns, h_query_times.size(), t0, tf, hp.initialStep, attempts, flagged, secs,
+                    o.out_final.c_str(), o.out_dense.c_str());
+
+    rk45_api::device_free(d_sp);
+    if (d_forc) { hlm_clear_forcings(); rk45_api::device_free(d_forc); }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    const Options o = parse(argc, argv);
+    try {
+        if (o.model == "204") return run<Model204>(o, hlm_io::CsvStyle::Model204);
+        if (o.model == "dummy") return run<DummyModel>(o, hlm_io::CsvStyle::Dummy);
+        usage("--model must be dummy or 204");
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "rk45_solver: %s\n", e.what());
+        return 1;
+    }
+}
