@@ -2,7 +2,8 @@
 //
 // A device model provides
 //   UID, NF (how many forcings rhs reads), struct Local (per-system constants kept in
-//   VGPRs for the whole integration), load(sp, sys) and rhs<MATH>(P, y, F0, F1, dydt).
+//   VGPRs for the whole integration), struct Forc (values derived from the held forcing
+//   samples), load(sp, sys), prep_forcing(P, F0, F1) and rhs<MATH>(P, F, y, dydt).
 // This is the device half of the reference's plug-in concept (Model::UID / SP_TYPE /
 // rhs, reference src/models/model_204.hpp:15-115); the host half is include/hlm/models/.
 #pragma once
@@ -17,13 +18,51 @@ namespace hlm {
 constexpr int MATH_STRICT = HLM_MATH_STRICT;
 constexpr int MATH_FAST = HLM_MATH_FAST;
 
+// IEEE minNum / maxNum as single VALU instructions.  fmin()/fmax() lower to
+// llvm.minnum/maxnum, for which hipcc (IEEE mode on) first quiets possibly-signalling
+// inputs with an extra "v_max_f64 x, x, x" whenever it cannot prove the operand came out
+// of an arithmetic instruction (27 of them per loop iteration in this kernel).  No
+// signalling NaN can reach these values (loads of user doubles are only ever combined
+// arithmetically first), and for quiet NaNs the bare instruction already returns the
+// non-NaN operand -- the behaviour the reference relies on for fmin(1.0, NaN) == 1.0.
+__device__ __forceinline__ double vmin(double a, double b)
+{
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double vmax(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max(|a|, |b|) with the absolute values as source modifiers
+__device__ __forceinline__ double vmax_abs(double a, double b)
+{
+    double r;
+    asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// max(m, |b|): "if (fabs(b) > m) m = fabs(b)" of the reference's norm loops
+// (rk45_step_dense.cuh:135-140, event_detector.cuh:46-53); like those comparisons it
+// ignores a NaN b.
+__device__ __forceinline__ double vmax_abs2(double m, double b)
+{
+    double r;
+    asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(m), "v"(b));
+    return r;
+}
+
+// x^(-1/n) refinement shared by the FAST roots: given a seed w ~ x^(-1/n) with residual
+// e = 1 - x w^n, the exact root is w (1-e)^(-1/n) = w (1 + c1 e + c2 e^2 + c3 e^3 + ...).
+// With an f32 exp2/log2 seed |e| < ~1e-4, so three series terms leave ~e^4 < 1e-16.
+
 // x^(2/3) for the Manning term (model_204.hpp:103).
 // STRICT: OCML pow (<1 ulp; the reference makes the same call through libdevice).
-// FAST:   x * x^(-1/3) with w = x^(-1/3) from a division-free Newton iteration
-//         w <- w (4 - x w^3) / 3 (quadratic; relative error e -> 2 e^2) started from an
-//         f32 exp2/log2 seed on the frexp-split argument, so the whole double range works
-//         (a draining surface store decays algebraically towards 1e-11 and below).
-//         Result within ~2 ulp of pow().  x < 0 must stay NaN like pow() so that
+// FAST:   x * x^(-1/3); the seed is taken on the frexp-split argument so the whole double
+//         range works (a draining surface store decays algebraically to 1e-11 and below).
+//         Result within a few ulp of pow().  x < 0 must stay NaN like pow() so that
 //         fmin(1.0, NaN) == 1.0 keeps the reference's behaviour for a negative surface
 //         store (SURVEY A.1 note 6); x == 0 never reaches here (caller's exact shortcut).
 template <int MATH>
@@ -32,18 +71,17 @@ __device__ __forceinline__ double pow_two_thirds(double x)
     if constexpr (MATH == MATH_STRICT) {
         return pow(x, 2.0 / 3.0);
     } else {
-        const int e = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^e, m in [0.5, 1)
+        const int ex = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^ex, m in [0.5, 1)
         const float m = (float)__builtin_amdgcn_frexp_mant(x);
-        const float lg = (float)e + __builtin_amdgcn_logf(m);  // log2(x), abs err ~1e-4 at most
+        const float lg = (float)ex + __builtin_amdgcn_logf(m);  // log2(x)
         const float v = lg * (-1.0f / 3.0f);
         const float vi = __builtin_rintf(v);
-        double w = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(v - vi), (int)vi);
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const double w3 = w * w * w;
-            w = w * __builtin_fma(-x, w3, 4.0) * (1.0 / 3.0);
-        }
-        const double r = x * w;
+        const double w = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(v - vi), (int)vi);
+        const double e = __builtin_fma(-x, w * w * w, 1.0);
+        double p = __builtin_fma(e, 14.0 / 81.0, 2.0 / 9.0);
+        p = __builtin_fma(e, p, 1.0 / 3.0);
+        const double xw = x * w;
+        const double r = __builtin_fma(xw * e, p, xw);
         return x < 0.0 ? __builtin_nan("") : r;
     }
 }
@@ -61,8 +99,18 @@ struct Model204Dev {
         double infil, perco, Hu, L, A_h, alpha3, alpha4, melt_f, temp_thr;
         double inv_n;       // 1.0 / n_mann   (same operation as :103, hoisted: bit-identical)
         double sqrt_slope;  // sqrt(slope)    (idem)
-        // FAST mode only: reciprocals replacing the per-call divides
-        double inv_Hu, L_over_A60, inv_alpha3, inv_alpha4;
+        // FAST mode only: reciprocals / products replacing the per-call divides
+        double inv_Hu, manning, inv_alpha3, inv_alpha4;
+    };
+
+    // Values that depend only on the held forcing samples; recomputed when a sample
+    // changes (about once per forcing hour) instead of in each of the 7 RHS calls.  They
+    // are the reference's own sub-expressions (:87-88, :96), so hoisting is bit-identical.
+    struct Forc {
+        double rain;     // F[0]
+        double melt_pot; // temperature * melt_f
+        double e_pot;    // 0.1 * temperature   (the linear ET stub, :96)
+        bool warm;       // temperature >= temp_thr
     };
 
     template <int MATH>
@@ -83,33 +131,41 @@ struct Model204Dev {
         P.sqrt_slope = sqrt(S.slope);
         if constexpr (MATH == MATH_FAST) {
             P.inv_Hu = 1.0 / S.Hu;
-            P.L_over_A60 = S.L / S.A_h * 60.0;
+            P.manning = P.inv_n * P.sqrt_slope * (S.L / S.A_h * 60.0);
             // the reference drains only when alpha >= 1 (:110,:113)
             P.inv_alpha3 = S.alpha3 >= 1.0 ? 1.0 / S.alpha3 : 0.0;
             P.inv_alpha4 = S.alpha4 >= 1.0 ? 1.0 / S.alpha4 : 0.0;
         } else {
-            P.inv_Hu = P.L_over_A60 = P.inv_alpha3 = P.inv_alpha4 = 0.0;
+            P.inv_Hu = P.manning = P.inv_alpha3 = P.inv_alpha4 = 0.0;
         }
         return P;
     }
 
+    static __device__ __forceinline__ Forc prep_forcing(const Local& P, double rainfall, double temperature)
+    {
+        Forc F;
+        F.rain = rainfall;
+        F.melt_pot = temperature * P.melt_f;
+        F.e_pot = 0.1 * temperature;
+        F.warm = temperature >= P.temp_thr;
+        return F;
+    }
+
     template <int MATH>
-    static __device__ __forceinline__ void rhs(const Local& P, const double (&y)[HLM_NEQ],
-                                               double rainfall, double temperature,
+    static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
                                                double (&dydt)[HLM_NEQ])
     {
         const double h_snow = y[0], h_stat = y[1], h_surf = y[2], h_grav = y[3], h_aq = y[4];
 
         // snow (:87-91)
-        const double snowmelt =
-            (temperature >= P.temp_thr) ? fmin(h_snow, temperature * P.melt_f) : 0.0;
-        const double x1 = rainfall + snowmelt;
-        dydt[0] = rainfall - snowmelt;
+        const double snowmelt = F.warm ? vmin(h_snow, F.melt_pot) : 0.0;
+        const double x1 = F.rain + snowmelt;
+        dydt[0] = F.rain - snowmelt;
 
         // static (:94-98)
-        const double x2 = fmax(0.0, x1 + h_stat - P.Hu);
+        const double x2 = vmax(0.0, x1 + h_stat - P.Hu);
         const double d1 = x1 - x2;
-        const double Emax = fmin(0.1 * temperature, h_stat);
+        const double Emax = vmin(F.e_pot, h_stat);
         double s;
         if constexpr (MATH == MATH_FAST) s = h_stat * P.inv_Hu; else s = h_stat / P.Hu;
         dydt[1] = d1 - s * Emax;
@@ -117,20 +173,23 @@ struct Model204Dev {
         // surface (:101-105).  pow(0, 2/3) == 0 exactly, hence alfa2 == 0, w == 0 and
         // dydt[2] == d2 - 0: a dry surface store skips the transcendental bit-exactly;
         // a wave whose 64 hillslopes are all dry skips it entirely (s_cbranch_execz).
-        const double x3 = fmin(x2, P.infil);
+        const double x3 = vmin(x2, P.infil);
         const double d2 = x2 - x3;
         double out2 = d2;
         if (h_surf != 0.0) {
-            const double alfa2 = P.inv_n * pow_two_thirds<MATH>(h_surf) * P.sqrt_slope;
             double w;
-            if constexpr (MATH == MATH_FAST) w = fmin(1.0, alfa2 * P.L_over_A60);
-            else w = fmin(1.0, alfa2 * P.L / P.A_h * 60.0);
+            if constexpr (MATH == MATH_FAST) {
+                w = vmin(1.0, P.manning * pow_two_thirds<MATH>(h_surf));
+            } else {
+                const double alfa2 = P.inv_n * pow_two_thirds<MATH>(h_surf) * P.sqrt_slope;
+                w = vmin(1.0, alfa2 * P.L / P.A_h * 60.0);
+            }
             out2 = d2 - h_surf * w;
         }
         dydt[2] = out2;
 
         // gravitational (:108-110) and aquifer (:113)
-        const double x4 = fmin(x3, P.perco);
+        const double x4 = vmin(x3, P.perco);
         const double d3 = x3 - x4;
         if constexpr (MATH == MATH_FAST) {
             dydt[3] = d3 - h_grav * P.inv_alpha3;
@@ -151,13 +210,15 @@ struct DummyDev {
     static constexpr int UID = HLM_UID_DUMMY;
     static constexpr int NF = 0;
     struct Local {};
+    struct Forc {};
 
     template <int MATH>
     static __device__ __forceinline__ Local load(const void*, int) { return Local{}; }
+    static __device__ __forceinline__ Forc prep_forcing(const Local&, double, double) { return Forc{}; }
 
     template <int MATH>
-    static __device__ __forceinline__ void rhs(const Local&, const double (&y)[HLM_NEQ],
-                                               double, double, double (&dydt)[HLM_NEQ])
+    static __device__ __forceinline__ void rhs(const Local&, const Forc&, const double (&y)[HLM_NEQ],
+                                               double (&dydt)[HLM_NEQ])
     {
         const double H0 = y[0], H1 = y[1], H3 = y[3];
         const double Y0 = 0.5 * H0, X2 = 0.3 * H1, I2 = 0.6 * H1, I3 = 0.4 * H3;

@@ -66,17 +66,15 @@ __device__ __forceinline__ double inv_fifth_root(double x)
     if constexpr (MATH == MATH_STRICT) {
         return pow(1.0 / x, 0.2);
     } else {
-        // f32 exp2/log2 seed for z = x^(-1/5), then two Newton steps on z^-5 = x:
-        // z <- z * (6 - x z^5) / 5.  x is in [1e-16, huge]; the seed is good to ~1e-6,
-        // each step squares the relative error.
+        // f32 exp2/log2 seed z ~ x^(-1/5) (x in [1e-16, huge]), residual e = 1 - x z^5,
+        // exact root = z (1-e)^(-1/5) = z (1 + e/5 + 3/25 e^2 + 11/125 e^3 + O(e^4)).
         const float xf = (float)x;
         double z = (double)__builtin_amdgcn_exp2f(-0.2f * __builtin_amdgcn_logf(xf));
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            const double z2 = z * z;
-            const double z5 = z2 * z2 * z;
-            z = z * __builtin_fma(-x, z5, 6.0) * 0.2;
-        }
+        const double z2 = z * z;
+        const double e = __builtin_fma(-x, z2 * z2 * z, 1.0);
+        double p = __builtin_fma(e, 11.0 / 125.0, 3.0 / 25.0);
+        p = __builtin_fma(e, p, 0.2);
+        z = __builtin_fma(z * e, p, z);
         return z;
     }
 }
@@ -90,7 +88,7 @@ __device__ __forceinline__ unsigned long long forcing_index(double t, double dtm
 }
 
 template <class Model, int MATH, bool DENSE, bool FIXED>
-__global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
+__global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
 {
     using namespace dp;
     // XCD-aware block -> hillslope-chunk map: workgroups are dealt round-robin over the
@@ -150,6 +148,7 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
     // the previous value IS the reference's k0, bit for bit.  have_k0 tracks that.
     bool have_k0 = false;
     double k0[NEQ];
+    typename Model::Forc FV = Model::prep_forcing(P, F0, F1);
 
     while (t < tf && status == HLM_SYS_OK) {
         if (n_attempt >= A.cap) { status = HLM_SYS_CAPPED; break; }
@@ -169,6 +168,7 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
                     F1 = (double)A.forc[A.forc_base[1] + i1 * (size_t)A.forc_ld + fcol];
                     have_k0 = false;
                 }
+                if (!have_k0) FV = Model::prep_forcing(P, F0, F1);
                 t_moved = false;
             }
         }
@@ -176,39 +176,39 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
         ++n_attempt;
         // ---- 7 stages -------------------------------------------------------------------
         double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
-        if (!have_k0) Model::template rhs<MATH>(P, y, F0, F1, k0);
+        if (!have_k0) Model::template rhs<MATH>(P, FV, y, k0);
         have_k0 = true;  // stays valid through a reject / slope-jump retry
         {
             const double a10 = h * A10;
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a10, k0[i]);
-            Model::template rhs<MATH>(P, yt, F0, F1, k1);
+            Model::template rhs<MATH>(P, FV, yt, k1);
         }
         {
             const double a20 = h * A20, a21 = h * A21;
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a20, k0[i], a21, k1[i]);
-            Model::template rhs<MATH>(P, yt, F0, F1, k2);
+            Model::template rhs<MATH>(P, FV, yt, k2);
         }
         {
             const double a30 = h * A30, a31 = h * A31, a32 = h * A32;
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]);
-            Model::template rhs<MATH>(P, yt, F0, F1, k3);
+            Model::template rhs<MATH>(P, FV, yt, k3);
         }
         {
             const double a40 = h * A40, a41 = h * A41, a42 = h * A42, a43 = h * A43;
 #pragma unroll
             for (int i = 0; i < NEQ; ++i)
                 yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]);
-            Model::template rhs<MATH>(P, yt, F0, F1, k4);
+            Model::template rhs<MATH>(P, FV, yt, k4);
         }
         {
             const double a50 = h * A50, a51 = h * A51, a52 = h * A52, a53 = h * A53, a54 = h * A54;
 #pragma unroll
             for (int i = 0; i < NEQ; ++i)
                 yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
-            Model::template rhs<MATH>(P, yt, F0, F1, k5);
+            Model::template rhs<MATH>(P, FV, yt, k5);
         }
         const double hb0 = h * B0, hb2 = h * B2, hb3 = h * B3, hb4 = h * B4, hb5 = h * B5;
         {
@@ -216,7 +216,7 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
 #pragma unroll
             for (int i = 0; i < NEQ; ++i)
                 yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
-            Model::template rhs<MATH>(P, yt, F0, F1, k6);
+            Model::template rhs<MATH>(P, FV, yt, k6);
         }
         // 5th-order solution (rk45_step_dense.cuh:111-117).  b[6] = 0, so it is the same
         // chain of operations as the stage-6 state: identical bits, reuse it.
@@ -234,12 +234,12 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
             for (int i = 0; i < NEQ; ++i) {
                 const double y_err =
                     lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
-                const double ymax = fmax(fabs(y[i]), fabs(yn[i]));
+                const double ymax = vmax_abs(y[i], yn[i]);
                 const double tol = __builtin_fma(A.rtol, ymax, A.atol);
                 double ratio;
-                if constexpr (MATH == MATH_FAST) ratio = fabs(y_err) * fast_rcp(tol);
-                else ratio = fabs(y_err / tol);
-                if (ratio > err) err = ratio;
+                if constexpr (MATH == MATH_FAST) ratio = y_err * fast_rcp(tol);
+                else ratio = y_err / tol;
+                err = vmax_abs2(err, ratio);  // "if (fabs(ratio) > max) max = fabs(ratio)"
             }
             // step-size factor shared by the accept and the reject branch
             // (rk45_kernel.cu:151,156)
@@ -251,8 +251,7 @@ __global__ void __launch_bounds__(WAVE) rk45_multi_kernel(const Rk45Args A)
                 double jump = 0.0;
 #pragma unroll
                 for (int i = 0; i < NEQ; ++i) {
-                    const double f = fabs(k0[i] - k1[i]);
-                    if (f > jump) jump = f;
+                    jump = vmax_abs2(jump, k0[i] - k1[i]);
                 }
                 if (jump > SLOPE_JUMP_THRESH) {
                     h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
