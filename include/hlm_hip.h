@@ -162,7 +162,19 @@ typedef struct hlm_device_job {
     int32_t* d_stiff;        /* [ns] */
     uint32_t* d_n_attempt;   /* [ns] nullable */
     uint32_t* d_n_accept;    /* [ns] nullable */
+    /* Query window (build feature for dense output larger than HBM; the reference's single
+     * allocation, rk45_api.hpp:76,92, cannot hold BASELINE config 5).  query_end == 0 means
+     * the whole range.  With a window, d_dense holds only rows [query_begin, query_end):
+     * [ns][query_end-query_begin][5], and d_resume (hlm_resume_bytes(ns) bytes) carries the
+     * integrator state between consecutive launches: resume_in = 0 on the first window,
+     * 1 afterwards.  Windows must be visited in order and tile [0, nq).  The committed step
+     * sequence, and therefore every output bit, equals the one-shot run. */
+    int query_begin, query_end;
+    void* d_resume;
+    int resume_in;
 } hlm_device_job;
+
+size_t hlm_resume_bytes(int num_systems);
 
 /* Enqueue the integration on `hip_stream` (a hipStream_t, NULL = default stream) of the
  * current device.  Asynchronous: returns after the launch. */
@@ -172,6 +184,25 @@ int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream);
  * bracketing EACH launch with HIP events on that stream; ms[i] receives the elapsed
  * milliseconds of launch i. */
 int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms);
+
+/* Dense output streamed to the host in query windows (BASELINE config 5: "dense-output at
+ * 1-min query stride ... overlapped hipMemcpyAsync writeback").  Runs `job` (its d_dense /
+ * window fields are ignored) window by window of `window_queries` queries into two
+ * alternating device buffers; while window k+1 integrates on `hip_stream`, window k is
+ * copied on a second stream into h_dense[(s*nq + q)*5 + c] (the host order of
+ * rk45_api.hpp:255-267; pinned memory from hlm_host_alloc_pinned makes the copy truly
+ * asynchronous).  Synchronous: returns when every byte is in host memory. */
+typedef struct hlm_stream_stats {
+    double wall_ms;        /* first launch -> last byte in host memory */
+    double kernel_ms;      /* sum of the window kernels (HIP events on the compute stream) */
+    double copy_ms;        /* sum of the window D2H copies (HIP events on the copy stream) */
+    int windows;
+    uint64_t dense_bytes;  /* ns * nq * 5 * 8 */
+} hlm_stream_stats;
+int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, double* h_dense,
+                                void* hip_stream, hlm_stream_stats* stats);
+int hlm_host_alloc_pinned(void** hptr, size_t bytes);
+int hlm_host_free_pinned(void* hptr);
 
 /* Static facts about the compiled kernels (for DESIGN.md / bench output). */
 int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs,

@@ -18,7 +18,7 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 23
+    assert len(names) == 27
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
@@ -30,7 +30,7 @@ def test_library_exports_every_declared_symbol(hlm):
 def test_struct_layouts_match_header(hlm):
     assert hlm.SP_DTYPE.itemsize == 136  # parameters_loader.hpp:19-37
     assert [n for n in hlm.SP_DTYPE.names][:4] == ["stream", "next_stream", "c1", "infil"]
-    assert C.sizeof(hlm._lib.GpuBuffers) == 7 * 8 + 2 * 4
+    assert C.sizeof(hlm._lib.GpuBuffers) == 7 * 8 + 2 * 4 and C.sizeof(hlm._lib.StreamStats) == 40
     j = hlm._lib.DeviceJob
     assert j.forc_dt_hours.offset % 8 == 0 and j.params.size == 48
 

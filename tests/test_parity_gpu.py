@@ -318,3 +318,80 @@ def test_cpp_driver_model204_g2(gpu, golden, tmp_path):
     assert rows[1][0] == "60.00000000"
     got60 = np.array(rows[1][1:6], dtype=float)
     assert np.allclose(got60, golden["g2_dense_sys0"][60], rtol=0, atol=6e-10 + 1e-6 * 5)
+
+
+# ---- dense output in query windows (BASELINE config 5) ------------------------------------------
+@pytest.mark.parametrize("window", [1, 7, 48, 1000])
+def test_streamed_dense_equals_one_shot_bitwise(gpu, window):
+    """The windowed run pauses a lane before it commits a step whose queries cross the
+    window end and redoes that attempt in the next launch, so finals, flags, counters and
+    every dense value equal the one-shot run bit for bit, for any window size."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 300, 2
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, wet=True)
+    q = np.concatenate([[-5.0, 0.0], synth.minute_queries(1.0, days * 1440.0 + 30.0, 13.0)])  # before t0 .. past tf
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, math_mode=H.MATH_FAST)
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    eng.integrate()
+    one = eng.results()
+    host, stats = eng.integrate_streamed(window)
+    two = eng.results()
+    assert stats["windows"] == -(-len(q) // min(window, len(q))) and stats["dense_bytes"] == ns * len(q) * 40
+    assert np.array_equal(host, one["dense"])
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(one[k], two[k]), k
+
+
+def test_streamed_dense_with_flagged_systems(gpu, oracle):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 256, 8
+    sp = synth.model204_params(0, ns)
+    y0 = synth.model204_y0(ns)
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    q = synth.minute_queries(0.0, days * 1440.0, 60.0)
+    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q)
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    eng.integrate()
+    one = eng.results()
+    assert 0 < (one["stiff"] == 1).sum() < ns
+    host, _ = eng.integrate_streamed(24)
+    assert np.array_equal(host, one["dense"])
+    assert np.array_equal(eng.results()["stiff"], one["stiff"])
+
+
+def test_manual_window_loop_through_device_job(gpu):
+    """The same protocol driven by the caller: consecutive hlm_rk45_integrate_device calls
+    with query_begin/query_end/d_resume."""
+    H = gpu
+    import torch
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns = 130
+    y0 = synth.dummy_y0(0, ns)
+    q = synth.dummy_query_times(5.0, 101)
+    eng = ShardEngine(H.DummyModel, y0, 0.0, 5.0, query=q)
+    eng.integrate()
+    one = eng.results()
+    resume = torch.zeros(H.api.resume_bytes(ns), dtype=torch.uint8, device="cuda:0")
+    out = np.zeros_like(one["dense"])
+    W = 40
+    for k, qb in enumerate(range(0, len(q), W)):
+        qe = min(qb + W, len(q))
+        win = torch.empty((ns, qe - qb, 5), dtype=torch.float64, device="cuda:0")
+        job = eng.job()
+        job.d_dense, job.query_begin, job.query_end = win.data_ptr(), qb, qe
+        job.d_resume, job.resume_in = resume.data_ptr(), int(k > 0)
+        H.api.integrate_device(job)
+        torch.cuda.synchronize()
+        out[:, qb:qe] = win.cpu().numpy()
+    assert np.array_equal(out, one["dense"])
+    assert np.array_equal(eng.results()["y_final"], one["y_final"])
+    bad = eng.job()
+    bad.query_begin, bad.query_end = 0, 10
+    with pytest.raises(H.HlmError):
+        H.api.integrate_device(bad)  # a partial window without d_resume

@@ -51,7 +51,14 @@ class DeviceJob(C.Structure):
         ("math_mode", C.c_int),
         ("d_y_final", C.c_void_p), ("d_dense", C.c_void_p), ("d_stiff", C.c_void_p),
         ("d_n_attempt", C.c_void_p), ("d_n_accept", C.c_void_p),
+        ("query_begin", C.c_int), ("query_end", C.c_int), ("d_resume", C.c_void_p), ("resume_in", C.c_int),
     ]
+
+
+class StreamStats(C.Structure):
+    """hlm_stream_stats"""
+    _fields_ = [("wall_ms", C.c_double), ("kernel_ms", C.c_double), ("copy_ms", C.c_double),
+                ("windows", C.c_int), ("dense_bytes", C.c_uint64)]
 
 
 # name -> (restype, argtypes); every symbol include/hlm_hip.h declares
@@ -80,6 +87,11 @@ SIGNATURES = {
     "hlm_run_rk45": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hlm_rk45_integrate_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p]),
+    "hlm_resume_bytes": (C.c_size_t, [C.c_int]),
+    "hlm_rk45_integrate_streamed": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p,
+                                              C.POINTER(StreamStats)]),
+    "hlm_host_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "hlm_host_free_pinned": (C.c_int, [C.c_void_p]),
     "hlm_rk45_time_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "hlm_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),

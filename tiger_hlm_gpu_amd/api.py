@@ -229,6 +229,23 @@ def integrate_device(job, stream=None):
     check(lib().hlm_rk45_integrate_device(C.byref(job), s))
 
 
+def integrate_streamed(job, window_queries, h_dense, stream=None):
+    """Dense output streamed to the host in query windows with overlapped D2H
+    (hlm_rk45_integrate_streamed).  ``h_dense``: a C-contiguous float64 host array of
+    ns*nq*5 elements (numpy array, ideally backed by pinned memory) or a raw pointer.
+    Returns the hlm_stream_stats as a dict."""
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    ptr = h_dense if isinstance(h_dense, int) else h_dense.ctypes.data
+    st = _lib.StreamStats()
+    check(lib().hlm_rk45_integrate_streamed(C.byref(job), int(window_queries), ptr, s, C.byref(st)))
+    return {"wall_ms": st.wall_ms, "kernel_ms": st.kernel_ms, "copy_ms": st.copy_ms, "windows": st.windows,
+            "dense_bytes": st.dense_bytes}
+
+
+def resume_bytes(ns):
+    return int(lib().hlm_resume_bytes(int(ns)))
+
+
 def time_device(job, iters, stream=None):
     """Per-launch kernel milliseconds measured with HIP events on the launch stream."""
     s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)

@@ -4,10 +4,12 @@
 // without a HIP device every compute entry point fails with HLM_ERR_NO_DEVICE/HIP.
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <vector>
 
 #include "hlm_hip.h"
 #include "hlm_rk45_kernel.h"
@@ -120,6 +122,14 @@ int validate_job(const hlm_device_job* j)
     if (j->math_mode != HLM_MATH_STRICT && j->math_mode != HLM_MATH_FAST)
         return fail(HLM_ERR_INVALID_ARGUMENT, "math_mode %d", j->math_mode);
     if (j->fixed_step < 0.0) return fail(HLM_ERR_INVALID_ARGUMENT, "fixed_step < 0");
+    if (j->query_end != 0 || j->query_begin != 0) {
+        if (j->query_begin < 0 || j->query_end <= j->query_begin || j->query_end > j->num_queries)
+            return fail(HLM_ERR_INVALID_ARGUMENT, "query window [%d,%d) outside [0,%d)", j->query_begin,
+                        j->query_end, j->num_queries);
+        if ((j->query_begin != 0 || j->query_end != j->num_queries) && !j->d_resume)
+            return fail(HLM_ERR_INVALID_ARGUMENT, "a partial query window needs d_resume");
+    }
+    if (j->resume_in && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "resume_in without d_resume");
     return HLM_SUCCESS;
 }
 
@@ -157,6 +167,10 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     a.cap = j->attempt_cap ? j->attempt_cap : (1u << 24);
     a.y_final = j->d_y_final;
     a.dense = j->d_dense;
+    a.q_begin = j->query_end ? j->query_begin : 0;
+    a.q_end = j->query_end ? j->query_end : j->num_queries;
+    a.resume = static_cast<double*>(j->d_resume);
+    a.resume_in = j->resume_in;
     a.stiff = j->d_stiff;
     a.n_attempt = j->d_n_attempt;
     a.n_accept = j->d_n_accept;
@@ -343,6 +357,119 @@ int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream)
     if (rc != HLM_SUCCESS) return rc;
     if (job->num_systems == 0) return HLM_SUCCESS;
     return launch(job, static_cast<hipStream_t>(hip_stream));
+}
+
+size_t hlm_resume_bytes(int ns)
+{
+    return ns <= 0 ? 0 : (size_t)ns * (hlm::RESUME_F64 * sizeof(double) + hlm::RESUME_I32 * sizeof(int32_t));
+}
+
+int hlm_host_alloc_pinned(void** hptr, size_t bytes)
+{
+    if (!hptr) return fail(HLM_ERR_INVALID_ARGUMENT, "hptr is NULL");
+    *hptr = nullptr;
+    if (bytes == 0) return HLM_SUCCESS;
+    HLM_HIP_TRY(hipHostMalloc(hptr, bytes, hipHostMallocDefault));
+    return HLM_SUCCESS;
+}
+
+int hlm_host_free_pinned(void* hptr)
+{
+    if (hptr) HLM_HIP_TRY(hipHostFree(hptr));
+    return HLM_SUCCESS;
+}
+
+int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, double* h_dense,
+                                void* hip_stream, hlm_stream_stats* stats)
+{
+    if (!job) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
+    hlm_device_job probe = *job;  // d_dense / window fields of the caller's job are ignored
+    probe.d_dense = reinterpret_cast<double*>(sizeof(double));
+    probe.query_begin = probe.query_end = probe.resume_in = 0;
+    probe.d_resume = nullptr;
+    int rc = validate_job(&probe);
+    if (rc != HLM_SUCCESS) return rc;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    const int ns = job->num_systems, nq = job->num_queries;
+    if (nq <= 0 || ns <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "streamed dense output needs num_systems, num_queries > 0");
+    if (window_queries <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "window_queries must be > 0");
+    if (!h_dense) return fail(HLM_ERR_INVALID_ARGUMENT, "h_dense is NULL");
+    const int W = window_queries < nq ? window_queries : nq;
+    const int nwin = (nq + W - 1) / W;
+    const size_t row = (size_t)HLM_NEQ * sizeof(double);  // 40 B per (system, query)
+
+    hipStream_t compute = static_cast<hipStream_t>(hip_stream), copy = nullptr;
+    double* buf[2] = {nullptr, nullptr};
+    void* resume = nullptr;
+    hipEvent_t done_k[2] = {nullptr, nullptr}, done_c[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev;  // per-window timing events
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+
+    ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        if (b == 0 || nwin > 1) ok(hipMalloc((void**)&buf[b], (size_t)ns * W * row));
+        ok(hipEventCreateWithFlags(&done_k[b], hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&done_c[b], hipEventDisableTiming));
+    }
+    ok(hipMalloc(&resume, hlm_resume_bytes(ns)));
+    ev.resize((size_t)nwin * 4, nullptr);
+    for (auto& x : ev) ok(hipEventCreate(&x));
+
+    hipEvent_t wall0 = nullptr, wall1 = nullptr;
+    ok(hipEventCreate(&wall0));
+    ok(hipEventCreate(&wall1));
+    if (e == hipSuccess) ok(hipEventRecord(wall0, compute));
+    if (e == hipSuccess) ok(hipStreamSynchronize(compute));  // setup done: the clock starts here
+    const auto host_t0 = std::chrono::steady_clock::now();
+
+    for (int k = 0; k < nwin && e == hipSuccess && rc == HLM_SUCCESS; ++k) {
+        const int b = k & 1, qb = k * W, qe = (qb + W < nq) ? qb + W : nq;
+        hlm_device_job j = *job;
+        j.d_dense = buf[b];
+        j.query_begin = qb;
+        j.query_end = qe;
+        j.d_resume = resume;
+        j.resume_in = k > 0;
+        if (k >= 2) ok(hipStreamWaitEvent(compute, done_c[b], 0));  // buffer b is free again
+        ok(hipEventRecord(ev[4 * k + 0], compute));
+        if (e == hipSuccess) rc = launch(&j, compute);
+        ok(hipEventRecord(ev[4 * k + 1], compute));
+        ok(hipEventRecord(done_k[b], compute));
+        ok(hipStreamWaitEvent(copy, done_k[b], 0));
+        ok(hipEventRecord(ev[4 * k + 2], copy));
+        // device [ns][qe-qb][5] -> host rows of nq*40 B, columns qb..qe
+        ok(hipMemcpy2DAsync(reinterpret_cast<char*>(h_dense) + (size_t)qb * row, (size_t)nq * row, buf[b],
+                            (size_t)(qe - qb) * row, (size_t)(qe - qb) * row, (size_t)ns,
+                            hipMemcpyDeviceToHost, copy));
+        ok(hipEventRecord(ev[4 * k + 3], copy));
+        ok(hipEventRecord(done_c[b], copy));
+    }
+    if (e == hipSuccess) ok(hipStreamSynchronize(compute));
+    if (e == hipSuccess) ok(hipStreamSynchronize(copy));
+    const auto host_t1 = std::chrono::steady_clock::now();  // last byte is in host memory
+    if (e == hipSuccess && rc == HLM_SUCCESS && stats) {
+        float ms = 0.f;
+        stats->windows = nwin;
+        stats->dense_bytes = (uint64_t)ns * (uint64_t)nq * row;
+        for (int k = 0; k < nwin; ++k) {
+            if (hipEventElapsedTime(&ms, ev[4 * k + 0], ev[4 * k + 1]) == hipSuccess) stats->kernel_ms += ms;
+            if (hipEventElapsedTime(&ms, ev[4 * k + 2], ev[4 * k + 3]) == hipSuccess) stats->copy_ms += ms;
+        }
+        stats->wall_ms = std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();
+    }
+    for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+    for (int b = 0; b < 2; ++b) {
+        if (buf[b]) (void)hipFree(buf[b]);
+        if (done_k[b]) (void)hipEventDestroy(done_k[b]);
+        if (done_c[b]) (void)hipEventDestroy(done_c[b]);
+    }
+    if (wall0) (void)hipEventDestroy(wall0);
+    if (wall1) (void)hipEventDestroy(wall1);
+    if (resume) (void)hipFree(resume);
+    if (copy) (void)hipStreamDestroy(copy);
+    if (e != hipSuccess) return fail(HLM_ERR_HIP, "integrate_streamed: %s", hipGetErrorString(e));
+    return rc;
 }
 
 int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms)

@@ -15,8 +15,17 @@
 
 namespace hlm {
 
+#ifndef HLM_MIN_WAVES_PER_SIMD
+#define HLM_MIN_WAVES_PER_SIMD 2  // <= 256 VGPRs; the loop is VALU-issue-bound, see DESIGN.md
+#endif
+
 constexpr int NEQ = HLM_NEQ;
 constexpr int WAVE = 64;
+constexpr int SYS_PAUSED = 3;  // internal: lane stopped at the end of its query window
+
+// resume record (SoA over systems): 7 doubles {y[5], t, h} then 5 int32 {reject_count,
+// n_attempt, n_accept, next_q, status}
+constexpr int RESUME_F64 = 7, RESUME_I32 = 5;
 
 // Kernel arguments (kernarg segment -> SGPRs; everything here is wave-uniform).
 struct Rk45Args {
@@ -36,7 +45,10 @@ struct Rk45Args {
     double fixed_step;
     uint32_t cap;
     double* y_final;     // [ns][5]
-    double* dense;       // [ns][nq][5]
+    double* dense;       // [ns][q_end - q_begin][5]: the rows of this launch's query window
+    int q_begin, q_end;  // global query indices [q_begin, q_end) written by this launch
+    double* resume;      // nullable: per-system integrator state carried between windows
+    int resume_in;       // 0 = start from y0, 1 = continue from `resume`
     int32_t* stiff;
     uint32_t* n_attempt;
     uint32_t* n_accept;
@@ -88,7 +100,7 @@ __device__ __forceinline__ unsigned long long forcing_index(double t, double dtm
 }
 
 template <class Model, int MATH, bool DENSE, bool FIXED>
-__global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
+__global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kernel(const Rk45Args A)
 {
     using namespace dp;
     // XCD-aware block -> hillslope-chunk map: workgroups are dealt round-robin over the
@@ -124,12 +136,48 @@ __global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
     double h = FIXED ? A.fixed_step : A.h0;
     const double tf = A.tf;
     int next_q = 0;
+    int reject_count = 0;
+    int status = HLM_SYS_OK;
+    uint32_t n_attempt = 0, n_accept = 0;
     double* dense_row = nullptr;
     double tq_next = 0.0;
+    [[maybe_unused]] int qb = 0, qe = 0;
+    [[maybe_unused]] int* resume_i = nullptr;
     if constexpr (DENSE) {
-        dense_row = A.dense + (size_t)sys * (size_t)A.nq * NEQ;
-        // queries at or before t0 are never produced (rk45_kernel.cu:141): their slot is 0
+        // Query window [qb, qe) of this launch (the whole range unless the host streams the
+        // dense output in chunks, hlm_rk45_integrate_streamed).  A lane that has to write a
+        // query >= qe stops WITHOUT committing the step that contains it, saves
+        // {y, t, h, counters} and re-executes that same attempt in the next launch: the
+        // sequence of committed steps -- and every output bit -- equals the one-shot run.
+        qb = A.q_begin;
+        qe = A.q_end;
+        dense_row = A.dense + (size_t)sys * (size_t)(qe - qb) * NEQ - (size_t)qb * NEQ;
+        if (A.resume) {
+            resume_i = reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns);
+            if (A.resume_in) {
+                const int st = resume_i[(size_t)4 * A.ns + sys];
+                if (st != SYS_PAUSED) {
+                    // finished or flagged in an earlier window: its remaining slots are 0
+                    for (int q = qb; q < qe; ++q) {
+#pragma unroll
+                        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * NEQ + c] = 0.0;
+                    }
+                    return;
+                }
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
+                t = A.resume[(size_t)5 * A.ns + sys];
+                h = A.resume[(size_t)6 * A.ns + sys];
+                reject_count = resume_i[(size_t)0 * A.ns + sys];
+                n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
+                n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
+                next_q = resume_i[(size_t)3 * A.ns + sys];
+            }
+        }
+        // queries at or before the current time are never produced (rk45_kernel.cu:141):
+        // their slot is 0.  (No-op on a resumed lane: earlier steps consumed them.)
         while (next_q < A.nq && A.query[next_q] <= t) {
+            if (next_q >= qe) { status = SYS_PAUSED; break; }
 #pragma unroll
             for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * NEQ + c] = 0.0;
             ++next_q;
@@ -137,9 +185,6 @@ __global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
         tq_next = next_q < A.nq ? A.query[next_q] : __builtin_inf();
     }
 
-    int reject_count = 0;
-    int status = HLM_SYS_OK;
-    uint32_t n_attempt = 0, n_accept = 0;
     bool t_moved = true;   // forcing must be (re)sampled at the step's start time
     // k0 = rhs(t, y, F) is recomputed by the reference on every attempt (no FSAL,
     // rk45_kernel.cu:114).  It is a pure function of (t, y, F): after a reject or a
@@ -281,7 +326,9 @@ __global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
                     Q2[i] = lc(P02 * k0[i], P22, k2[i], P32, k3[i], P42, k4[i], P52, k5[i], P62, k6[i]);
                     Q3[i] = lc(P03 * k0[i], P23, k2[i], P33, k3[i], P43, k4[i], P53, k5[i], P63, k6[i]);
                 }
+                bool pause = false;
                 do {
+                    if (next_q >= qe) { pause = true; break; }
                     const double th = (tq_next - t) / h;  // rk45_kernel.cu:142
                     const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
                     double* o = dense_row + (size_t)next_q * NEQ;
@@ -293,6 +340,13 @@ __global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
                     ++next_q;
                     tq_next = next_q < A.nq ? A.query[next_q] : __builtin_inf();
                 } while (tq_next <= t1);
+                if (pause) {
+                    // the rest of this step's queries belong to the next window: leave the
+                    // step uncommitted (y, t, h unchanged) and redo it there
+                    status = SYS_PAUSED;
+                    --n_attempt;
+                    break;
+                }
             }
         }
 #pragma unroll
@@ -307,6 +361,23 @@ __global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
         else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
     }
 
+    if constexpr (DENSE) {
+        if (resume_i) {
+            resume_i[(size_t)4 * A.ns + sys] = status;
+            if (status == SYS_PAUSED) {
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
+                A.resume[(size_t)5 * A.ns + sys] = t;
+                A.resume[(size_t)6 * A.ns + sys] = h;
+                resume_i[(size_t)0 * A.ns + sys] = reject_count;
+                resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
+                resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
+                resume_i[(size_t)3 * A.ns + sys] = next_q;
+            }
+        }
+        if (status == SYS_PAUSED) return;  // outputs are written by the launch that finishes the lane
+    }
+
     if (A.n_attempt) A.n_attempt[sys] = n_attempt;
     if (A.n_accept) A.n_accept[sys] = n_accept;
     const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170
@@ -314,8 +385,9 @@ __global__ void __launch_bounds__(WAVE, 2) rk45_multi_kernel(const Rk45Args A)
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
     if constexpr (DENSE) {
-        // a flagged system never reaches its remaining queries: zero rows
-        for (; next_q < A.nq; ++next_q) {
+        // queries this lane never reaches (flagged, or later than tf): zero rows
+        const int q_stop = A.nq < qe ? A.nq : qe;
+        for (; next_q < q_stop; ++next_q) {
 #pragma unroll
             for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * NEQ + c] = 0.0;
         }

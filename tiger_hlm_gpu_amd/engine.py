@@ -14,7 +14,7 @@ from .models import Parameters, SP_DTYPE
 
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
-                 math_mode=_lib.MATH_STRICT, fixed_step=0.0, attempt_cap=0):
+                 math_mode=_lib.MATH_STRICT, fixed_step=0.0, attempt_cap=0, alloc_dense=True):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -40,7 +40,7 @@ class ShardEngine:
         self.forc_dt, self.forc_nT, self.forc_ld = (), (), 0
         self.y_final = torch.empty((self.ns, model.N_EQ), dtype=torch.float64, device=dev)
         self.dense = (torch.empty((self.ns, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
-                      if self.nq else None)
+                      if self.nq and alloc_dense else None)
         self.stiff = torch.empty(self.ns, dtype=torch.int32, device=dev)
         self.n_attempt = torch.empty(self.ns, dtype=torch.int32, device=dev)  # uint32 bits
         self.n_accept = torch.empty(self.ns, dtype=torch.int32, device=dev)
@@ -84,6 +84,24 @@ class ShardEngine:
         """Enqueue one pass of the hot path on ``stream`` (default: torch's current stream)."""
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         api.integrate_device(self.job(), s)
+
+    def integrate_streamed(self, window_queries, host_out=None, stream=None):
+        """BASELINE config 5: dense output streamed to pinned host memory in windows of
+        ``window_queries`` queries, D2H of window k overlapped with the integration of
+        window k+1.  Returns (host array [ns, nq, 5], stats dict).  The engine's own
+        ``dense`` buffer is not used (it may not even fit in HBM)."""
+        assert self.nq > 0
+        if host_out is None:
+            host_out = torch.empty((self.ns, self.nq, self.model.N_EQ), dtype=torch.float64, pin_memory=True)
+        arr = host_out.numpy() if torch.is_tensor(host_out) else host_out
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        keep, self.dense = self.dense, None
+        try:
+            job = self.job()
+        finally:
+            self.dense = keep
+        stats = api.integrate_streamed(job, window_queries, arr, s)
+        return arr, stats
 
     def total_attempts(self):
         return int(self.n_attempt.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
