@@ -57,6 +57,10 @@ def parse():
     ap.add_argument("--dense-stride", type=float, default=0.0,
                     help="minutes between dense queries (0 = no dense output)")
     ap.add_argument("--no-variants", action="store_true", help="skip the wet-surface variant pass")
+    ap.add_argument("--no-dense", action="store_true", help="skip the dense-output (config 5 style) section")
+    ap.add_argument("--dense-ns", type=int, default=65536)
+    ap.add_argument("--dense-days", type=int, default=2)
+    ap.add_argument("--dense-window", type=int, default=720, help="queries per streamed window")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -133,6 +137,39 @@ def timed_passes(eng, total, world, warmup, steps):
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     return wall, kernel_ms
+
+
+def dense_section(args):
+    """BASELINE config 5 shape on one GPU: 1-minute query stride, dense output streamed to
+    pinned host memory in query windows with the D2H of window k overlapped with the
+    integration of window k+1.  dense-output MB/s = ns*nq*5*8 B / wall time until the bytes
+    are in host memory in [sys][q][comp] order."""
+    ns, days = args.dense_ns, args.dense_days
+    sp = synth.model204_params(0, ns)
+    y0 = synth.model204_y0(ns)
+    cells = synth.cell_of_system(0, ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days)
+    tf = days * 1440.0
+    q = synth.minute_queries(0.0, tf, 1.0)
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, alloc_dense=False,
+                      math_mode=H.MATH_FAST if args.math == "fast" else H.MATH_STRICT,
+                      device=f"cuda:{torch.cuda.current_device()}")
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    host = torch.empty((ns, len(q), 5), dtype=torch.float64, pin_memory=True)
+    eng.integrate_streamed(args.dense_window, host_out=host)          # warm-up (also faults the pages in)
+    torch.cuda.synchronize()
+    _, st = eng.integrate_streamed(args.dense_window, host_out=host)
+    attempts = eng.total_attempts()
+    algo_bytes = st["dense_bytes"] + ns * B_SYS + 4.0 * sum(eng.forc_nT) * ns
+    hbm = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9
+    return {"workload": f"Model 204, {ns} hillslopes, {days} days, query every 1 min (nq={len(q)}), "
+                        f"{st['windows']} windows of {args.dense_window} queries, math={args.math}",
+            "dense_output_MBps": st["dense_bytes"] / (st["wall_ms"] * 1e-3) / 1e6,
+            "dense_bytes": st["dense_bytes"], "wall_ms": st["wall_ms"], "kernel_ms_sum": st["kernel_ms"],
+            "d2h_ms_sum": st["copy_ms"], "steps_per_s_kernel_only": attempts / (st["kernel_ms"] * 1e-3),
+            "roofline_hbm_kernel": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                    "frac": hbm / PEAK_HBM_GBS, "algorithmic_bytes": algo_bytes},
+            "pcie_GBps": st["dense_bytes"] / (st["copy_ms"] * 1e-3) / 1e9}
 
 
 def cpu_baseline(args):
@@ -248,6 +285,9 @@ def main():
                          "valu_fp64_frac": av * F_STEP_204 / (kms[0] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS}
             del engv
             torch.cuda.empty_cache()
+
+    if rank == 0 and world == 1 and not args.no_dense:
+        out["dense_output"] = dense_section(args)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)

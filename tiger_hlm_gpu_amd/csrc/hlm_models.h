@@ -110,7 +110,7 @@ struct Model204Dev {
         double rain;     // F[0]
         double melt_pot; // temperature * melt_f
         double e_pot;    // 0.1 * temperature   (the linear ET stub, :96)
-        bool warm;       // temperature >= temp_thr
+        unsigned long long warm_mask;  // all ones if temperature >= temp_thr, else 0
     };
 
     template <int MATH>
@@ -147,7 +147,7 @@ struct Model204Dev {
         F.rain = rainfall;
         F.melt_pot = temperature * P.melt_f;
         F.e_pot = 0.1 * temperature;
-        F.warm = temperature >= P.temp_thr;
+        F.warm_mask = temperature >= P.temp_thr ? ~0ull : 0ull;
         return F;
     }
 
@@ -158,7 +158,9 @@ struct Model204Dev {
         const double h_snow = y[0], h_stat = y[1], h_surf = y[2], h_grav = y[3], h_aq = y[4];
 
         // snow (:87-91)
-        const double snowmelt = F.warm ? vmin(h_snow, F.melt_pot) : 0.0;
+        // (T >= thr) ? fmin(h_snow, T*melt_f) : 0.0 as min + bit-mask: no exec-mask branch
+        const double snowmelt =
+            __longlong_as_double(__double_as_longlong(vmin(h_snow, F.melt_pot)) & (long long)F.warm_mask);
         const double x1 = F.rain + snowmelt;
         dydt[0] = F.rain - snowmelt;
 
