@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--layout", choices=["per-stream", "per-cell"], default="per-stream")
     ap.add_argument("--dense-stride", type=float, default=0.0,
                     help="minutes between dense queries (0 = no dense output)")
+    ap.add_argument("--dense-tiled", action="store_true",
+                    help="with --dense-stride: tile-major device layout (kernel measurement only)")
     ap.add_argument("--no-variants", action="store_true", help="skip the wet-surface variant pass")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-output (config 5 style) section")
     ap.add_argument("--dense-ns", type=int, default=65536)
@@ -90,7 +92,7 @@ def build_engine(args, rank, world, wet, math=None):
     q = synth.minute_queries(0.0, tf, args.dense_stride) if args.dense_stride > 0 else None
     eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q,
                       math_mode=H.MATH_FAST if (math or args.math) == "fast" else H.MATH_STRICT,
-                      device=f"cuda:{torch.cuda.current_device()}")
+                      device=f"cuda:{torch.cuda.current_device()}", dense_tiled=args.dense_tiled)
     if args.layout == "per-stream":
         eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     else:

@@ -172,6 +172,10 @@ typedef struct hlm_device_job {
     int query_begin, query_end;
     void* d_resume;
     int resume_in;
+    /* 0: d_dense is [ns][W][5] (W = window length, nq when no window): the host-facing order.
+     * 1: tile-major [ceil(ns/64)][W][64][5]: what hlm_rk45_integrate_streamed uses internally
+     *    (fully coalesced row stores); a caller using it must transpose itself. */
+    int dense_tiled;
 } hlm_device_job;
 
 size_t hlm_resume_bytes(int num_systems);
@@ -201,6 +205,11 @@ typedef struct hlm_stream_stats {
 } hlm_stream_stats;
 int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, double* h_dense,
                                 void* hip_stream, hlm_stream_stats* stats);
+/* Transfer path of hlm_rk45_integrate_streamed.  0 (default): linear device windows +
+ * hipMemcpy2DAsync on the copy engine (fastest end to end: 54.8 GB/s measured).  1: tile-major
+ * device windows (coalesced kernel stores) + a transposing kernel that writes pinned host
+ * memory directly (51.5 GB/s; falls back to path 0 when h_dense is not pinned). */
+int hlm_set_stream_path(int path);
 int hlm_host_alloc_pinned(void** hptr, size_t bytes);
 int hlm_host_free_pinned(void* hptr);
 

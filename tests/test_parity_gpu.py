@@ -321,8 +321,9 @@ def test_cpp_driver_model204_g2(gpu, golden, tmp_path):
 
 
 # ---- dense output in query windows (BASELINE config 5) ------------------------------------------
+@pytest.mark.parametrize("path", ["transfer-kernel", "copy-engine", "pageable"])
 @pytest.mark.parametrize("window", [1, 7, 48, 1000])
-def test_streamed_dense_equals_one_shot_bitwise(gpu, window):
+def test_streamed_dense_equals_one_shot_bitwise(gpu, window, path):
     """The windowed run pauses a lane before it commits a step whose queries cross the
     window end and redoes that attempt in the next launch, so finals, flags, counters and
     every dense value equal the one-shot run bit for bit, for any window size."""
@@ -336,7 +337,12 @@ def test_streamed_dense_equals_one_shot_bitwise(gpu, window):
     eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     eng.integrate()
     one = eng.results()
-    host, stats = eng.integrate_streamed(window)
+    H._lib.lib().hlm_set_stream_path(1 if path == "transfer-kernel" else 0)
+    try:
+        host_out = np.full((ns, len(q), 5), np.nan) if path == "pageable" else None
+        host, stats = eng.integrate_streamed(window, host_out=host_out)
+    finally:
+        H._lib.lib().hlm_set_stream_path(0)
     two = eng.results()
     assert stats["windows"] == -(-len(q) // min(window, len(q))) and stats["dense_bytes"] == ns * len(q) * 40
     assert np.array_equal(host, one["dense"])

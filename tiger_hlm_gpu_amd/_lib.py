@@ -52,6 +52,7 @@ class DeviceJob(C.Structure):
         ("d_y_final", C.c_void_p), ("d_dense", C.c_void_p), ("d_stiff", C.c_void_p),
         ("d_n_attempt", C.c_void_p), ("d_n_accept", C.c_void_p),
         ("query_begin", C.c_int), ("query_end", C.c_int), ("d_resume", C.c_void_p), ("resume_in", C.c_int),
+        ("dense_tiled", C.c_int),
     ]
 
 
@@ -90,6 +91,7 @@ SIGNATURES = {
     "hlm_resume_bytes": (C.c_size_t, [C.c_int]),
     "hlm_rk45_integrate_streamed": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p,
                                               C.POINTER(StreamStats)]),
+    "hlm_set_stream_path": (C.c_int, [C.c_int]),
     "hlm_host_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "hlm_host_free_pinned": (C.c_int, [C.c_void_p]),
     "hlm_rk45_time_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p, C.c_int, C.POINTER(C.c_float)]),

@@ -45,7 +45,8 @@ struct Rk45Args {
     double fixed_step;
     uint32_t cap;
     double* y_final;     // [ns][5]
-    double* dense;       // [ns][q_end - q_begin][5]: the rows of this launch's query window
+    double* dense;       // rows of this launch's query window, linear [ns][W][5] or tile-major
+    int dense_tiled;     // 1: [ceil(ns/64)][W][64][5] (W = q_end - q_begin), coalesced across a wave
     int q_begin, q_end;  // global query indices [q_begin, q_end) written by this launch
     double* resume;      // nullable: per-system integrator state carried between windows
     int resume_in;       // 0 = start from y0, 1 = continue from `resume`
@@ -186,6 +187,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     int status = HLM_SYS_OK;
     uint32_t n_attempt = 0, n_accept = 0;
     double* dense_row = nullptr;
+    [[maybe_unused]] size_t q_stride = NEQ;
     double tq_next = 0.0;
     __shared__ double lds_rows[DENSE && DENSE_KQ > 0 ? WAVE * DENSE_LROW : 1];
     __shared__ double lds_query[DENSE ? DENSE_QWIN : 1];
@@ -213,7 +215,17 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         // sequence of committed steps -- and every output bit -- equals the one-shot run.
         qb = A.q_begin;
         qe = A.q_end;
-        dense_row = A.dense + (size_t)sys * (size_t)(qe - qb) * NEQ - (size_t)qb * NEQ;
+        // row(q) = dense_row + q * q_stride.  Linear layout: the host-facing [sys][q][comp].
+        // Tile-major layout [sys/64][q][sys%64][comp]: the 64 lanes of a wave write one
+        // contiguous 2560-byte row block per query (full cache lines, no write
+        // amplification); dense_tile_to_host() transposes it on its way to host memory.
+        if (A.dense_tiled) {
+            q_stride = (size_t)WAVE * NEQ;
+            dense_row = A.dense + ((size_t)(sys / WAVE) * (size_t)(qe - qb) - (size_t)qb) * q_stride + (size_t)(sys % WAVE) * NEQ;
+        } else {
+            q_stride = NEQ;
+            dense_row = A.dense + ((size_t)sys * (size_t)(qe - qb) - (size_t)qb) * NEQ;
+        }
         if (A.resume) {
             resume_i = reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns);
             if (A.resume_in) {
@@ -222,7 +234,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
                     // finished or flagged in an earlier window: its remaining slots are 0
                     for (int q = qb; q < qe; ++q) {
 #pragma unroll
-                        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * NEQ + c] = 0.0;
+                        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * q_stride + c] = 0.0;
                     }
                     return;
                 }
@@ -241,7 +253,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         while (next_q < A.nq && A.query[next_q] <= t) {
             if (next_q >= qe) { status = SYS_PAUSED; break; }
 #pragma unroll
-            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * NEQ + c] = 0.0;
+            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
             ++next_q;
         }
         tq_next = next_q < A.nq ? A.query[next_q] : __builtin_inf();
@@ -412,7 +424,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
                     double th;  // rk45_kernel.cu:142
                     if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
                     const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
-                    double* o = dense_row + (size_t)next_q * NEQ;
+                    double* o = dense_row + (size_t)next_q * q_stride;
                     double row[NEQ];
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) {
@@ -483,7 +495,37 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         const int q_stop = A.nq < qe ? A.nq : qe;
         for (; next_q < q_stop; ++next_q) {
 #pragma unroll
-            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * NEQ + c] = 0.0;
+            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
+        }
+    }
+}
+
+// ---- tile-major window -> host order -------------------------------------------------------
+// Transposes one query window from the kernel's tile-major layout [blk][W][64][5] to the
+// host-facing order dst[(sys*nq + q)*5 + c] (rk45_api.hpp:255-267).  dst is normally PINNED
+// HOST memory mapped into the device: the kernel IS the device-to-host transfer (PCIe
+// writes in 640-byte contiguous runs), running on its own stream beside the integration of
+// the next window.  One workgroup = 64 systems x TQ queries staged through LDS.
+constexpr int TILE_TQ = 16;
+
+__global__ void __launch_bounds__(256) dense_tile_to_host(const double* __restrict__ src, double* __restrict__ dst,
+                                                          int ns, int nq, int q_begin, int W)
+{
+    __shared__ double tile[TILE_TQ * WAVE * NEQ];  // 40 KB: [ql][lane][c]
+    const int blk = blockIdx.x, q0 = blockIdx.y * TILE_TQ;
+    const int nql = (W - q0) < TILE_TQ ? (W - q0) : TILE_TQ;
+    const int n_in = nql * WAVE * NEQ;
+    const double* s = src + ((size_t)blk * (size_t)W + (size_t)q0) * (WAVE * NEQ);
+    for (int i = threadIdx.x; i < n_in; i += 256) tile[i] = s[i];  // contiguous, coalesced
+    __syncthreads();
+    const int row_len = nql * NEQ;  // doubles each system contributes: contiguous in dst
+    const int n_out = WAVE * row_len;
+    for (int o = threadIdx.x; o < n_out; o += 256) {
+        const int l = o / row_len, r = o - l * row_len;
+        const int sys = blk * WAVE + l;
+        if (sys < ns) {
+            const int ql = r / NEQ, c = r - ql * NEQ;
+            dst[((size_t)sys * (size_t)nq + (size_t)(q_begin + q0)) * NEQ + r] = tile[(ql * WAVE + l) * NEQ + c];
         }
     }
 }

@@ -14,7 +14,8 @@ from .models import Parameters, SP_DTYPE
 
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
-                 math_mode=_lib.MATH_STRICT, fixed_step=0.0, attempt_cap=0, alloc_dense=True):
+                 math_mode=_lib.MATH_STRICT, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
+                 dense_tiled=False):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -39,7 +40,11 @@ class ShardEngine:
         self.forc = self.forc_col = None
         self.forc_dt, self.forc_nT, self.forc_ld = (), (), 0
         self.y_final = torch.empty((self.ns, model.N_EQ), dtype=torch.float64, device=dev)
-        self.dense = (torch.empty((self.ns, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
+        # dense_tiled: tile-major [ceil(ns/64)][nq][64][5] device layout (what the streamed path
+        # uses internally); only for measuring the kernel -- results() then returns that layout
+        self.dense_tiled = bool(dense_tiled)
+        rows = -(-self.ns // 64) * 64 if self.dense_tiled else self.ns
+        self.dense = (torch.empty((rows, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
                       if self.nq and alloc_dense else None)
         self.stiff = torch.empty(self.ns, dtype=torch.int32, device=dev)
         self.n_attempt = torch.empty(self.ns, dtype=torch.int32, device=dev)  # uint32 bits
@@ -73,12 +78,14 @@ class ShardEngine:
 
     # -- run -------------------------------------------------------------------------------
     def job(self):
-        return api.make_device_job(
+        j = api.make_device_job(
             self.model, y0=self.y0, t0=self.t0, tf=self.tf, query=self.query, sp=self.sp,
             forc=self.forc, forc_dt_hours=self.forc_dt, forc_nT=self.forc_nT, forc_ld=self.forc_ld,
             forc_col=self.forc_col, params=self.params, fixed_step=self.fixed_step,
             attempt_cap=self.attempt_cap, math_mode=self.math_mode, y_final=self.y_final,
             dense=self.dense, stiff=self.stiff, n_attempt=self.n_attempt, n_accept=self.n_accept)
+        j.dense_tiled = int(self.dense_tiled and self.dense is not None)
+        return j
 
     def integrate(self, stream=None):
         """Enqueue one pass of the hot path on ``stream`` (default: torch's current stream)."""
