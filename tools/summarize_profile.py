@@ -71,6 +71,8 @@ if "hbm_bytes_per_launch" in out:
     json.dump({"tag": tag, "hbm_bytes_per_launch": out["hbm_bytes_per_launch"],
                "hbm_read_bytes_per_launch": out["hbm_read_bytes_per_launch"],
                "hbm_write_bytes_per_launch": out["hbm_write_bytes_per_launch"],
-               "workload": out.get("bench_line_under_trace", {}).get("config", {}).get("workload")},
+               "workload": out.get("bench_line_under_trace", {}).get("config", {}).get("workload"),
+               "hillslopes_per_gpu": out.get("bench_line_under_trace", {}).get("config", {}).get("hillslopes_per_gpu"),
+               "per_gpu_key": out.get("bench_line_under_trace", {}).get("config", {}).get("per_gpu_key")},
               open(os.path.join(prof, "traffic_latest.json"), "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k != "bench_line_under_trace"}, indent=1))
