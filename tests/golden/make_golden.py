@@ -63,6 +63,10 @@ def main():
     else:
         np.save(f"{HERE}/g2_m204_dense.npy", den)
     shutil.copyfile(f"{REF}/data/small_test.csv", f"{HERE}/small_test.csv")
+    # the two NetCDF-4 result files themselves (data, written by netcdf 4.9.2 / hdf5 1.14.4):
+    # fixtures for the HDF5-based NetCDF reader, include/hlm/netcdf4_io.hpp
+    shutil.copyfile(f"{REF}/src/final_example.nc", f"{HERE}/final_example.nc")
+    shutil.copyfile(f"{REF}/src/dense_example.nc", f"{HERE}/dense_example.nc")
     meta["g2"] = {"source": ["src/final_example.nc", "src/dense_example.nc", "data/small_test.csv"],
                   "nsys": 10, "nq": 2881, "all_systems_identical": ident,
                   "inputs": "Model 204, params data/small_test.csv via loadSpatialParams, "

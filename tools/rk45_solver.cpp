@@ -16,9 +16,13 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "hlm/forcing.hpp"
+#ifdef HLM_WITH_HDF5
+#include "hlm/netcdf4_io.hpp"  // NetCDFLoader, write_final_netcdf, write_dense_netcdf
+#endif
 #include "hlm/model_registry.hpp"
 #include "hlm/models/model_204.hpp"
 #include "hlm/models/model_dummy.hpp"
@@ -40,6 +44,12 @@ struct Options {
     bool scipy_h0 = false;
     std::string math = "strict";
     std::string out_final = "final.csv", out_dense = "dense.csv";
+    // NetCDF forcings "file:var:dt_hours" in forcing order (main.cpp:513-514: pr 1 h, t2m 24 h)
+    std::vector<std::string> forcing_nc;
+    std::string lookup;           // stream,lat_index,lon_index CSV (main.cpp:495)
+    bool expand_forcings = false; // reference per-stream layout instead of the per-cell table
+    std::string out_format = "csv";  // csv | nc | both  (nc: main.cpp:786-823)
+    int nc_compression = 0;
     int device = 0;
     bool quiet = false;
 };
@@ -51,7 +61,9 @@ struct Options {
                  "usage: rk45_solver [--model dummy|204] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast]\n"
-                 "                   [--out-final F] [--out-dense F] [--device D] [--quiet]\n");
+                 "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings]\n"
+                 "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L]\n"
+                 "                   [--device D] [--quiet]\n");
     std::exit(msg ? 2 : 0);
 }
 
@@ -80,6 +92,11 @@ Options parse(int argc, char** argv)
         else if (a == "--math") o.math = val();
         else if (a == "--out-final") o.out_final = val();
         else if (a == "--out-dense") o.out_dense = val();
+        else if (a == "--forcing-nc") o.forcing_nc.push_back(val());
+        else if (a == "--lookup") o.lookup = val();
+        else if (a == "--expand-forcings") o.expand_forcings = true;
+        else if (a == "--out-format") o.out_format = val();
+        else if (a == "--nc-compression") o.nc_compression = std::atoi(val());
         else if (a == "--device") o.device = std::atoi(val());
         else if (a == "--quiet") o.quiet = true;
         else if (a == "-h" || a == "--help") usage(nullptr);
@@ -132,8 +149,65 @@ int run(const Options& o, hlm_io::CsvStyle style)
     rk45_api::detail::check(hlm_set_device(o.device), "hlm_set_device");
     SpatialParams* d_sp = rk45_api::device_upload(spatial.data(), spatial.size());
     float* d_forc = nullptr;
+    int32_t* d_col = nullptr;
     ForcingBlock fb;
-    if (is204) {
+    if (is204 && !o.forcing_nc.empty()) {
+#ifdef HLM_WITH_HDF5
+        // NetCDF (time, lat, lon) forcings through the lookup table (main.cpp:495-549).  The
+        // reference expands every forcing to one column per stream; by default this driver
+        // keeps ONE column per distinct grid cell plus an int32 column index per stream
+        // (41 274 streams map to 88 cells in the sample lookup) -- same values, 1/469 of the bytes.
+        if (o.lookup.empty()) usage("--forcing-nc needs --lookup <csv>");
+        LookupMapper lm(o.lookup);
+        if (!lm.load()) throw std::runtime_error("Lookup load failed: " + o.lookup);
+        std::vector<int32_t> col_of_stream(ns);
+        std::vector<size_t> cell_of_col;
+        std::unordered_map<size_t, int32_t> col_of_cell;
+        size_t lon_size = 0;
+        const double days = std::ceil((tf - t0) / 1440.0);
+        for (size_t fi = 0; fi < o.forcing_nc.size(); ++fi) {
+            const std::string& spec = o.forcing_nc[fi];
+            const size_t c2 = spec.rfind(':'), c1 = c2 == std::string::npos ? c2 : spec.rfind(':', c2 - 1);
+            if (c1 == std::string::npos) usage("--forcing-nc expects FILE:VAR:DT_HOURS");
+            const std::string path = spec.substr(0, c1), var = spec.substr(c1 + 1, c2 - c1 - 1);
+            const double dt_h = std::atof(spec.substr(c2 + 1).c_str());
+            if (!(dt_h > 0)) usage("--forcing-nc: DT_HOURS must be > 0");
+            NetCDFLoader loader(path, var);
+            if (fi == 0) {
+                lon_size = loader.getLonSize();
+                for (int s = 0; s < ns; ++s) {
+                    const auto [lat, lon] = lm.getLatLon(streams[s].id);
+                    if (lat < 0 || lon < 0 || (size_t)lat >= loader.getLatSize() || (size_t)lon >= lon_size)
+                        throw std::runtime_error("stream " + std::to_string(streams[s].id) + " has no valid grid cell in " + o.lookup);
+                    const size_t cell = (size_t)lat * lon_size + (size_t)lon;  // main.cpp:503-504
+                    if (o.expand_forcings) { col_of_stream[s] = s; cell_of_col.push_back(cell); continue; }
+                    auto it = col_of_cell.find(cell);
+                    if (it == col_of_cell.end()) {
+                        it = col_of_cell.emplace(cell, (int32_t)cell_of_col.size()).first;
+                        cell_of_col.push_back(cell);
+                    }
+                    col_of_stream[s] = it->second;
+                }
+                fb.ld = (long long)cell_of_col.size();
+            } else if (loader.getLonSize() != lon_size) {
+                throw std::runtime_error("forcing grids differ: " + path);
+            }
+            size_t steps = (size_t)std::llround(days * 24.0 / dt_h);  // main.cpp:531-533
+            steps = std::max<size_t>(1, std::min(loader.getTimeSize(), steps));
+            const auto raw = loader.loadTimeChunk(0, steps);
+            const size_t grid = loader.getLatSize() * loader.getLonSize();
+            std::vector<float> table(steps * cell_of_col.size());
+            for (size_t t = 0; t < steps; ++t)
+                for (size_t c = 0; c < cell_of_col.size(); ++c) table[t * cell_of_col.size() + c] = raw[t * grid + cell_of_col[c]];
+            fb.add(table, steps, dt_h);
+        }
+        d_forc = rk45_api::device_upload(fb.data.data(), fb.data.size());
+        if (!o.expand_forcings) d_col = rk45_api::device_upload(col_of_stream.data(), col_of_stream.size());
+        rk45_api::set_forcings(d_forc, fb.dt_hours, fb.nT, fb.ld, d_col);
+#else
+        usage("--forcing-nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
+#endif
+    } else if (is204) {
         // constant rain / temperature held over the window, in the reference's flattened
         // [forcing][time][stream] layout with hourly and daily sampling (main.cpp:513-549)
         fb.ld = ns;
@@ -174,8 +248,24 @@ int run(const Options& o, hlm_io::CsvStyle style)
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
     const rk45_api::RunInfo info = rk45_api::last_run_info();
 
-    hlm_io::write_final_csv(o.out_final, h_y_final, ns, N_EQ, style);
-    hlm_io::write_dense_csv(o.out_dense, h_dense, h_query_times, ns, N_EQ, style);
+    if (o.out_format == "csv" || o.out_format == "both") {
+        hlm_io::write_final_csv(o.out_final, h_y_final, ns, N_EQ, style);
+        hlm_io::write_dense_csv(o.out_dense, h_dense, h_query_times, ns, N_EQ, style);
+    }
+    if (o.out_format == "nc" || o.out_format == "both") {
+#ifdef HLM_WITH_HDF5
+        // main.cpp:786-823: system = 0..ns-1 (not link ids), variable = 0..N_EQ-1
+        std::vector<int> linkid_vals(ns), state_vals(N_EQ);
+        for (int s = 0; s < ns; ++s) linkid_vals[s] = s;
+        for (int v = 0; v < N_EQ; ++v) state_vals[v] = v;
+        auto nc_name = [](std::string p) { const size_t d = p.rfind('.'); return (d == std::string::npos ? p : p.substr(0, d)) + ".nc"; };
+        write_final_netcdf(nc_name(o.out_final), h_y_final.data(), linkid_vals.data(), state_vals.data(), ns, N_EQ, o.nc_compression);
+        write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
+                           (int)h_query_times.size(), ns, N_EQ, o.nc_compression);
+#else
+        usage("--out-format nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
+#endif
+    }
 
     unsigned long long attempts = 0;
     int flagged = 0;
@@ -192,6 +282,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
 
     rk45_api::device_free(d_sp);
     if (d_forc) { hlm_clear_forcings(); rk45_api::device_free(d_forc); }
+    if (d_col) rk45_api::device_free(d_col);
     return 0;
 }
 
