@@ -3,7 +3,8 @@
 // A device model provides
 //   UID, NF (how many forcings rhs reads), struct Local (per-system constants kept in
 //   VGPRs for the whole integration), struct Forc (values derived from the held forcing
-//   samples), load(sp, sys), prep_forcing(P, F0, F1) and rhs<MATH>(P, F, y, dydt).
+//   samples), load(sp, sys), prep_forcing(P, F0, F1), rhs<MATH>(P, F, y, dydt) and optionally
+//   (HAS_FASTPATH) a cheaper rhs_fast that is exact while fastpath_ok(y) holds.
 // This is the device half of the reference's plug-in concept (Model::UID / SP_TYPE /
 // rhs, reference src/models/model_204.hpp:15-115); the host half is include/hlm/models/.
 #pragma once
@@ -151,9 +152,28 @@ struct Model204Dev {
         return F;
     }
 
+    // Fast path: while the surface store is exactly 0, pow(0, 2/3) == 0 makes alfa2 == 0,
+    // w == 0 and dydt[2] == d2 - 0 (model_204.hpp:103-105), so the Manning term can be
+    // left out bit-exactly.  rhs_fast reports d2 != 0 (inflow: the next stage state is wet).
+    static constexpr bool HAS_FASTPATH = true;
+    static __device__ __forceinline__ bool fastpath_ok(const double (&y)[HLM_NEQ]) { return y[2] == 0.0; }
+
     template <int MATH>
     static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
                                                double (&dydt)[HLM_NEQ])
+    {
+        (void)rhs_impl<MATH, false>(P, F, y, dydt);
+    }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_fast(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
+                                                    double (&dydt)[HLM_NEQ])
+    {
+        return rhs_impl<MATH, true>(P, F, y, dydt);
+    }
+
+    template <int MATH, bool DRY>
+    static __device__ __forceinline__ bool rhs_impl(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
+                                                    double (&dydt)[HLM_NEQ])
     {
         const double h_snow = y[0], h_stat = y[1], h_surf = y[2], h_grav = y[3], h_aq = y[4];
 
@@ -178,7 +198,7 @@ struct Model204Dev {
         const double x3 = vmin(x2, P.infil);
         const double d2 = x2 - x3;
         double out2 = d2;
-        if (h_surf != 0.0) {
+        if (!DRY && h_surf != 0.0) {
             double w;
             if constexpr (MATH == MATH_FAST) {
                 w = vmin(1.0, P.manning * pow_two_thirds<MATH>(h_surf));
@@ -200,6 +220,7 @@ struct Model204Dev {
             dydt[3] = d3 - (P.alpha3 >= 1.0 ? h_grav / P.alpha3 : 0.0);
             dydt[4] = x4 - (P.alpha4 >= 1.0 ? h_aq / P.alpha4 : 0.0);
         }
+        return DRY && d2 != 0.0;
     }
 };
 
@@ -213,6 +234,11 @@ struct DummyDev {
     static constexpr int NF = 0;
     struct Local {};
     struct Forc {};
+    static constexpr bool HAS_FASTPATH = false;
+    static __device__ __forceinline__ bool fastpath_ok(const double (&)[HLM_NEQ]) { return false; }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[HLM_NEQ],
+                                                    double (&)[HLM_NEQ]) { return true; }
 
     template <int MATH>
     static __device__ __forceinline__ Local load(const void*, int) { return Local{}; }

@@ -100,6 +100,65 @@ __device__ __forceinline__ unsigned long long forcing_index(double t, double dtm
     return (r < 0.0) ? 0ull : (r >= (double)nT ? nT - 1ull : (unsigned long long)r);
 }
 
+// ---- the 7 stages of one attempt ---------------------------------------------------------
+// k0 = rhs(y) unless still valid, k1..k6, and yt = the stage-6 state (= the 5th-order solution).
+// FAST selects Model::rhs_fast (exact while Model::fastpath_ok holds); the return value tells
+// whether any stage left that regime (always false for the general path).
+template <class Model, int MATH, bool FAST>
+__device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const typename Model::Forc& FV,
+                                          const double (&y)[NEQ], double h, bool have_k0, double (&k0)[NEQ],
+                                          double (&k1)[NEQ], double (&k2)[NEQ], double (&k3)[NEQ], double (&k4)[NEQ],
+                                          double (&k5)[NEQ], double (&k6)[NEQ], double (&yt)[NEQ])
+{
+    using namespace dp;
+    bool broke = false;
+    auto f = [&](const double (&state)[NEQ], double (&slope)[NEQ]) {
+        if constexpr (FAST) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
+        else Model::template rhs<MATH>(P, FV, state, slope);
+    };
+    if (!have_k0) f(y, k0);  // no FSAL in the reference: see the have_k0 comment in the kernel
+    {
+        const double a10 = h * A10;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a10, k0[i]);
+        f(yt, k1);
+    }
+    {
+        const double a20 = h * A20, a21 = h * A21;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a20, k0[i], a21, k1[i]);
+        f(yt, k2);
+    }
+    {
+        const double a30 = h * A30, a31 = h * A31, a32 = h * A32;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]);
+        f(yt, k3);
+    }
+    {
+        const double a40 = h * A40, a41 = h * A41, a42 = h * A42, a43 = h * A43;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]);
+        f(yt, k4);
+    }
+    {
+        const double a50 = h * A50, a51 = h * A51, a52 = h * A52, a53 = h * A53, a54 = h * A54;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i)
+            yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
+        f(yt, k5);
+    }
+    {
+        // stage 6 state: row 6 of a is b (rk45_step_dense.cuh:66-68)
+        const double hb0 = h * B0, hb2 = h * B2, hb3 = h * B3, hb4 = h * B4, hb5 = h * B5;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i)
+            yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
+        f(yt, k6);
+    }
+    return broke;
+}
+
 // ---- dense-output staging -----------------------------------------------------------------
 // The host-facing dense layout is [sys][query][comp]: a lane's rows are contiguous in
 // memory (40 B per query) but the 64 lanes of a wave are nq*40 B apart, so a row store
@@ -310,50 +369,23 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         }
 
         ++n_attempt;
-        // ---- 7 stages -------------------------------------------------------------------
+        // ---- 7 stages (rk_stages below) ---------------------------------------------------
+        // A model may offer a cheaper RHS that is exact while its per-lane precondition holds
+        // (Model 204: surface store == 0, the Manning term vanishes).  The wave takes it only
+        // when ALL its lanes qualify, and every stage reports whether the precondition broke
+        // during the step (inflow reached the surface store); if it did for any lane the
+        // attempt is simply recomputed with the general RHS -- same bits either way.
         double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
-        if (!have_k0) Model::template rhs<MATH>(P, FV, y, k0);
+        bool general = true;
+        if constexpr (Model::HAS_FASTPATH) {
+            if (__builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
+                const bool broke = rk_stages<Model, MATH, true>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+                have_k0 = true;  // k0 of a qualifying state is exact
+                general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+            }
+        }
+        if (general) rk_stages<Model, MATH, false>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
         have_k0 = true;  // stays valid through a reject / slope-jump retry
-        {
-            const double a10 = h * A10;
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a10, k0[i]);
-            Model::template rhs<MATH>(P, FV, yt, k1);
-        }
-        {
-            const double a20 = h * A20, a21 = h * A21;
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a20, k0[i], a21, k1[i]);
-            Model::template rhs<MATH>(P, FV, yt, k2);
-        }
-        {
-            const double a30 = h * A30, a31 = h * A31, a32 = h * A32;
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]);
-            Model::template rhs<MATH>(P, FV, yt, k3);
-        }
-        {
-            const double a40 = h * A40, a41 = h * A41, a42 = h * A42, a43 = h * A43;
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i)
-                yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]);
-            Model::template rhs<MATH>(P, FV, yt, k4);
-        }
-        {
-            const double a50 = h * A50, a51 = h * A51, a52 = h * A52, a53 = h * A53, a54 = h * A54;
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i)
-                yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
-            Model::template rhs<MATH>(P, FV, yt, k5);
-        }
-        const double hb0 = h * B0, hb2 = h * B2, hb3 = h * B3, hb4 = h * B4, hb5 = h * B5;
-        {
-            // stage 6 state: row 6 of a is b (rk45_step_dense.cuh:66-68)
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i)
-                yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
-            Model::template rhs<MATH>(P, FV, yt, k6);
-        }
         // 5th-order solution (rk45_step_dense.cuh:111-117).  b[6] = 0, so it is the same
         // chain of operations as the stage-6 state: identical bits, reuse it.
 #pragma unroll
