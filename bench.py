@@ -264,7 +264,6 @@ def main():
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            same = (tj.get("workload") or "").replace("(%d total)" % tj.get("total", -1), "")
             if tj.get("hillslopes_per_gpu") == eng.ns and tj.get("per_gpu_key") == _per_gpu_key(args, nq):
                 traffic = tj.get("hbm_bytes_per_launch")
         except Exception:

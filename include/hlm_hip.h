@@ -12,10 +12,10 @@
  * (rk45_api::setModelParameters<M>, run_rk45<M>, ...) lives in include/hlm/ and
  * forwards to these functions.
  *
- * Threading: like the reference (global devParams + forcing symbols) the model
- * registry and forcing registration are process-global state; one integration may be
- * in flight per device.  hlm_rk45_integrate_device() itself is re-entrant (all state
- * is in the job struct).
+ * Threading: like the reference (global devParams + forcing symbols) the model registry is
+ * process-global state and the forcing registration is per HIP device (the current device of
+ * the calling thread); one host-API integration may be in flight per device.
+ * hlm_rk45_integrate_device() itself is re-entrant (all state is in the job struct).
  */
 #ifndef HLM_HIP_H
 #define HLM_HIP_H

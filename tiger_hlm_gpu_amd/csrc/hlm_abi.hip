@@ -57,7 +57,18 @@ struct ForcingState {
     double dt_h[HLM_MAX_FORCINGS] = {};
     uint64_t nT[HLM_MAX_FORCINGS] = {};
     int nforc = 0;
-} g_forc;
+};
+// one registration per HIP device: d_forc is a device pointer, and a host process may drive
+// several GPUs (one thread each) through the host-buffer API
+constexpr int kMaxDevices = 64;
+ForcingState g_forc_dev[kMaxDevices];
+ForcingState& forc_state()
+{
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) { (void)hipGetLastError(); d = 0; }
+    return g_forc_dev[d];
+}
+#define g_forc forc_state()
 
 ModelState* find_model(int uid)
 {
