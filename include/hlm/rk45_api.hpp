@@ -47,8 +47,12 @@ namespace detail {
 struct Live {
     std::mutex mu;
     std::map<const void*, hlm_gpu_buffers> by_y0;  // buffers handed out by setup_gpu_buffers
-    RunInfo last;
 };
+inline RunInfo& last_info()
+{
+    static thread_local RunInfo info;  // per host thread: one thread may drive each GPU
+    return info;
+}
 inline Live& live()
 {
     static Live l;
@@ -152,11 +156,7 @@ std::pair<FinalType, DenseType> retrieve_and_free(double* d_y0_all, double* d_y_
                                         info.n_attempt.empty() ? nullptr : info.n_attempt.data(),
                                         info.n_accept.empty() ? nullptr : info.n_accept.data()),
                   "retrieve_and_free");
-    {
-        detail::Live& L = detail::live();
-        std::lock_guard<std::mutex> lk(L.mu);
-        L.last = std::move(info);
-    }
+    detail::last_info() = std::move(info);
     return {std::move(h_final), std::move(h_dense)};
 }
 
@@ -179,12 +179,7 @@ std::pair<FinalType, DenseType> run_rk45(const std::vector<double>& h_y0, double
     return retrieve_and_free<Model>(d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, ns, nq, t0, tf, d_sp);
 }
 
-// flags / step counters of the most recent retrieve_and_free on this process
-inline RunInfo last_run_info()
-{
-    detail::Live& L = detail::live();
-    std::lock_guard<std::mutex> lk(L.mu);
-    return L.last;
-}
+// flags / step counters of the most recent retrieve_and_free on the calling thread
+inline RunInfo last_run_info() { return detail::last_info(); }
 
 }  // namespace rk45_api

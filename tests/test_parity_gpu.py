@@ -552,3 +552,32 @@ def test_full_size_idempotence_and_properties(gpu):
     assert np.all(a["y_final"][ok, 4] < 0.2) and np.all(a["y_final"][ok, 4] > 0.19)
     assert np.all(a["y_final"][:, 2] == 0.0)  # dry surface store stays exactly 0
     assert a["n_attempt"][ok].min() > 500 and a["n_attempt"].max() < 2000
+
+
+def test_cpp_driver_multi_gpu_shards_equal_single(gpu, golden, tmp_path):
+    """rk45_solver --gpus N: the reference's contiguous split (main.cpp:275-307), one host thread
+    per shard.  On the one-GPU box the shards share the card (--oversubscribe); results must be
+    bit-identical to the unsharded run because hillslopes are independent."""
+    import os
+    import subprocess
+    exe = _driver_exe()
+    outs = {}
+    for g in (1, 3):
+        f, d = str(tmp_path / f"final_{g}.csv"), str(tmp_path / f"dense_{g}.csv")
+        cmd = [exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "2880", "--query-stride", "30",
+               "--rain", "0.0004", "--temp", "3.5", "--out-final", f, "--out-dense", d, "--gpus", str(g), "--quiet"]
+        if g > 1:
+            cmd.append("--oversubscribe")
+        subprocess.run(cmd, check=True, timeout=300)
+        outs[g] = (open(f).read(), open(d).read())
+    assert outs[1] == outs[3]
+    assert len(outs[1][0].splitlines()) == 11 and len(outs[1][1].splitlines()) == 98
+    # without --oversubscribe more GPUs than devices is an error, not a silent fallback
+    p = subprocess.run([exe, "--gpus", "64", "--quiet"], capture_output=True, text=True)
+    assert p.returncode == 1 and "device(s) visible" in p.stderr
+    # DummyModel, 64 systems over 5 shards (13/13/13/13/12)
+    f1, f5 = str(tmp_path / "a.csv"), str(tmp_path / "b.csv")
+    subprocess.run([exe, "--out-final", f1, "--out-dense", str(tmp_path / "ad.csv"), "--nq", "20", "--quiet"], check=True, timeout=300)
+    subprocess.run([exe, "--out-final", f5, "--out-dense", str(tmp_path / "bd.csv"), "--nq", "20", "--gpus", "5", "--oversubscribe",
+                    "--quiet"], check=True, timeout=300)
+    assert open(f1).read() == open(f5).read() and open(tmp_path / "ad.csv").read() == open(tmp_path / "bd.csv").read()

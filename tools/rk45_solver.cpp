@@ -15,7 +15,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <algorithm>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -51,6 +53,8 @@ struct Options {
     std::string out_format = "csv";  // csv | nc | both  (nc: main.cpp:786-823)
     int nc_compression = 0;
     int device = 0;
+    int gpus = 1;               // shard the hillslopes over this many GPUs (one host thread each)
+    bool oversubscribe = false; // allow --gpus > visible devices (shards share GPUs round-robin)
     bool quiet = false;
 };
 
@@ -63,7 +67,7 @@ struct Options {
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings]\n"
                  "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L]\n"
-                 "                   [--device D] [--quiet]\n");
+                 "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
     std::exit(msg ? 2 : 0);
 }
 
@@ -98,6 +102,8 @@ Options parse(int argc, char** argv)
         else if (a == "--out-format") o.out_format = val();
         else if (a == "--nc-compression") o.nc_compression = std::atoi(val());
         else if (a == "--device") o.device = std::atoi(val());
+        else if (a == "--gpus") o.gpus = std::atoi(val());
+        else if (a == "--oversubscribe") o.oversubscribe = true;
         else if (a == "--quiet") o.quiet = true;
         else if (a == "-h" || a == "--help") usage(nullptr);
         else usage(("unknown option " + a).c_str());
@@ -145,22 +151,19 @@ int run(const Options& o, hlm_io::CsvStyle style)
     const double t0 = o.t0;
     const double tf = o.tf > 0 ? o.tf : (is204 ? 2 * 24.0 * 60.0 : 5.0);  // main.cpp:610-611 / README
 
-    // ---- device: parameters and forcings ---------------------------------------------------------
-    rk45_api::detail::check(hlm_set_device(o.device), "hlm_set_device");
-    SpatialParams* d_sp = rk45_api::device_upload(spatial.data(), spatial.size());
-    float* d_forc = nullptr;
-    int32_t* d_col = nullptr;
+    // ---- forcings on the host: a table [sum nT][ncol] + one column index per stream ---------------
+    // NetCDF (time, lat, lon) forcings go through the lookup table (main.cpp:495-549).  The
+    // reference expands every forcing to one column per stream; this driver keeps ONE column per
+    // distinct grid cell plus an int32 column index per stream (41 274 streams map to 88 cells
+    // in the sample lookup) -- same values, 1/469 of the bytes.  --expand-forcings builds the
+    // reference's per-stream layout instead.
     ForcingBlock fb;
+    std::vector<int32_t> col_of_stream(ns, 0);
     if (is204 && !o.forcing_nc.empty()) {
 #ifdef HLM_WITH_HDF5
-        // NetCDF (time, lat, lon) forcings through the lookup table (main.cpp:495-549).  The
-        // reference expands every forcing to one column per stream; by default this driver
-        // keeps ONE column per distinct grid cell plus an int32 column index per stream
-        // (41 274 streams map to 88 cells in the sample lookup) -- same values, 1/469 of the bytes.
         if (o.lookup.empty()) usage("--forcing-nc needs --lookup <csv>");
         LookupMapper lm(o.lookup);
         if (!lm.load()) throw std::runtime_error("Lookup load failed: " + o.lookup);
-        std::vector<int32_t> col_of_stream(ns);
         std::vector<size_t> cell_of_col;
         std::unordered_map<size_t, int32_t> col_of_cell;
         size_t lon_size = 0;
@@ -180,7 +183,6 @@ int run(const Options& o, hlm_io::CsvStyle style)
                     if (lat < 0 || lon < 0 || (size_t)lat >= loader.getLatSize() || (size_t)lon >= lon_size)
                         throw std::runtime_error("stream " + std::to_string(streams[s].id) + " has no valid grid cell in " + o.lookup);
                     const size_t cell = (size_t)lat * lon_size + (size_t)lon;  // main.cpp:503-504
-                    if (o.expand_forcings) { col_of_stream[s] = s; cell_of_col.push_back(cell); continue; }
                     auto it = col_of_cell.find(cell);
                     if (it == col_of_cell.end()) {
                         it = col_of_cell.emplace(cell, (int32_t)cell_of_col.size()).first;
@@ -201,23 +203,16 @@ int run(const Options& o, hlm_io::CsvStyle style)
                 for (size_t c = 0; c < cell_of_col.size(); ++c) table[t * cell_of_col.size() + c] = raw[t * grid + cell_of_col[c]];
             fb.add(table, steps, dt_h);
         }
-        d_forc = rk45_api::device_upload(fb.data.data(), fb.data.size());
-        if (!o.expand_forcings) d_col = rk45_api::device_upload(col_of_stream.data(), col_of_stream.size());
-        rk45_api::set_forcings(d_forc, fb.dt_hours, fb.nT, fb.ld, d_col);
 #else
         usage("--forcing-nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
 #endif
     } else if (is204) {
-        // constant rain / temperature held over the window, in the reference's flattened
-        // [forcing][time][stream] layout with hourly and daily sampling (main.cpp:513-549)
-        fb.ld = ns;
+        // constant rain / temperature (the stub forcings of model_204.hpp:76-77) with the
+        // reference's hourly and daily sampling (main.cpp:513-514): one shared column
+        fb.ld = 1;
         const size_t n_hours = (size_t)std::ceil((tf - t0) / 60.0), n_days = (size_t)std::ceil((tf - t0) / 1440.0);
         fb.add_constant((float)o.rain, n_hours ? n_hours : 1, 1.0);
         fb.add_constant((float)o.temp, n_days ? n_days : 1, 24.0);
-        d_forc = rk45_api::device_upload(fb.data.data(), fb.data.size());
-        rk45_api::set_forcings(d_forc, fb.dt_hours, fb.nT, fb.ld);
-    } else {
-        rk45_api::detail::check(hlm_clear_forcings(), "hlm_clear_forcings");
     }
 
     // ---- solver parameters (main.cpp:615-641) ---------------------------------------------------------
@@ -225,7 +220,12 @@ int run(const Options& o, hlm_io::CsvStyle style)
     hp.rtol = o.rtol;
     hp.atol = o.atol;
     if (o.initial_step > 0) hp.initialStep = o.initial_step;
-    else if (o.scipy_h0) hp.initialStep = scipy_initial_step<Model>(spatial.data(), fb.data.data(), (int)fb.nT.size(), o.rtol, o.atol);
+    else if (o.scipy_h0) {
+        std::vector<float> f0;  // forcing samples of system 0 at t0
+        size_t row = 0;
+        for (size_t j = 0; j < fb.nT.size(); ++j) { f0.push_back(fb.data[row * (size_t)fb.ld + (size_t)col_of_stream[0]]); row += fb.nT[j]; }
+        hp.initialStep = scipy_initial_step<Model>(spatial.data(), f0.data(), (int)f0.size(), o.rtol, o.atol);
+    }
     rk45_api::setModelParameters<Model>(hp);
     rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
 
@@ -241,12 +241,73 @@ int run(const Options& o, hlm_io::CsvStyle style)
         const int nq = o.nq >= 0 ? o.nq : 10000;
         for (int q = 0; q < nq; ++q) h_query_times.push_back(t0 + (tf - t0) * (q + 1) / double(nq + 1));  // src/dense.csv grid
     }
+    const size_t nq = h_query_times.size();
 
-    // ---- integrate ---------------------------------------------------------------------------------------------
+    // ---- shard over the GPUs of the node and integrate -------------------------------------------------------
+    // The reference's rank 0 cuts the parameter rows into contiguous chunks, baseChunk + (r <=
+    // remainder), one per worker rank / GPU (main.cpp:275-307).  Same rule here, one host thread per
+    // GPU instead of one MPI rank; hillslopes are independent, so the shards never talk, and
+    // the "gather" is each thread writing its rows of the host result arrays.
+    int ndev = 0;
+    rk45_api::detail::check(hlm_device_count(&ndev), "hlm_device_count");
+    const int G = std::max(1, o.gpus);
+    if (G > ndev && !o.oversubscribe)
+        throw std::runtime_error("--gpus " + std::to_string(G) + " but only " + std::to_string(ndev) + " device(s) visible");
+    std::vector<double> h_y_final((size_t)ns * N_EQ), h_dense((size_t)ns * nq * N_EQ);
+    std::vector<int32_t> stiff(ns, 0);
+    std::vector<uint32_t> n_attempt(ns, 0);
+    std::vector<std::string> errors(G);
+    auto run_shard = [&](int r) {
+        try {
+            const int base = ns / G, rem = ns % G;
+            const int start = r * base + std::min(r, rem), count = base + (r < rem ? 1 : 0);
+            if (count == 0) return;
+            rk45_api::detail::check(hlm_set_device(G > 1 ? (o.device + r) % std::max(ndev, 1) : o.device), "hlm_set_device");
+            SpatialParams* d_sp = rk45_api::device_upload(spatial.data() + start, (size_t)count);
+            float* d_forc = nullptr;
+            int32_t* d_col = nullptr;
+            if (!fb.nT.empty()) {
+                if (o.expand_forcings) {  // the reference's [forcing][time][stream] block for this shard
+                    size_t rows = 0;
+                    for (size_t n : fb.nT) rows += n;
+                    std::vector<float> block(rows * (size_t)count);
+                    for (size_t t = 0; t < rows; ++t)
+                        for (int s = 0; s < count; ++s) block[t * count + s] = fb.data[t * (size_t)fb.ld + (size_t)col_of_stream[start + s]];
+                    d_forc = rk45_api::device_upload(block.data(), block.size());
+                    rk45_api::set_forcings(d_forc, fb.dt_hours, fb.nT, count);
+                } else {
+                    d_forc = rk45_api::device_upload(fb.data.data(), fb.data.size());
+                    d_col = rk45_api::device_upload(col_of_stream.data() + start, (size_t)count);
+                    rk45_api::set_forcings(d_forc, fb.dt_hours, fb.nT, fb.ld, d_col);
+                }
+            } else {
+                rk45_api::detail::check(hlm_clear_forcings(), "hlm_clear_forcings");
+            }
+            const std::vector<double> y0_shard(h_y0.begin() + (size_t)start * N_EQ, h_y0.begin() + (size_t)(start + count) * N_EQ);
+            auto [yf, dn] = rk45_api::run_rk45<Model>(y0_shard, t0, tf, h_query_times, d_sp);
+            const rk45_api::RunInfo info = rk45_api::last_run_info();
+            std::copy(yf.begin(), yf.end(), h_y_final.begin() + (size_t)start * N_EQ);
+            std::copy(dn.begin(), dn.end(), h_dense.begin() + (size_t)start * nq * N_EQ);
+            std::copy(info.stiff.begin(), info.stiff.end(), stiff.begin() + start);
+            if (!info.n_attempt.empty()) std::copy(info.n_attempt.begin(), info.n_attempt.end(), n_attempt.begin() + start);
+            rk45_api::device_free(d_sp);
+            if (d_forc) { hlm_clear_forcings(); rk45_api::device_free(d_forc); }
+            if (d_col) rk45_api::device_free(d_col);
+        } catch (const std::exception& e) {
+            errors[r] = e.what();
+        }
+    };
     const auto w0 = std::chrono::steady_clock::now();
-    auto [h_y_final, h_dense] = rk45_api::run_rk45<Model>(h_y0, t0, tf, h_query_times, d_sp);
+    if (G == 1) {
+        run_shard(0);
+    } else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < G; ++r) th.emplace_back(run_shard, r);
+        for (auto& t : th) t.join();
+    }
     const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - w0).count();
-    const rk45_api::RunInfo info = rk45_api::last_run_info();
+    for (int r = 0; r < G; ++r)
+        if (!errors[r].empty()) throw std::runtime_error("shard " + std::to_string(r) + ": " + errors[r]);
 
     if (o.out_format == "csv" || o.out_format == "both") {
         hlm_io::write_final_csv(o.out_final, h_y_final, ns, N_EQ, style);
@@ -261,7 +322,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
         auto nc_name = [](std::string p) { const size_t d = p.rfind('.'); return (d == std::string::npos ? p : p.substr(0, d)) + ".nc"; };
         write_final_netcdf(nc_name(o.out_final), h_y_final.data(), linkid_vals.data(), state_vals.data(), ns, N_EQ, o.nc_compression);
         write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
-                           (int)h_query_times.size(), ns, N_EQ, o.nc_compression);
+                           (int)nq, ns, N_EQ, o.nc_compression);
 #else
         usage("--out-format nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
 #endif
@@ -270,19 +331,15 @@ int run(const Options& o, hlm_io::CsvStyle style)
     unsigned long long attempts = 0;
     int flagged = 0;
     for (int s = 0; s < ns; ++s) {
-        attempts += info.n_attempt.empty() ? 0 : info.n_attempt[s];
-        flagged += info.stiff[s] != 0;
+        attempts += n_attempt[s];
+        flagged += stiff[s] != 0;
     }
     if (!o.quiet)
         std::printf("{\"model\": %d, \"num_systems\": %d, \"num_queries\": %zu, \"t0\": %g, \"tf\": %g, "
-                    "\"initial_step\": %g, \"attempted_steps\": %llu, \"flagged\": %d, \"run_rk45_seconds\": %.6f, "
-                    "\"final\": \"%s\", \"dense\": \"%s\"}\n",
-                    (int)Model::UID, ns, h_query_times.size(), t0, tf, hp.initialStep, attempts, flagged, secs,
+                    "\"initial_step\": %g, \"gpus\": %d, \"attempted_steps\": %llu, \"flagged\": %d, "
+                    "\"run_rk45_seconds\": %.6f, \"final\": \"%s\", \"dense\": \"%s\"}\n",
+                    (int)Model::UID, ns, nq, t0, tf, hp.initialStep, G, attempts, flagged, secs,
                     o.out_final.c_str(), o.out_dense.c_str());
-
-    rk45_api::device_free(d_sp);
-    if (d_forc) { hlm_clear_forcings(); rk45_api::device_free(d_forc); }
-    if (d_col) rk45_api::device_free(d_col);
     return 0;
 }
 
