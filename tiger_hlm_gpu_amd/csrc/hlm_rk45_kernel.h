@@ -398,16 +398,31 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
             const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5,
                          he6 = h * E6;
             double err = 0.0;
+            if constexpr (MATH == MATH_FAST) {
+                // max_i |e_i| / tol_i with ONE reciprocal: max_i(|e_i| * prod_{j != i} tol_j) / prod_j tol_j
+                // (tol_i in [atol, ~rtol*|y|]: the 5-fold products stay far from the double range)
+                static_assert(NEQ == 5, "the product tree below is written for 5 components");
+                double e[NEQ], tl[NEQ];
 #pragma unroll
-            for (int i = 0; i < NEQ; ++i) {
-                const double y_err =
-                    lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
-                const double ymax = vmax_abs(y[i], yn[i]);
-                const double tol = __builtin_fma(A.rtol, ymax, A.atol);
-                double ratio;
-                if constexpr (MATH == MATH_FAST) ratio = y_err * fast_rcp(tol);
-                else ratio = y_err / tol;
-                err = vmax_abs2(err, ratio);  // "if (fabs(ratio) > max) max = fabs(ratio)"
+                for (int i = 0; i < NEQ; ++i) {
+                    e[i] = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                    tl[i] = __builtin_fma(A.rtol, vmax_abs(y[i], yn[i]), A.atol);
+                }
+                const double a = tl[0] * tl[1], b = tl[2] * tl[3];
+                const double ab = a * b, all = ab * tl[4], bt4 = b * tl[4], at4 = a * tl[4];
+                double num = vmax_abs(e[0] * (tl[1] * bt4), e[1] * (tl[0] * bt4));
+                num = vmax_abs2(num, e[2] * (tl[3] * at4));
+                num = vmax_abs2(num, e[3] * (tl[2] * at4));
+                num = vmax_abs2(num, e[4] * ab);
+                err = num * fast_rcp(all);
+            } else {
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) {
+                    const double y_err =
+                        lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                    const double tol = __builtin_fma(A.rtol, vmax_abs(y[i], yn[i]), A.atol);
+                    err = vmax_abs2(err, y_err / tol);  // "if (fabs(ratio) > max) max = fabs(ratio)"
+                }
             }
             // step-size factor shared by the accept and the reject branch
             // (rk45_kernel.cu:151,156)
