@@ -213,6 +213,11 @@ int hlm_set_stream_path(int path);
 int hlm_host_alloc_pinned(void** hptr, size_t bytes);
 int hlm_host_free_pinned(void* hptr);
 
+/* Self-test of the device elementary functions the FAST math mode substitutes (the analogue of
+ * the reference's printf debug kernels, main.cpp:184-246): evaluates function `which` on n
+ * doubles.  0: x^(2/3) FAST, 1: x^(-1/5) FAST, 2: 1/x FAST, 3: x^(2/3) STRICT, 4: x^(-1/5) STRICT. */
+int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void* hip_stream);
+
 /* Static facts about the compiled kernels (for DESIGN.md / bench output). */
 int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs,
                     int* lds_bytes, int* max_threads);

@@ -581,3 +581,44 @@ def test_cpp_driver_multi_gpu_shards_equal_single(gpu, golden, tmp_path):
     subprocess.run([exe, "--out-final", f5, "--out-dense", str(tmp_path / "bd.csv"), "--nq", "20", "--gpus", "5", "--oversubscribe",
                     "--quiet"], check=True, timeout=300)
     assert open(f1).read() == open(f5).read() and open(tmp_path / "ad.csv").read() == open(tmp_path / "bd.csv").read()
+
+
+def test_fast_math_elementary_functions(gpu):
+    """The FAST-mode substitutes for pow(x, 2/3), pow(1/x, 0.2) and 1/x against float128-free
+    references (numpy long double where available, else mpmath-free double math on exactly
+    representable cases): relative error of a few ulp over the whole range the solver can feed
+    them, pow()'s NaN for negative arguments preserved."""
+    H = gpu
+    import torch
+    rng = np.random.default_rng(11)
+    L = H._lib.lib()
+
+    def run(which, x):
+        xin = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+        out = torch.empty_like(xin)
+        H._lib.check(L.hlm_selftest_math(which, xin.data_ptr(), out.data_ptr(), xin.numel(), None))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    ld = np.longdouble
+    x = np.concatenate([10.0 ** rng.uniform(-280, 300, 200000), 10.0 ** rng.uniform(-12, 1, 200000), [1.0, 8.0, 1e-9, 0.125]])
+    # the reference computes pow(x, 2.0/3.0) with the DOUBLE constant 0.6666666666666666 =
+    # 2/3 - 3.7e-17, i.e. x^(2/3) * x^(-3.7e-17); FAST computes the mathematical x^(2/3)
+    ref23 = (x.astype(ld) ** (ld(2) / ld(3))).astype(np.float64)
+    ref_pow = (x.astype(ld) ** ld(2.0 / 3.0)).astype(np.float64)
+    got = run(0, x)
+    assert np.max(np.abs(got - ref23) / ref23) < 8e-16
+    assert np.all(np.abs(got - ref_pow) / ref_pow < 8e-16 + 3.8e-17 * np.abs(np.log(x)))
+    # STRICT calls OCML's pow, measured here at up to 2.7e-15 (12 ulp) on [1e-12, 10] and 6e-14
+    # near 1e290: the FAST substitute is the more accurate of the two
+    strict = run(3, x)
+    es = np.abs(strict - ref_pow) / ref_pow
+    assert es.max() < 2e-13 and es[(x > 1e-12) & (x < 10)].max() < 6e-15
+    assert np.all(np.isnan(run(0, np.array([-1.0, -1e-300, -np.inf]))))  # like pow(): NaN for x < 0
+    assert np.all(run(0, np.array([1e-300, 5e-324])) == 0.0)       # below 1e-290: flushed (value < 1e-193)
+    xe = np.concatenate([10.0 ** rng.uniform(-16, 30, 400000), [1e-16, 1.0, 32.0]])
+    ref5 = (xe.astype(ld) ** (ld(-1) / ld(5))).astype(np.float64)
+    assert np.max(np.abs(run(1, xe) - ref5) / ref5) < 8e-16
+    assert np.max(np.abs(run(4, xe) - ref5) / ref5) < 2e-14
+    xr = 10.0 ** rng.uniform(-12, 12, 400000) * rng.choice([-1.0, 1.0], 400000)
+    assert np.max(np.abs(run(2, xr) * xr - 1.0)) < 1e-13

@@ -82,7 +82,8 @@ __device__ __forceinline__ double pow_two_thirds(double x)
         double p = __builtin_fma(e, 14.0 / 81.0, 2.0 / 9.0);
         p = __builtin_fma(e, p, 1.0 / 3.0);
         const double xw = x * w;
-        const double r = __builtin_fma(xw * e, p, xw);
+        double r = __builtin_fma(xw * e, p, xw);
+        r = x < 1e-290 ? 0.0 : r;  // w^3 would overflow below ~2^-1023; x^(2/3) < 1e-193 there
         return x < 0.0 ? __builtin_nan("") : r;
     }
 }

@@ -547,6 +547,25 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     }
 }
 
+// ---- self-test of the FAST-mode elementary functions (hlm_selftest_math) ---------------------
+// which: 0 = x^(2/3) (pow_two_thirds<FAST>), 1 = x^(-1/5) (inv_fifth_root<FAST>), 2 = 1/x (fast_rcp),
+//        3 = x^(2/3) STRICT (OCML pow), 4 = x^(-1/5) STRICT
+__global__ void selftest_math_kernel(int which, const double* __restrict__ in, double* __restrict__ out, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double x = in[i];
+    double r;
+    switch (which) {
+        case 0: r = pow_two_thirds<MATH_FAST>(x); break;
+        case 1: r = inv_fifth_root<MATH_FAST>(x); break;
+        case 2: r = fast_rcp(x); break;
+        case 3: r = pow_two_thirds<MATH_STRICT>(x); break;
+        default: r = inv_fifth_root<MATH_STRICT>(x); break;
+    }
+    out[i] = r;
+}
+
 // ---- tile-major window -> host order -------------------------------------------------------
 // Transposes one query window from the kernel's tile-major layout [blk][W][64][5] to the
 // host-facing order dst[(sys*nq + q)*5 + c] (rk45_api.hpp:255-267).  dst is normally PINNED
