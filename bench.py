@@ -112,13 +112,19 @@ def _coll_device(dev):
     return dev if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
+def gather_results(eng, world):
+    """End-of-run gather (the path's only exchange): final states, flags and step counters of
+    every rank's shard arrive on rank 0 in ONE collective -- the engine keeps them in a single
+    52-byte-per-hillslope allocation.  Equal shards (weak scaling), so no padding copy."""
+    blob = eng.result_blob
+    return gather_to_root(blob.view(1, -1), world)  # one row per rank
+
+
 def one_pass(eng, total, world):
     """The hot path over one batch + the end-of-run gather (the path's only exchange)."""
     eng.integrate()
     if world > 1:
-        gather_to_root(eng.y_final, total)
-        gather_to_root(eng.stiff, total)
-        gather_to_root(eng.n_attempt, total)
+        gather_results(eng, world)
 
 
 def timed_passes(eng, total, world, warmup, steps):
@@ -137,9 +143,7 @@ def timed_passes(eng, total, world, warmup, steps):
         eng.integrate()
         ev[i][1].record()
         if world > 1:
-            gather_to_root(eng.y_final, total)
-            gather_to_root(eng.stiff, total)
-            gather_to_root(eng.n_attempt, total)
+            gather_results(eng, world)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
@@ -237,6 +241,17 @@ def main():
     if world > 1:
         dist.all_reduce(attempts)
         dist.all_reduce(flagged)
+    if world > 1:
+        # sanity of the gather (outside the timed region): rank 0 must hold every shard's blob,
+        # and the step counters inside it must add up to the all-reduced total
+        g = gather_results(eng, world)
+        if rank == 0:
+            assert g.shape[0] == world and torch.equal(g[0].to(eng.result_blob.device), eng.result_blob)
+            tot = 0
+            for r in range(world):
+                _, _, natt, _ = ShardEngine.split_result_blob(g[r], eng.ns)
+                tot += int(natt.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+            assert tot == int(attempts.item()), (tot, attempts.item())
     attempts_all = float(attempts.item())          # over all ranks, per pass
     value = attempts_all * args.steps / wall
     ms_per_step = 1e3 * wall / args.steps

@@ -39,16 +39,21 @@ class ShardEngine:
         self.nq = 0 if self.query is None else self.query.numel()
         self.forc = self.forc_col = None
         self.forc_dt, self.forc_nT, self.forc_ld = (), (), 0
-        self.y_final = torch.empty((self.ns, model.N_EQ), dtype=torch.float64, device=dev)
+        # y_final | stiff | n_attempt | n_accept live in ONE allocation (52 B per hillslope), so the
+        # end-of-run gather to rank 0 is a single collective on `result_blob`
+        ns8 = -(-self.ns // 2) * 2  # keeps every section 8-byte aligned
+        self.result_blob = torch.empty(self.ns * 40 + 3 * ns8 * 4, dtype=torch.uint8, device=dev)
+        o = self.ns * 40
+        self.y_final = self.result_blob[:o].view(torch.float64).view(self.ns, model.N_EQ)
         # dense_tiled: tile-major [ceil(ns/64)][nq][64][5] device layout (what the streamed path
         # uses internally); only for measuring the kernel -- results() then returns that layout
         self.dense_tiled = bool(dense_tiled)
         rows = -(-self.ns // 64) * 64 if self.dense_tiled else self.ns
         self.dense = (torch.empty((rows, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
                       if self.nq and alloc_dense else None)
-        self.stiff = torch.empty(self.ns, dtype=torch.int32, device=dev)
-        self.n_attempt = torch.empty(self.ns, dtype=torch.int32, device=dev)  # uint32 bits
-        self.n_accept = torch.empty(self.ns, dtype=torch.int32, device=dev)
+        self.stiff = self.result_blob[o:o + ns8 * 4].view(torch.int32)[:self.ns]
+        self.n_attempt = self.result_blob[o + ns8 * 4:o + 2 * ns8 * 4].view(torch.int32)[:self.ns]  # uint32 bits
+        self.n_accept = self.result_blob[o + 2 * ns8 * 4:o + 3 * ns8 * 4].view(torch.int32)[:self.ns]
 
     # -- forcings ------------------------------------------------------------------------
     def set_forcings_per_stream(self, block, dt_hours, nT):
@@ -112,6 +117,15 @@ class ShardEngine:
 
     def total_attempts(self):
         return int(self.n_attempt.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
+
+    @staticmethod
+    def split_result_blob(blob, ns, n_eq=5):
+        """Views (y_final, stiff, n_attempt, n_accept) of a result_blob of ``ns`` hillslopes."""
+        ns8 = -(-ns // 2) * 2
+        o = ns * 8 * n_eq
+        y = blob[:o].view(torch.float64).view(ns, n_eq)
+        i32 = lambda k: blob[o + k * ns8 * 4:o + (k + 1) * ns8 * 4].view(torch.int32)[:ns]
+        return y, i32(0), i32(1), i32(2)
 
     def results(self):
         """Host copies: dict(y_final[ns,5], dense[ns,nq,5] or None, stiff, n_attempt, n_accept)."""
