@@ -298,7 +298,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_ms,
-                     "kernel": "hlm::rk45_multi_kernel<Model204Dev>"},
+                     "kernel": "hlm::rk45_multi_kernel<Model204Dev>",
+                     "note": "0.19 algorithmic bytes per RK45 step: this kernel cannot be HBM-bound; its binding "
+                             "roofline is roofline_valu_fp64 (FP64 vector ALU, no MFMA in a per-lane ODE)"},
         "roofline_valu_fp64": {"bound": "valu_fp64", "achieved": valu_tf, "peak": PEAK_FP64_VALU_TFLOPS,
                                "unit": "TFLOP/s", "frac": valu_tf / PEAK_FP64_VALU_TFLOPS,
                                "algorithmic_flops_per_step": F_STEP_204},
