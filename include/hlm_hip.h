@@ -176,6 +176,18 @@ typedef struct hlm_device_job {
      * 1: tile-major [ceil(ns/64)][W][64][5]: what hlm_rk45_integrate_streamed uses internally
      *    (fully coalesced row stores); a caller using it must transpose itself. */
     int dense_tiled;
+    /* Time chunks / checkpoints (build feature).  use_t_stop != 0: every hillslope pauses the
+     * first time its t reaches t_stop (before its next attempt; needs d_resume) and continues in
+     * the next launch with resume_in = 1 -- the step sequence, hence every output bit, is that of
+     * the uninterrupted run.  The bytes of d_resume ARE a checkpoint (copy them out and back).
+     * forc_first_index[j] / forc_rows[j] (rows 0 = all nT[j]) describe which samples of forcing
+     * j the block d_forc holds in this launch, [first, first + rows): the host can stream the
+     * forcing series through HBM in time chunks ("NetCDF forcings streamed", BASELINE config 3)
+     * as long as each chunk covers every sample index floor(t / dt_j) for t in [t_launch, t_stop). */
+    int use_t_stop;
+    double t_stop;
+    uint64_t forc_first_index[HLM_MAX_FORCINGS];
+    uint64_t forc_rows[HLM_MAX_FORCINGS];
 } hlm_device_job;
 
 size_t hlm_resume_bytes(int num_systems);

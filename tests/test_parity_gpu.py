@@ -622,3 +622,57 @@ def test_fast_math_elementary_functions(gpu):
     assert np.max(np.abs(run(4, xe) - ref5) / ref5) < 2e-14
     xr = 10.0 ** rng.uniform(-12, 12, 400000) * rng.choice([-1.0, 1.0], 400000)
     assert np.max(np.abs(run(2, xr) * xr - 1.0)) < 1e-13
+
+
+# ---- time chunks: streamed forcings, checkpoints (BASELINE config 3 "forcings streamed") --------------
+@pytest.mark.parametrize("layout", ["per-cell", "per-stream"])
+@pytest.mark.parametrize("chunk", [60.0, 7 * 60.0 + 13.0, 1440.0, 3.3 * 1440.0])
+def test_streamed_forcings_equal_resident_bitwise(gpu, layout, chunk):
+    """Forcing series passed through HBM in time chunks (lanes pause at each chunk end, the next
+    chunk is uploaded meanwhile) give exactly the bits of the run with all forcings resident."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 700, 5
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, wet=True)
+    q = synth.minute_queries(0.0, days * 1440.0, 97.0)
+    ref = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT),
+                      per_cell=(layout == "per-cell"), math_mode=H.MATH_FAST)
+    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, math_mode=H.MATH_FAST)
+    if layout == "per-cell":
+        n = eng.integrate_forcing_streamed((pr, t2m), dt, chunk, cells=cells)
+    else:
+        n = eng.integrate_forcing_streamed((pr[:, cells], t2m[:, cells]), dt, chunk)
+    assert n == int(np.ceil(days * 1440.0 / chunk))
+    got = eng.results()
+    for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(got[k], ref[k]), k
+
+
+def test_checkpoint_restore_continues_bitwise(gpu):
+    """Pause at t_stop, copy the 76-byte-per-hillslope state to the host, restore it into a NEW
+    engine and finish: finals, flags and counters equal the uninterrupted run."""
+    H = gpu
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 1000, 4
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days)
+    ref = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, forcing=(pr, t2m, cells, dt, nT))
+    a = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp)
+    a.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    a.integrate(t_stop=2000.0)
+    blob = a.checkpoint()
+    assert blob.nbytes == 76 * ns
+    t_paused = blob[: 7 * 8 * ns].view(np.float64).reshape(7, ns)[5]
+    assert np.all(t_paused >= 2000.0) and np.all(t_paused < 2000.0 + 60.0)  # first step end past t_stop
+    b = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp)
+    b.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    b.restore(blob)
+    b.integrate(t_stop=4000.0, resume_in=True)
+    b.integrate(resume_in=True)
+    got = b.results()
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(got[k], ref[k]), k
+    with pytest.raises(H.HlmError):
+        j = a.job()
+        j.use_t_stop, j.t_stop = 1, 100.0   # t_stop without a resume buffer
+        H.api.integrate_device(j)

@@ -52,7 +52,8 @@ class DeviceJob(C.Structure):
         ("d_y_final", C.c_void_p), ("d_dense", C.c_void_p), ("d_stiff", C.c_void_p),
         ("d_n_attempt", C.c_void_p), ("d_n_accept", C.c_void_p),
         ("query_begin", C.c_int), ("query_end", C.c_int), ("d_resume", C.c_void_p), ("resume_in", C.c_int),
-        ("dense_tiled", C.c_int),
+        ("dense_tiled", C.c_int), ("use_t_stop", C.c_int), ("t_stop", C.c_double),
+        ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
     ]
 
 

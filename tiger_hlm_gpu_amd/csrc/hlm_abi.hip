@@ -79,27 +79,39 @@ ModelState* find_model(int uid)
 
 using KernelFn = void (*)(const hlm::Rk45Args);
 
-template <class Model>
-KernelFn pick_kernel(int math, bool dense, bool fixed)
+template <class Model, int MATH, bool RES>
+KernelFn pick_kernel2(bool dense, bool fixed)
 {
     using namespace hlm;
-    if (math == HLM_MATH_FAST) {
-        if (dense) return fixed ? rk45_multi_kernel<Model, MATH_FAST, true, true>
-                                : rk45_multi_kernel<Model, MATH_FAST, true, false>;
-        return fixed ? rk45_multi_kernel<Model, MATH_FAST, false, true>
-                     : rk45_multi_kernel<Model, MATH_FAST, false, false>;
-    }
-    if (dense) return fixed ? rk45_multi_kernel<Model, MATH_STRICT, true, true>
-                            : rk45_multi_kernel<Model, MATH_STRICT, true, false>;
-    return fixed ? rk45_multi_kernel<Model, MATH_STRICT, false, true>
-                 : rk45_multi_kernel<Model, MATH_STRICT, false, false>;
+    if (dense) return fixed ? rk45_multi_kernel<Model, MATH, true, true, RES> : rk45_multi_kernel<Model, MATH, true, false, RES>;
+    return fixed ? rk45_multi_kernel<Model, MATH, false, true, RES> : rk45_multi_kernel<Model, MATH, false, false, RES>;
 }
 
-KernelFn pick(int uid, int math, bool dense, bool fixed)
+template <class Model>
+KernelFn pick_kernel(int math, bool dense, bool fixed, bool resumable)
 {
-    if (uid == HLM_UID_204) return pick_kernel<hlm::Model204Dev>(math, dense, fixed);
-    if (uid == HLM_UID_DUMMY) return pick_kernel<hlm::DummyDev>(math, dense, fixed);
+    using namespace hlm;
+    if (math == HLM_MATH_FAST)
+        return resumable ? pick_kernel2<Model, MATH_FAST, true>(dense, fixed) : pick_kernel2<Model, MATH_FAST, false>(dense, fixed);
+    return resumable ? pick_kernel2<Model, MATH_STRICT, true>(dense, fixed) : pick_kernel2<Model, MATH_STRICT, false>(dense, fixed);
+}
+
+KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
+{
+    if (uid == HLM_UID_204) return pick_kernel<hlm::Model204Dev>(math, dense, fixed, resumable);
+    if (uid == HLM_UID_DUMMY) return pick_kernel<hlm::DummyDev>(math, dense, fixed, resumable);
     return nullptr;
+}
+
+// a job needs the resumable kernel variant when it carries state between launches or holds only
+// a time chunk of a forcing series
+bool job_is_resumable(const hlm_device_job* j)
+{
+    if (j->d_resume || j->use_t_stop || j->resume_in) return true;
+    if (j->query_end != 0 && (j->query_begin != 0 || j->query_end != j->num_queries)) return true;
+    for (int k = 0; k < j->nforc; ++k)
+        if (j->forc_first_index[k] != 0 || (j->forc_rows[k] != 0 && j->forc_rows[k] != j->forc_nT[k])) return true;
+    return false;
 }
 
 int validate_job(const hlm_device_job* j)
@@ -143,6 +155,14 @@ int validate_job(const hlm_device_job* j)
     }
     if (j->resume_in && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "resume_in without d_resume");
     if (j->dense_tiled != 0 && j->dense_tiled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0 or 1");
+    if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
+    if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
+    for (int k = 0; k < j->nforc; ++k)
+        if (j->forc_first_index[k] + (j->forc_rows[k] ? j->forc_rows[k] : j->forc_nT[k]) > j->forc_nT[k] ||
+            j->forc_first_index[k] >= j->forc_nT[k])
+            return fail(HLM_ERR_INVALID_ARGUMENT, "forcing %d: chunk [%llu, +%llu) outside its %llu samples", k,
+                        (unsigned long long)j->forc_first_index[k], (unsigned long long)j->forc_rows[k],
+                        (unsigned long long)j->forc_nT[k]);
     return HLM_SUCCESS;
 }
 
@@ -158,13 +178,17 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     a.forc_ld = j->forc_ld;
     unsigned long long base = 0;
     for (int k = 0; k < j->nforc; ++k) {
+        const unsigned long long rows = j->forc_rows[k] ? j->forc_rows[k] : j->forc_nT[k];
         if (k < 2) {
             a.forc_dtmin[k] = j->forc_dt_hours[k] * 60.0;  // rk45_kernel.cu:90
             a.forc_nT[k] = j->forc_nT[k];
             a.forc_base[k] = base;
+            a.forc_first[k] = j->forc_first_index[k];
+            a.forc_rows[k] = rows;
         }
-        base += (unsigned long long)j->forc_nT[k] * (unsigned long long)j->forc_ld;
+        base += rows * (unsigned long long)j->forc_ld;
     }
+    a.t_stop = j->use_t_stop ? j->t_stop : __builtin_inf();
     a.nforc = j->nforc;
     a.ns = j->num_systems;
     a.nq = j->num_queries;
@@ -195,7 +219,7 @@ int launch(const hlm_device_job* j, hipStream_t stream)
 {
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
-    KernelFn fn = pick(j->uid, j->math_mode, dense, fixed);
+    KernelFn fn = pick(j->uid, j->math_mode, dense, fixed, job_is_resumable(j));
     if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
     const hlm::Rk45Args a = make_args(j);
     const unsigned blocks = (unsigned)((j->num_systems + hlm::WAVE - 1) / hlm::WAVE);

@@ -37,10 +37,13 @@ struct Rk45Args {
     long long forc_ld;
     double forc_dtmin[2];          // dt_hours * 60 (rk45_kernel.cu:90), only the NF<=2 used rows
     unsigned long long forc_nT[2];
-    unsigned long long forc_base[2];  // sum_{k<j} nT_k * ld (rk45_kernel.cu:101-104)
+    unsigned long long forc_base[2];  // sum_{k<j} rows_k * ld (rk45_kernel.cu:101-104)
+    unsigned long long forc_first[2]; // sample index of the first row present in this block
+    unsigned long long forc_rows[2];  // rows present (= nT unless the host streams time chunks)
     int nforc;
     int ns, nq;
     double t0, tf;
+    double t_stop;                    // lanes pause when t >= t_stop (+inf: run to tf)
     double h0, rtol, atol, safety, min_scale, max_scale;  // Model::Parameters
     double fixed_step;
     uint32_t cap;
@@ -48,7 +51,7 @@ struct Rk45Args {
     double* dense;       // rows of this launch's query window, linear [ns][W][5] or tile-major
     int dense_tiled;     // 1: [ceil(ns/64)][W][64][5] (W = q_end - q_begin), coalesced across a wave
     int q_begin, q_end;  // global query indices [q_begin, q_end) written by this launch
-    double* resume;      // nullable: per-system integrator state carried between windows
+    double* resume;      // nullable: per-system integrator state carried between launches
     int resume_in;       // 0 = start from y0, 1 = continue from `resume`
     int32_t* stiff;
     uint32_t* n_attempt;
@@ -98,6 +101,15 @@ __device__ __forceinline__ unsigned long long forcing_index(double t, double dtm
 {
     const double r = t / dtmin;
     return (r < 0.0) ? 0ull : (r >= (double)nT ? nT - 1ull : (unsigned long long)r);
+}
+
+// row of the launch's forcing block that holds global sample `idx` (the block may be a time
+// chunk [first, first+rows) of the series; clamped so that a bad chunk can never fault)
+__device__ __forceinline__ size_t forcing_row(unsigned long long idx, unsigned long long first,
+                                              unsigned long long rows)
+{
+    const unsigned long long r = idx >= first ? idx - first : 0ull;
+    return (size_t)(r < rows ? r : rows - 1ull);
 }
 
 // ---- the 7 stages of one attempt ---------------------------------------------------------
@@ -205,7 +217,10 @@ __device__ __forceinline__ void dense_flush(const double* lds_rows, int lane, in
     cnt = 0;
 }
 
-template <class Model, int MATH, bool DENSE, bool FIXED>
+// RESUMABLE: query windows / t_stop / forcing time chunks / checkpoints.  The plain variant
+// (one uninterrupted launch, all forcings resident) carries none of that state: keeping it
+// out of the default kernel is worth 3.5 % (199 -> 192 ms on the C3 pass).
+template <class Model, int MATH, bool DENSE, bool FIXED, bool RESUMABLE>
 __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kernel(const Rk45Args A)
 {
     using namespace dp;
@@ -265,7 +280,6 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     [[maybe_unused]] int parked = 0;             // rows of this lane waiting in LDS
     [[maybe_unused]] double* gfirst = nullptr;   // global address of the first parked row
     [[maybe_unused]] int qb = 0, qe = 0;
-    [[maybe_unused]] int* resume_i = nullptr;
     if constexpr (DENSE) {
         // Query window [qb, qe) of this launch (the whole range unless the host streams the
         // dense output in chunks, hlm_rk45_integrate_streamed).  A lane that has to write a
@@ -285,28 +299,34 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
             q_stride = NEQ;
             dense_row = A.dense + ((size_t)sys * (size_t)(qe - qb) - (size_t)qb) * NEQ;
         }
-        if (A.resume) {
-            resume_i = reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns);
-            if (A.resume_in) {
-                const int st = resume_i[(size_t)4 * A.ns + sys];
-                if (st != SYS_PAUSED) {
-                    // finished or flagged in an earlier window: its remaining slots are 0
-                    for (int q = qb; q < qe; ++q) {
+    }
+    // Integrator state carried between launches (query windows, time chunks of streamed
+    // forcings, checkpoints): a paused lane continues exactly where it stopped.
+    int* const resume_i =
+        RESUMABLE && A.resume ? reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns) : nullptr;
+    if (resume_i && A.resume_in) {
+        const int st = resume_i[(size_t)4 * A.ns + sys];
+        if (st != SYS_PAUSED) {
+            // finished or flagged in an earlier launch: outputs were written then; the dense
+            // slots it never reaches are 0
+            if constexpr (DENSE) {
+                for (int q = qb; q < qe; ++q) {
 #pragma unroll
-                        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * q_stride + c] = 0.0;
-                    }
-                    return;
+                    for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * q_stride + c] = 0.0;
                 }
-#pragma unroll
-                for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
-                t = A.resume[(size_t)5 * A.ns + sys];
-                h = A.resume[(size_t)6 * A.ns + sys];
-                reject_count = resume_i[(size_t)0 * A.ns + sys];
-                n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
-                n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
-                next_q = resume_i[(size_t)3 * A.ns + sys];
             }
+            return;
         }
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
+        t = A.resume[(size_t)5 * A.ns + sys];
+        h = A.resume[(size_t)6 * A.ns + sys];
+        reject_count = resume_i[(size_t)0 * A.ns + sys];
+        n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
+        n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
+        next_q = resume_i[(size_t)3 * A.ns + sys];
+    }
+    if constexpr (DENSE) {
         // queries at or before the current time are never produced (rk45_kernel.cu:141):
         // their slot is 0.  (No-op on a resumed lane: earlier steps consumed them.)
         while (next_q < A.nq && A.query[next_q] <= t) {
@@ -328,7 +348,10 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     double k0[NEQ];
     typename Model::Forc FV = Model::prep_forcing(P, F0, F1);
 
-    while (t < tf && status == HLM_SYS_OK) {
+    // t_stop (time chunks / checkpoints): a lane whose t has reached it pauses BEFORE its next
+    // attempt, so the continuation in the next launch repeats nothing and changes nothing.
+    const double t_end = RESUMABLE ? fmin(tf, A.t_stop) : tf;
+    while (t < t_end && status == HLM_SYS_OK) {
         if constexpr (DENSE) {
             // drain the LDS tile as soon as any lane's slots are full (wave-uniform branch)
             if constexpr (DENSE_KQ > 0) {
@@ -354,13 +377,13 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
                 if (use_f0 && !(t < tb0)) {
                     const unsigned long long i0 = forcing_index(t, A.forc_dtmin[0], A.forc_nT[0]);
                     tb0 = (i0 + 1ull < A.forc_nT[0]) ? (double)(i0 + 1ull) * A.forc_dtmin[0] : __builtin_inf();
-                    F0 = (double)A.forc[A.forc_base[0] + i0 * (size_t)A.forc_ld + fcol];
+                    F0 = (double)A.forc[A.forc_base[0] + (RESUMABLE ? forcing_row(i0, A.forc_first[0], A.forc_rows[0]) : (size_t)i0) * (size_t)A.forc_ld + fcol];
                     have_k0 = false;
                 }
                 if (use_f1 && !(t < tb1)) {
                     const unsigned long long i1 = forcing_index(t, A.forc_dtmin[1], A.forc_nT[1]);
                     tb1 = (i1 + 1ull < A.forc_nT[1]) ? (double)(i1 + 1ull) * A.forc_dtmin[1] : __builtin_inf();
-                    F1 = (double)A.forc[A.forc_base[1] + i1 * (size_t)A.forc_ld + fcol];
+                    F1 = (double)A.forc[A.forc_base[1] + (RESUMABLE ? forcing_row(i1, A.forc_first[1], A.forc_rows[1]) : (size_t)i1) * (size_t)A.forc_ld + fcol];
                     have_k0 = false;
                 }
                 if (!have_k0) FV = Model::prep_forcing(P, F0, F1);
@@ -513,23 +536,22 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
     }
 
-    if constexpr (DENSE) {
-        if constexpr (DENSE_KQ > 0) dense_flush(lds_rows, lane, parked, gfirst);  // all lanes have left the loop
-        if (resume_i) {
-            resume_i[(size_t)4 * A.ns + sys] = status;
-            if (status == SYS_PAUSED) {
+    if constexpr (DENSE && DENSE_KQ > 0) dense_flush(lds_rows, lane, parked, gfirst);  // all lanes have left the loop
+    if (RESUMABLE && status == HLM_SYS_OK && t < tf) status = SYS_PAUSED;  // stopped by t_stop
+    if (resume_i) {
+        resume_i[(size_t)4 * A.ns + sys] = status;
+        if (status == SYS_PAUSED) {
 #pragma unroll
-                for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
-                A.resume[(size_t)5 * A.ns + sys] = t;
-                A.resume[(size_t)6 * A.ns + sys] = h;
-                resume_i[(size_t)0 * A.ns + sys] = reject_count;
-                resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
-                resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
-                resume_i[(size_t)3 * A.ns + sys] = next_q;
-            }
+            for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
+            A.resume[(size_t)5 * A.ns + sys] = t;
+            A.resume[(size_t)6 * A.ns + sys] = h;
+            resume_i[(size_t)0 * A.ns + sys] = reject_count;
+            resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
+            resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
+            resume_i[(size_t)3 * A.ns + sys] = next_q;
         }
-        if (status == SYS_PAUSED) return;  // outputs are written by the launch that finishes the lane
     }
+    if (status == SYS_PAUSED) return;  // outputs are written by the launch that finishes the lane
 
     if (A.n_attempt) A.n_attempt[sys] = n_attempt;
     if (A.n_accept) A.n_accept[sys] = n_accept;

@@ -92,10 +92,86 @@ class ShardEngine:
         j.dense_tiled = int(self.dense_tiled and self.dense is not None)
         return j
 
-    def integrate(self, stream=None):
-        """Enqueue one pass of the hot path on ``stream`` (default: torch's current stream)."""
+    def integrate(self, stream=None, t_stop=None, resume_in=False):
+        """Enqueue one pass of the hot path on ``stream`` (default: torch's current stream).
+        ``t_stop``: pause every hillslope once its t reaches it (state kept in the engine's
+        resume buffer); ``resume_in``: continue from that buffer.  A sequence of such launches
+        gives the same bits as one uninterrupted pass."""
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        api.integrate_device(self.job(), s)
+        j = self.job()
+        if t_stop is not None or resume_in:
+            j.d_resume, j.resume_in = self._resume_buffer().data_ptr(), int(bool(resume_in))
+            if t_stop is not None:
+                j.use_t_stop, j.t_stop = 1, float(t_stop)
+        api.integrate_device(j, s)
+
+    def _resume_buffer(self):
+        if getattr(self, "_resume", None) is None:
+            self._resume = torch.zeros(api.resume_bytes(self.ns), dtype=torch.uint8, device=self.device)
+        return self._resume
+
+    def checkpoint(self):
+        """Host copy of the integrator state of a paused run (76 bytes per hillslope)."""
+        torch.cuda.synchronize(self.device)
+        return self._resume_buffer().cpu().numpy().copy()
+
+    def restore(self, blob):
+        self._resume_buffer().copy_(torch.from_numpy(np.ascontiguousarray(blob, dtype=np.uint8)))
+
+    def integrate_forcing_streamed(self, tables, dt_hours, chunk_minutes, cells=None):
+        """BASELINE config 3, "forcings streamed": the forcing series stay in (pinned) host
+        memory and pass through HBM in time chunks.  While chunk k integrates (lanes pause at
+        its end time), chunk k+1 is uploaded on a second stream into the other of two device
+        buffers.  ``tables``: per forcing a float32 array [nT_j][ld]; ``cells``: int32 column
+        index per hillslope when the tables are per grid cell (ld = ncell), None when they are
+        per stream (ld = ns, the reference layout).  Bit-identical to the resident-forcing run."""
+        dev = self.device
+        host = [torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).pin_memory() for t in tables]
+        nT = [int(h.shape[0]) for h in host]
+        ld = int(host[0].shape[1])
+        assert all(h.shape[1] == ld for h in host) and (cells is not None or ld == self.ns)
+        col = None if cells is None else torch.from_numpy(np.ascontiguousarray(cells, dtype=np.int32)).to(dev)
+        dtmin = [float(d) * 60.0 for d in dt_hours]
+
+        def span(j, ta, tb):  # sample rows any t in [ta, tb] can ask for (rk45_kernel.cu:90-98)
+            first = min(max(int(np.floor(ta / dtmin[j])), 0), nT[j] - 1)
+            last = min(max(int(np.floor(tb / dtmin[j])), 0), nT[j] - 1)
+            return first, last - first + 1
+
+        edges = [self.t0]
+        while edges[-1] < self.tf:
+            edges.append(min(self.tf, edges[-1] + float(chunk_minutes)))
+        max_rows = sum(max(span(j, a, b)[1] for a, b in zip(edges[:-1], edges[1:])) for j in range(len(host)))
+        bufs = [torch.empty(max_rows * ld, dtype=torch.float32, device=dev) for _ in range(2)]
+        compute = torch.cuda.current_stream(dev)
+        copy = torch.cuda.Stream(device=dev)
+        done = [None, None]
+        for k, (ta, tb) in enumerate(zip(edges[:-1], edges[1:])):
+            b = k & 1
+            spans = [span(j, ta, tb) for j in range(len(host))]
+            with torch.cuda.stream(copy):
+                if done[b] is not None:
+                    copy.wait_event(done[b])  # the kernel that read this buffer has finished
+                off = 0
+                for j, (first, rows) in enumerate(spans):
+                    bufs[b][off:off + rows * ld].copy_(host[j][first:first + rows].reshape(-1), non_blocking=True)
+                    off += rows * ld
+                uploaded = torch.cuda.Event()
+                uploaded.record(copy)
+            compute.wait_event(uploaded)
+            j_ = self.job()
+            j_.d_forc, j_.d_forc_col, j_.forc_ld, j_.nforc = bufs[b].data_ptr(), (None if col is None else col.data_ptr()), ld, len(host)
+            for j, (first, rows) in enumerate(spans):
+                j_.forc_dt_hours[j], j_.forc_nT[j] = float(dt_hours[j]), nT[j]
+                j_.forc_first_index[j], j_.forc_rows[j] = first, rows
+            j_.d_resume, j_.resume_in = self._resume_buffer().data_ptr(), int(k > 0)
+            if tb < self.tf:
+                j_.use_t_stop, j_.t_stop = 1, tb
+            api.integrate_device(j_, compute)
+            done[b] = torch.cuda.Event()
+            done[b].record(compute)
+        torch.cuda.synchronize(dev)
+        return len(edges) - 1
 
     def integrate_streamed(self, window_queries, host_out=None, stream=None):
         """BASELINE config 5: dense output streamed to pinned host memory in windows of
