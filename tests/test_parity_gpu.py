@@ -676,3 +676,19 @@ def test_checkpoint_restore_continues_bitwise(gpu):
         j = a.job()
         j.use_t_stop, j.t_stop = 1, 100.0   # t_stop without a resume buffer
         H.api.integrate_device(j)
+
+
+def test_cpp_template_api_three_phases_and_errors(gpu, golden, tmp_path):
+    """include/hlm/*.hpp compiled with plain g++ (no HIP headers) and run on the GPU: the
+    reference's host API surface end to end (tests/cpp/test_rk45_api.cpp)."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "test_rk45_api")
+    lib = os.path.join(ROOT, "tiger_hlm_gpu_amd", "lib")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_rk45_api.cpp"), "-o", exe, "-L" + lib, "-lhlm_hip",
+                    "-Wl,-rpath," + lib, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    p = subprocess.run([exe, golden["small_test_csv"]], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert p.stdout.count("OK ") == 3 and "FAILED" not in p.stdout

@@ -130,7 +130,8 @@ int validate_job(const hlm_device_job* j)
         return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs d_sp (SpatialParams)");
     if (j->nforc < 0 || j->nforc > HLM_MAX_FORCINGS)
         return fail(HLM_ERR_INVALID_ARGUMENT, "nforc %d outside [0,%d]", j->nforc, HLM_MAX_FORCINGS);
-    if (j->nforc > 0) {
+    const bool reads_forcings = j->uid != HLM_UID_DUMMY;  // DummyDev::NF == 0: registered forcings are ignored
+    if (j->nforc > 0 && reads_forcings) {
         if (!j->d_forc) return fail(HLM_ERR_INVALID_ARGUMENT, "nforc > 0 needs d_forc");
         if (j->forc_ld <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "forc_ld must be > 0");
         if (!j->d_forc_col && j->forc_ld < j->num_systems)
@@ -157,7 +158,7 @@ int validate_job(const hlm_device_job* j)
     if (j->dense_tiled != 0 && j->dense_tiled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0 or 1");
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
-    for (int k = 0; k < j->nforc; ++k)
+    for (int k = 0; reads_forcings && k < j->nforc; ++k)
         if (j->forc_first_index[k] + (j->forc_rows[k] ? j->forc_rows[k] : j->forc_nT[k]) > j->forc_nT[k] ||
             j->forc_first_index[k] >= j->forc_nT[k])
             return fail(HLM_ERR_INVALID_ARGUMENT, "forcing %d: chunk [%llu, +%llu) outside its %llu samples", k,
