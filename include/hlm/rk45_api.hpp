@@ -106,6 +106,18 @@ inline void set_forcings(const float* d_forc, const std::vector<double>& dt_hour
     detail::check(hlm_set_forcings(d_forc, dt_hours.data(), n64.data(), (int)nT.size(), ld, d_col), "set_forcings");
 }
 
+// Forcing series kept in host memory and streamed through HBM in chunks of chunk_minutes by
+// launch_rk45_kernel / run_rk45 (h_tables[j]: float [nT[j]][ld], valid until hlm_clear_forcings).
+inline void set_forcings_host(const std::vector<const float*>& h_tables, const std::vector<double>& dt_hours,
+                              const std::vector<size_t>& nT, long long ld, double chunk_minutes,
+                              const int32_t* d_col = nullptr)
+{
+    if (dt_hours.size() != nT.size() || h_tables.size() != nT.size()) throw std::runtime_error("set_forcings_host: size mismatch");
+    std::vector<uint64_t> n64(nT.begin(), nT.end());
+    detail::check(hlm_set_forcings_host(h_tables.data(), dt_hours.data(), n64.data(), (int)nT.size(), ld, d_col, chunk_minutes),
+                  "set_forcings_host");
+}
+
 // ---- 1) allocate device buffers & copy inputs ------------------------------------------------
 template <class Model>
 auto setup_gpu_buffers(const std::vector<double>& h_y0, const std::vector<double>& h_query_times)

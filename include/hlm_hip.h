@@ -98,6 +98,12 @@ int hlm_set_math_mode(int mode);
  * means column = system (the reference layout). */
 int hlm_set_forcings(const float* d_forc, const double* dt_hours, const uint64_t* nT,
                      int nforc, int64_t ld, const int32_t* d_col);
+/* Alternative registration for the host API: the forcing series stay in HOST memory
+ * (h_tables[j]: float [nT[j]][ld]; the pointers must stay valid until hlm_clear_forcings) and
+ * hlm_launch_rk45_kernel / hlm_run_rk45 stream them through HBM in chunks of chunk_minutes
+ * (hlm_rk45_integrate_forcing_streamed). */
+int hlm_set_forcings_host(const float* const* h_tables, const double* dt_hours, const uint64_t* nT,
+                          int nforc, int64_t ld, const int32_t* d_col, double chunk_minutes);
 int hlm_clear_forcings(void);
 
 /* ---- three-phase host API (rk45_api.hpp:63-116, :120-154, :159-270) --------------- */
@@ -217,6 +223,16 @@ typedef struct hlm_stream_stats {
 } hlm_stream_stats;
 int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, double* h_dense,
                                 void* hip_stream, hlm_stream_stats* stats);
+/* Forcing series streamed through HBM in time chunks (BASELINE config 3: "NetCDF precip+t2m
+ * forcings streamed").  h_tables[j]: HOST float [job->forc_nT[j]][job->forc_ld] of forcing j
+ * (pinned memory makes the uploads asynchronous); job->d_forc is ignored.  The window [t0, tf]
+ * is cut into chunks of chunk_minutes; while chunk k integrates on `hip_stream` (hillslopes
+ * pause at its end time), the sample rows chunk k+1 needs are uploaded on a second stream into
+ * the other of two device buffers.  Results are bit-identical to the run with all forcings
+ * resident.  Synchronous.  *chunks (nullable) receives the number of launches. */
+int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* const* h_tables,
+                                        double chunk_minutes, void* hip_stream, int* chunks);
+
 /* Transfer path of hlm_rk45_integrate_streamed.  0 (default): linear device windows +
  * hipMemcpy2DAsync on the copy engine (fastest end to end: 54.8 GB/s measured).  1: tile-major
  * device windows (coalesced kernel stores) + a transposing kernel that writes pinned host

@@ -439,7 +439,7 @@ def test_cpp_driver_netcdf_forcings_and_netcdf_outputs(gpu, golden, tmp_path):
     lookup = tmp_path / "lookup.csv"
     lookup.write_text("stream,lat_index,lon_index\n" + "".join(f"{int(sp['stream'][i])},{a},{o}\n" for i, (a, o) in enumerate(cells)))
     f, d = str(tmp_path / "final.csv"), str(tmp_path / "dense.csv")
-    for extra in ([], ["--expand-forcings"]):
+    for extra in ([], ["--expand-forcings"], ["--stream-forcings", "420"]):
         subprocess.run([exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "2880", "--query-stride", "60",
                         "--forcing-nc", pr_nc + ":pr:1", "--forcing-nc", t2m_nc + ":t2m:24", "--lookup", str(lookup),
                         "--out-final", f, "--out-dense", d, "--out-format", "both", "--quiet"] + extra, check=True, timeout=300)
@@ -639,14 +639,16 @@ def test_streamed_forcings_equal_resident_bitwise(gpu, layout, chunk):
     ref = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT),
                       per_cell=(layout == "per-cell"), math_mode=H.MATH_FAST)
     eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, math_mode=H.MATH_FAST)
-    if layout == "per-cell":
-        n = eng.integrate_forcing_streamed((pr, t2m), dt, chunk, cells=cells)
-    else:
-        n = eng.integrate_forcing_streamed((pr[:, cells], t2m[:, cells]), dt, chunk)
-    assert n == int(np.ceil(days * 1440.0 / chunk))
-    got = eng.results()
-    for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
-        assert np.array_equal(got[k], ref[k]), k
+    for method in (eng.integrate_forcing_streamed, eng.integrate_forcing_streamed_abi):  # python loop, C ABI loop
+        eng.y_final.zero_()
+        if layout == "per-cell":
+            n = method((pr, t2m), dt, chunk, cells=cells)
+        else:
+            n = method((pr[:, cells], t2m[:, cells]), dt, chunk)
+        assert n == int(np.ceil(days * 1440.0 / chunk))
+        got = eng.results()
+        for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(got[k], ref[k]), (method.__name__, k)
 
 
 def test_checkpoint_restore_continues_bitwise(gpu):

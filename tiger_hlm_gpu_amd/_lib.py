@@ -81,6 +81,8 @@ SIGNATURES = {
     "hlm_set_math_mode": (C.c_int, [C.c_int]),
     "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
                                    C.c_int64, C.c_void_p]),
+    "hlm_set_forcings_host": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
+                                        C.c_int64, C.c_void_p, C.c_double]),
     "hlm_clear_forcings": (C.c_int, []),
     "hlm_setup_gpu_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(GpuBuffers)]),
     "hlm_launch_rk45_kernel": (C.c_int, [C.c_int, C.POINTER(GpuBuffers), C.c_double, C.c_double, C.c_void_p]),
@@ -92,6 +94,8 @@ SIGNATURES = {
     "hlm_resume_bytes": (C.c_size_t, [C.c_int]),
     "hlm_rk45_integrate_streamed": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p,
                                               C.POINTER(StreamStats)]),
+    "hlm_rk45_integrate_forcing_streamed": (C.c_int, [C.POINTER(DeviceJob), C.POINTER(C.c_void_p), C.c_double,
+                                                      C.c_void_p, C.POINTER(C.c_int)]),
     "hlm_set_stream_path": (C.c_int, [C.c_int]),
     "hlm_host_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "hlm_host_free_pinned": (C.c_int, [C.c_void_p]),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -57,6 +58,8 @@ struct ForcingState {
     double dt_h[HLM_MAX_FORCINGS] = {};
     uint64_t nT[HLM_MAX_FORCINGS] = {};
     int nforc = 0;
+    const float* h_tables[HLM_MAX_FORCINGS] = {};  // hlm_set_forcings_host: series kept on the host
+    double chunk_minutes = 0.0;                     // > 0: stream them in time chunks
 };
 // one registration per HIP device: d_forc is a device pointer, and a host process may drive
 // several GPUs (one thread each) through the host-buffer API
@@ -390,6 +393,27 @@ int hlm_set_forcings(const float* d_forc, const double* dt_hours, const uint64_t
     return HLM_SUCCESS;
 }
 
+int hlm_set_forcings_host(const float* const* h_tables, const double* dt_hours, const uint64_t* nT, int nforc,
+                          int64_t ld, const int32_t* d_col, double chunk_minutes)
+{
+    if (nforc <= 0 || nforc > HLM_MAX_FORCINGS || !h_tables || !dt_hours || !nT || ld <= 0 || !(chunk_minutes > 0.0))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "set_forcings_host: need 1..%d host tables, dt, nT, ld > 0, chunk > 0", HLM_MAX_FORCINGS);
+    std::lock_guard<std::mutex> lk(g_mu);
+    ForcingState& F = g_forc;
+    F = ForcingState{};
+    F.d_col = d_col;
+    F.ld = ld;
+    F.nforc = nforc;
+    F.chunk_minutes = chunk_minutes;
+    for (int k = 0; k < nforc; ++k) {
+        if (!h_tables[k]) return fail(HLM_ERR_INVALID_ARGUMENT, "h_tables[%d] is NULL", k);
+        F.h_tables[k] = h_tables[k];
+        F.dt_h[k] = dt_hours[k];
+        F.nT[k] = nT[k];
+    }
+    return HLM_SUCCESS;
+}
+
 int hlm_clear_forcings(void)
 {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -548,6 +572,96 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
     return rc;
 }
 
+int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* const* h_tables,
+                                        double chunk_minutes, void* hip_stream, int* chunks)
+{
+    if (!job || !h_tables) return fail(HLM_ERR_INVALID_ARGUMENT, "job / h_tables is NULL");
+    if (!(chunk_minutes > 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "chunk_minutes must be > 0");
+    if (job->nforc <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "no forcings to stream");
+    for (int k = 0; k < job->nforc; ++k)
+        if (!h_tables[k]) return fail(HLM_ERR_INVALID_ARGUMENT, "h_tables[%d] is NULL", k);
+    hlm_device_job probe = *job;  // the caller's d_forc / chunk / resume fields are ignored
+    probe.d_forc = reinterpret_cast<const float*>(sizeof(float));
+    probe.d_resume = nullptr;
+    probe.resume_in = probe.use_t_stop = 0;
+    std::memset(probe.forc_first_index, 0, sizeof(probe.forc_first_index));
+    std::memset(probe.forc_rows, 0, sizeof(probe.forc_rows));
+    int rc = validate_job(&probe);
+    if (rc != HLM_SUCCESS) return rc;
+    if (chunks) *chunks = 0;
+    if (job->num_systems == 0) return HLM_SUCCESS;
+    const int nf = job->nforc;
+    const size_t ld = (size_t)job->forc_ld;
+
+    // chunk edges and, per chunk and forcing, the sample rows any t in [ta, tb] can ask for
+    std::vector<double> edge{job->t0};
+    while (edge.back() < job->tf) edge.push_back(std::fmin(job->tf, edge.back() + chunk_minutes));
+    const int nchunk = (int)edge.size() - 1;
+    if (nchunk <= 0) return launch(&probe, static_cast<hipStream_t>(hip_stream)) /* tf <= t0: nothing to integrate */;
+    auto span = [&](int j, double ta, double tb, uint64_t* first, uint64_t* rows) {
+        const double dtm = job->forc_dt_hours[j] * 60.0;
+        auto idx = [&](double t) {
+            const double r = std::floor(t / dtm);
+            return r < 0.0 ? (uint64_t)0 : (r >= (double)job->forc_nT[j] ? job->forc_nT[j] - 1 : (uint64_t)r);
+        };
+        *first = idx(ta);
+        *rows = idx(tb) - *first + 1;
+    };
+    size_t max_rows = 0;
+    for (int j = 0; j < nf; ++j) {
+        uint64_t worst = 0, f, r;
+        for (int k = 0; k < nchunk; ++k) { span(j, edge[k], edge[k + 1], &f, &r); worst = r > worst ? r : worst; }
+        max_rows += worst;
+    }
+
+    hipStream_t compute = static_cast<hipStream_t>(hip_stream), copy = nullptr;
+    float* buf[2] = {nullptr, nullptr};
+    void* resume = nullptr;
+    hipEvent_t uploaded[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+    ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        if (b == 0 || nchunk > 1) ok(hipMalloc((void**)&buf[b], max_rows * ld * sizeof(float)));
+        ok(hipEventCreateWithFlags(&uploaded[b], hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
+    }
+    ok(hipMalloc(&resume, hlm_resume_bytes(job->num_systems)));
+    for (int k = 0; k < nchunk && e == hipSuccess && rc == HLM_SUCCESS; ++k) {
+        const int b = k & 1;
+        hlm_device_job j = *job;
+        if (k >= 2) ok(hipStreamWaitEvent(copy, consumed[b], 0));  // the kernel that read buffer b is done
+        size_t off = 0;
+        for (int f = 0; f < nf; ++f) {
+            span(f, edge[k], edge[k + 1], &j.forc_first_index[f], &j.forc_rows[f]);
+            ok(hipMemcpyAsync(buf[b] + off, h_tables[f] + (size_t)j.forc_first_index[f] * ld,
+                              (size_t)j.forc_rows[f] * ld * sizeof(float), hipMemcpyHostToDevice, copy));
+            off += (size_t)j.forc_rows[f] * ld;
+        }
+        ok(hipEventRecord(uploaded[b], copy));
+        ok(hipStreamWaitEvent(compute, uploaded[b], 0));
+        j.d_forc = buf[b];
+        j.d_resume = resume;
+        j.resume_in = k > 0;
+        j.use_t_stop = edge[k + 1] < job->tf;
+        j.t_stop = edge[k + 1];
+        if (e == hipSuccess) rc = launch(&j, compute);
+        ok(hipEventRecord(consumed[b], compute));
+    }
+    if (e == hipSuccess) ok(hipStreamSynchronize(compute));
+    if (e == hipSuccess) ok(hipStreamSynchronize(copy));
+    for (int b = 0; b < 2; ++b) {
+        if (buf[b]) (void)hipFree(buf[b]);
+        if (uploaded[b]) (void)hipEventDestroy(uploaded[b]);
+        if (consumed[b]) (void)hipEventDestroy(consumed[b]);
+    }
+    if (resume) (void)hipFree(resume);
+    if (copy) (void)hipStreamDestroy(copy);
+    if (e != hipSuccess) return fail(HLM_ERR_HIP, "integrate_forcing_streamed: %s", hipGetErrorString(e));
+    if (chunks && rc == HLM_SUCCESS) *chunks = nchunk;
+    return rc;
+}
+
 int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms)
 {
     if (iters < 0 || (iters > 0 && !ms)) return fail(HLM_ERR_INVALID_ARGUMENT, "iters/ms");
@@ -651,7 +765,18 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     j.d_stiff = b->d_stiff;
     j.d_n_attempt = b->d_n_attempt;
     j.d_n_accept = b->d_n_accept;
-    rc = hlm_rk45_integrate_device(&j, nullptr);
+    const float* host_tables[HLM_MAX_FORCINGS];
+    double chunk_minutes = 0.0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        const ForcingState& F = g_forc;
+        chunk_minutes = F.chunk_minutes;
+        std::memcpy(host_tables, F.h_tables, sizeof(host_tables));
+    }
+    if (chunk_minutes > 0.0 && uid != HLM_UID_DUMMY)
+        rc = hlm_rk45_integrate_forcing_streamed(&j, host_tables, chunk_minutes, nullptr, nullptr);
+    else
+        rc = hlm_rk45_integrate_device(&j, nullptr);
     if (rc != HLM_SUCCESS) return rc;
     HLM_HIP_TRY(hipDeviceSynchronize());  // rk45_api.hpp:150
     return HLM_SUCCESS;

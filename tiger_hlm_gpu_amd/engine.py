@@ -118,6 +118,23 @@ class ShardEngine:
     def restore(self, blob):
         self._resume_buffer().copy_(torch.from_numpy(np.ascontiguousarray(blob, dtype=np.uint8)))
 
+    def integrate_forcing_streamed_abi(self, tables, dt_hours, chunk_minutes, cells=None):
+        """Same as integrate_forcing_streamed, but the chunk loop runs inside the library
+        (hlm_rk45_integrate_forcing_streamed): what a C / C++ host calls."""
+        import ctypes as C
+        host = [torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).pin_memory() for t in tables]
+        ld = int(host[0].shape[1])
+        col = None if cells is None else torch.from_numpy(np.ascontiguousarray(cells, dtype=np.int32)).to(self.device)
+        j = self.job()
+        j.d_forc, j.d_forc_col, j.forc_ld, j.nforc = None, (None if col is None else col.data_ptr()), ld, len(host)
+        for k, h in enumerate(host):
+            j.forc_dt_hours[k], j.forc_nT[k] = float(dt_hours[k]), int(h.shape[0])
+        ptrs = (C.c_void_p * len(host))(*[h.data_ptr() for h in host])
+        n = C.c_int(0)
+        s = torch.cuda.current_stream(self.device)
+        _lib.check(_lib.lib().hlm_rk45_integrate_forcing_streamed(C.byref(j), ptrs, float(chunk_minutes), s.cuda_stream, C.byref(n)))
+        return n.value
+
     def integrate_forcing_streamed(self, tables, dt_hours, chunk_minutes, cells=None):
         """BASELINE config 3, "forcings streamed": the forcing series stay in (pinned) host
         memory and pass through HBM in time chunks.  While chunk k integrates (lanes pause at

@@ -50,6 +50,7 @@ struct Options {
     std::vector<std::string> forcing_nc;
     std::string lookup;           // stream,lat_index,lon_index CSV (main.cpp:495)
     bool expand_forcings = false; // reference per-stream layout instead of the per-cell table
+    double stream_forcings = 0.0; // > 0: keep the series on the host, stream them in chunks of this many minutes
     std::string out_format = "csv";  // csv | nc | both  (nc: main.cpp:786-823)
     int nc_compression = 0;
     int device = 0;
@@ -65,7 +66,7 @@ struct Options {
                  "usage: rk45_solver [--model dummy|204] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast]\n"
-                 "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings]\n"
+                 "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
                  "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L]\n"
                  "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
     std::exit(msg ? 2 : 0);
@@ -99,6 +100,7 @@ Options parse(int argc, char** argv)
         else if (a == "--forcing-nc") o.forcing_nc.push_back(val());
         else if (a == "--lookup") o.lookup = val();
         else if (a == "--expand-forcings") o.expand_forcings = true;
+        else if (a == "--stream-forcings") o.stream_forcings = std::atof(val());
         else if (a == "--out-format") o.out_format = val();
         else if (a == "--nc-compression") o.nc_compression = std::atoi(val());
         else if (a == "--device") o.device = std::atoi(val());
@@ -275,6 +277,13 @@ int run(const Options& o, hlm_io::CsvStyle style)
                         for (int s = 0; s < count; ++s) block[t * count + s] = fb.data[t * (size_t)fb.ld + (size_t)col_of_stream[start + s]];
                     d_forc = rk45_api::device_upload(block.data(), block.size());
                     rk45_api::set_forcings(d_forc, fb.dt_hours, fb.nT, count);
+                } else if (o.stream_forcings > 0) {
+                    // series stay in host memory; the library uploads the rows each time chunk needs
+                    d_col = rk45_api::device_upload(col_of_stream.data() + start, (size_t)count);
+                    std::vector<const float*> tables;
+                    size_t row = 0;
+                    for (size_t n : fb.nT) { tables.push_back(fb.data.data() + row * (size_t)fb.ld); row += n; }
+                    rk45_api::set_forcings_host(tables, fb.dt_hours, fb.nT, fb.ld, o.stream_forcings, d_col);
                 } else {
                     d_forc = rk45_api::device_upload(fb.data.data(), fb.data.size());
                     d_col = rk45_api::device_upload(col_of_stream.data() + start, (size_t)count);
@@ -291,7 +300,8 @@ int run(const Options& o, hlm_io::CsvStyle style)
             std::copy(info.stiff.begin(), info.stiff.end(), stiff.begin() + start);
             if (!info.n_attempt.empty()) std::copy(info.n_attempt.begin(), info.n_attempt.end(), n_attempt.begin() + start);
             rk45_api::device_free(d_sp);
-            if (d_forc) { hlm_clear_forcings(); rk45_api::device_free(d_forc); }
+            hlm_clear_forcings();
+            if (d_forc) rk45_api::device_free(d_forc);
             if (d_col) rk45_api::device_free(d_col);
         } catch (const std::exception& e) {
             errors[r] = e.what();
