@@ -694,3 +694,30 @@ def test_cpp_template_api_three_phases_and_errors(gpu, golden, tmp_path):
     p = subprocess.run([exe, golden["small_test_csv"]], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0, p.stdout + p.stderr
     assert p.stdout.count("OK ") == 3 and "FAILED" not in p.stdout
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_c3_thirty_days_50k_hillslopes_vs_oracle(gpu, oracle, math_mode):
+    """The benchmark workload itself (BASELINE config 3: Model 204, 30-day window, hourly pr +
+    daily t2m, per-stream forcing layout) on a 50 000-hillslope slice, every hillslope compared
+    with the CPU oracle after ~16 000 adaptive steps: finals within 1e-9 + 1e-6|y|, flags equal,
+    step counts within 1 %."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 50_000, 30
+    start = 123_456  # an interior slice of the 1 M-hillslope shard
+    sp = synth.model204_params(start, ns)
+    y0 = synth.model204_y0(ns)
+    cells = synth.cell_of_system(start, ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days)
+    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells),
+                     forc_dt_h=dt, forc_nT=nT)
+    agree = got["stiff"] == ref["stiff"]
+    assert agree.mean() > 0.9995, (~agree).sum()   # a marginal reject can flip a flag (5e-5 of systems are flagged at all)
+    ok = agree & (ref["stiff"] == 0)
+    d = np.abs(got["y_final"][ok] - ref["y_final"][ok])
+    within = np.all(d <= 1e-9 + 1e-6 * np.abs(ref["y_final"][ok]), axis=1)
+    assert within.mean() > 0.9995, (within.mean(), float(d.max()))
+    rel = np.abs(got["n_attempt"][ok].astype(float) - ref["n_attempt"][ok]) / ref["n_attempt"][ok]
+    assert rel.max() < 0.01 and 15000 < got["n_attempt"][ok].mean() < 17500
