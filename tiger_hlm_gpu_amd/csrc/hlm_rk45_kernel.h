@@ -171,51 +171,21 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     return broke;
 }
 
-// ---- dense-output staging -----------------------------------------------------------------
-// The host-facing dense layout is [sys][query][comp]: a lane's rows are contiguous in
-// memory (40 B per query) but the 64 lanes of a wave are nq*40 B apart, so a row store
-// touches 64 different cache lines per instruction.  Two store paths exist:
-//   HLM_DENSE_KQ == 0 (default)  every row is stored directly by its lane;
-//   HLM_DENSE_KQ  > 0            each lane parks up to KQ consecutive rows in LDS (stride
-//        66 dwords == 2 mod 32: conflict-free 64-bit writes) and the wave drains the tile
-//        cooperatively, one coalesced <= 240-byte store per source lane.
-// Measured on MI355X (1 M hillslopes, 1-minute queries, 57.6 GB of rows; profiles/
-// r01_dense_pmc.json): direct 26.6 ms, WRITE_SIZE 91.8 GB (partial-line evictions), 54 %
-// of wave cycles waiting; LDS-staged (KQ=6) 27.7 ms, WRITE_SIZE 67.0 GB, but +50 % VALU
-// instructions for the drain loop.  Neither is ALU-bound (the same steps take ~10 ms without
-// the stores); the streamed pipeline is PCIe-bound at 55 GB/s either way, so the simpler
-// direct path is the default and the tile-major device layout + transpose-to-host kernel
-// is the next step.
-#ifndef HLM_DENSE_KQ
-#define HLM_DENSE_KQ 0
-#endif
-constexpr int DENSE_KQ = HLM_DENSE_KQ;  // rows parked per lane (0 = store every row directly)
-constexpr int DENSE_LROW = 33;  // doubles of LDS per lane (30 used + pad)
+// ---- dense output ---------------------------------------------------------------------------
+// The host-facing dense layout is [sys][query][comp]: a lane's rows are contiguous in memory
+// (40 B per query) but the 64 lanes of a wave are nq*40 B apart, so a row store touches 64
+// different cache lines per instruction.  Measured on MI355X (1 M hillslopes, 1-minute queries,
+// 57.6 GB of rows; profiles/r01_dense_pmc.json): 26.6 ms, WRITE_SIZE 91.8 GB (partial-line
+// evictions), 54 % of wave cycles waiting.  Parking rows in LDS and draining them cooperatively
+// with coalesced <= 240-byte stores lowered WRITE_SIZE to 67.0 GB but cost +50 % VALU for the
+// drain loop (27.7 ms) and was removed again; the tile-major layout below (rows of a wave
+// contiguous) runs in 19.4 ms.  The streamed pipeline is PCIe-bound at 55 GB/s either way.
 // Query times: the next query time gates the row loop; instead of a dependent global load
 // per row the wave keeps a sliding window of QWIN query times in LDS (lanes of a wave
 // advance through the queries together; a lane outside the window falls back to the global
 // load).  Worth 2 % on the dense kernel (27.2 -> 26.6 ms): the stores, not this load, set
 // its pace.
 constexpr int DENSE_QWIN = 256;
-
-__device__ __forceinline__ void dense_flush(const double* lds_rows, int lane, int& cnt, double* gfirst)
-{
-    const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
-    const int nact = __builtin_popcountll(act);
-    const int rank = __builtin_popcountll(act & ((1ull << lane) - 1ull));
-    unsigned long long todo = __builtin_amdgcn_ballot_w64(cnt > 0);
-    const unsigned glo = (unsigned)((unsigned long long)gfirst), ghi = (unsigned)((unsigned long long)gfirst >> 32);
-    while (todo) {
-        const int L = __builtin_ctzll(todo);  // wave-uniform source lane
-        todo &= todo - 1ull;
-        const int nd = __builtin_amdgcn_readlane(cnt, L) * NEQ;
-        double* g = reinterpret_cast<double*>(((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)ghi, L) << 32) |
-                                              (unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)glo, L));
-        const double* src = lds_rows + L * DENSE_LROW;
-        for (int i = rank; i < nd; i += nact) g[i] = src[i];
-    }
-    cnt = 0;
-}
 
 // RESUMABLE: query windows / t_stop / forcing time chunks / checkpoints.  The plain variant
 // (one uninterrupted launch, all forcings resident) carries none of that state: keeping it
@@ -263,7 +233,6 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     double* dense_row = nullptr;
     [[maybe_unused]] size_t q_stride = NEQ;
     double tq_next = 0.0;
-    __shared__ double lds_rows[DENSE && DENSE_KQ > 0 ? WAVE * DENSE_LROW : 1];
     __shared__ double lds_query[DENSE ? DENSE_QWIN : 1];
     [[maybe_unused]] int qwin_base = -(1 << 30);  // wave-uniform: first query index held in lds_query
     using lds_cdouble_ptr = const __attribute__((address_space(3))) double*;
@@ -277,8 +246,6 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         return v;
     };
     [[maybe_unused]] const int lane = (int)threadIdx.x;
-    [[maybe_unused]] int parked = 0;             // rows of this lane waiting in LDS
-    [[maybe_unused]] double* gfirst = nullptr;   // global address of the first parked row
     [[maybe_unused]] int qb = 0, qe = 0;
     if constexpr (DENSE) {
         // Query window [qb, qe) of this launch (the whole range unless the host streams the
@@ -353,10 +320,6 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     const double t_end = RESUMABLE ? fmin(tf, A.t_stop) : tf;
     while (t < t_end && status == HLM_SYS_OK) {
         if constexpr (DENSE) {
-            // drain the LDS tile as soon as any lane's slots are full (wave-uniform branch)
-            if constexpr (DENSE_KQ > 0) {
-                if (__builtin_amdgcn_ballot_w64(parked >= DENSE_KQ) != 0ull) dense_flush(lds_rows, lane, parked, gfirst);
-            }
             // slide the query-time window when the wave's first active lane nears its end
             const int qf = __builtin_amdgcn_readfirstlane(next_q);
             if (qf < A.nq && (unsigned)(qf - qwin_base) >= (unsigned)(DENSE_QWIN - 16)) {
@@ -495,22 +458,10 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
                     if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
                     const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
                     double* o = dense_row + (size_t)next_q * q_stride;
-                    double row[NEQ];
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) {
                         const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
-                        row[i] = __builtin_fma(h, poly, y[i]);  // rk45_step_dense.cuh:235-243
-                    }
-                    if (parked < DENSE_KQ) {
-                        if (parked == 0) gfirst = o;
-                        double* l = lds_rows + lane * DENSE_LROW + parked * NEQ;
-#pragma unroll
-                        for (int i = 0; i < NEQ; ++i) l[i] = row[i];
-                        ++parked;
-                    } else {
-                        // a single long step with more queries than LDS slots: store directly
-#pragma unroll
-                        for (int i = 0; i < NEQ; ++i) o[i] = row[i];
+                        o[i] = __builtin_fma(h, poly, y[i]);  // rk45_step_dense.cuh:235-243
                     }
                     ++next_q;
                     tq_next = next_q < A.nq ? query_at(next_q) : __builtin_inf();
@@ -536,7 +487,6 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
     }
 
-    if constexpr (DENSE && DENSE_KQ > 0) dense_flush(lds_rows, lane, parked, gfirst);  // all lanes have left the loop
     if (RESUMABLE && status == HLM_SYS_OK && t < tf) status = SYS_PAUSED;  // stopped by t_stop
     if (resume_i) {
         resume_i[(size_t)4 * A.ns + sys] = status;
