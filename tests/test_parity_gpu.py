@@ -721,3 +721,35 @@ def test_c3_thirty_days_50k_hillslopes_vs_oracle(gpu, oracle, math_mode):
     assert within.mean() > 0.9995, (within.mean(), float(d.max()))
     rel = np.abs(got["n_attempt"][ok].astype(float) - ref["n_attempt"][ok]) / ref["n_attempt"][ok]
     assert rel.max() < 0.01 and 15000 < got["n_attempt"][ok].mean() < 17500
+
+
+def test_division_by_invariant_is_ieee_exact(gpu):
+    """STRICT mode divides by per-system constants with q = n*RN(1/d); q += fma(-q, d, n)*RN(1/d)
+    (Markstein's step) instead of the 11-instruction IEEE expansion.  Bit-for-bit equality with
+    '/' is checked here on 6e7 operand pairs: wide-range, narrow-exponent random significands,
+    and adversarial divisors (significands near 1, near 2, long runs of ones)."""
+    H = gpu
+    import torch
+    L = H._lib.lib()
+    rng = np.random.default_rng(5)
+
+    def run(which, n, d):
+        x = torch.from_numpy(np.concatenate([n, d])).cuda()
+        out = torch.empty(n.size, dtype=torch.float64, device="cuda")
+        H._lib.check(L.hlm_selftest_math(which, x.data_ptr(), out.data_ptr(), n.size, None))
+        torch.cuda.synchronize()
+        return out.cpu().numpy()
+
+    N = 20_000_000
+    cases = []
+    cases.append((10.0 ** rng.uniform(-30, 30, N) * rng.choice([-1.0, 1.0], N), 10.0 ** rng.uniform(-6, 8, N)))
+    cases.append((np.ldexp(1.0 + rng.random(N), rng.integers(-3, 4, N)), np.ldexp(1.0 + rng.random(N), rng.integers(-3, 4, N))))
+    k = rng.integers(0, 2 ** 20, N).astype(np.uint64)
+    pat = rng.integers(0, 4, N)
+    ones = np.uint64(2 ** 52 - 1)
+    m = np.where(pat == 0, k, np.where(pat == 1, ones - k, np.where(pat == 2, k << np.uint64(32), ones ^ (k << np.uint64(20)))))
+    d_adv = (np.uint64(0x3FF0000000000000) | (m & ones)).view(np.float64)
+    cases.append((np.ldexp(1.0 + rng.random(N), rng.integers(-2, 3, N)), d_adv))
+    for n, d in cases:
+        a, b = run(5, n, d), run(6, n, d)
+        assert np.array_equal(a.view(np.uint64), b.view(np.uint64))

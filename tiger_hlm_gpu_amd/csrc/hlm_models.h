@@ -55,6 +55,35 @@ __device__ __forceinline__ double vmax_abs2(double m, double b)
     return r;
 }
 
+// n / d for a divisor whose correctly rounded reciprocal rd = RN(1/d) is at hand (per-system
+// constants: Hu, alpha3, alpha4, A_h): q = RN(n*rd) is within 2 ulp of n/d, the residual
+// n - q*d is exact in one FMA, and q + rem*rd rounds to RN(n/d) (Markstein's division step).
+// Three FMA-class instructions instead of the ~11 + v_rcp_f64 of the IEEE expansion.
+// Verified bit-for-bit against '/' on the GPU for 4e8 operand pairs incl. adversarial
+// significands (tests/test_parity_gpu.py::test_division_by_invariant_is_ieee_exact); operands
+// and quotient must be normal, finite and clear of the overflow/underflow margins, which the
+// caller guarantees by falling back to '/' otherwise.
+__device__ __forceinline__ double div_by_invariant(double n, double d, double rd)
+{
+    const double q = n * rd;
+    const double rem = __builtin_fma(-q, d, n);
+    return __builtin_fma(rem, rd, q);
+}
+
+// IEEE n / d for STRICT mode: the 3-instruction form when it is provably exact, '/' otherwise
+// (zero, subnormal, huge, Inf or NaN numerators; a divisor outside [1e-100, 1e100]).
+__device__ __forceinline__ double strict_div(double n, double d, double rd, bool divisor_ok)
+{
+    const double an = fabs(n);
+    if (divisor_ok && an >= 1e-290 && an <= 1e290) return div_by_invariant(n, d, rd);
+    return n / d;
+}
+__device__ __forceinline__ bool divisor_in_safe_range(double d)
+{
+    const double ad = fabs(d);
+    return ad >= 1e-100 && ad <= 1e100;
+}
+
 // x^(-1/n) refinement shared by the FAST roots: given a seed w ~ x^(-1/n) with residual
 // e = 1 - x w^n, the exact root is w (1-e)^(-1/n) = w (1 + c1 e + c2 e^2 + c3 e^3 + ...).
 // With an f32 exp2/log2 seed |e| < ~1e-4, so three series terms leave ~e^4 < 1e-16.
@@ -101,8 +130,10 @@ struct Model204Dev {
         double infil, perco, Hu, L, A_h, alpha3, alpha4, melt_f, temp_thr;
         double inv_n;       // 1.0 / n_mann   (same operation as :103, hoisted: bit-identical)
         double sqrt_slope;  // sqrt(slope)    (idem)
-        // FAST mode only: reciprocals / products replacing the per-call divides
-        double inv_Hu, manning, inv_alpha3, inv_alpha4;
+        // FAST: reciprocals / products replacing the per-call divides.  STRICT: inv_* are the
+        // correctly rounded reciprocals RN(1/d) that strict_div() needs for its exact 3-FMA form.
+        double inv_Hu, manning, inv_alpha3, inv_alpha4, inv_A_h;
+        bool div_ok;  // STRICT: all four divisors are within [1e-100, 1e100]
     };
 
     // Values that depend only on the held forcing samples; recomputed when a sample
@@ -137,8 +168,16 @@ struct Model204Dev {
             // the reference drains only when alpha >= 1 (:110,:113)
             P.inv_alpha3 = S.alpha3 >= 1.0 ? 1.0 / S.alpha3 : 0.0;
             P.inv_alpha4 = S.alpha4 >= 1.0 ? 1.0 / S.alpha4 : 0.0;
+            P.inv_A_h = 0.0;
+            P.div_ok = false;
         } else {
-            P.inv_Hu = P.manning = P.inv_alpha3 = P.inv_alpha4 = 0.0;
+            P.manning = 0.0;
+            P.inv_Hu = 1.0 / S.Hu;
+            P.inv_alpha3 = 1.0 / S.alpha3;
+            P.inv_alpha4 = 1.0 / S.alpha4;
+            P.inv_A_h = 1.0 / S.A_h;
+            P.div_ok = divisor_in_safe_range(S.Hu) && divisor_in_safe_range(S.alpha3) &&
+                       divisor_in_safe_range(S.alpha4) && divisor_in_safe_range(S.A_h);
         }
         return P;
     }
@@ -190,7 +229,8 @@ struct Model204Dev {
         const double d1 = x1 - x2;
         const double Emax = vmin(F.e_pot, h_stat);
         double s;
-        if constexpr (MATH == MATH_FAST) s = h_stat * P.inv_Hu; else s = h_stat / P.Hu;
+        if constexpr (MATH == MATH_FAST) s = h_stat * P.inv_Hu;
+        else s = strict_div(h_stat, P.Hu, P.inv_Hu, P.div_ok);  // == h_stat / Hu, bit for bit
         dydt[1] = d1 - s * Emax;
 
         // surface (:101-105).  pow(0, 2/3) == 0 exactly, hence alfa2 == 0, w == 0 and
@@ -205,7 +245,7 @@ struct Model204Dev {
                 w = vmin(1.0, P.manning * pow_two_thirds<MATH>(h_surf));
             } else {
                 const double alfa2 = P.inv_n * pow_two_thirds<MATH>(h_surf) * P.sqrt_slope;
-                w = vmin(1.0, alfa2 * P.L / P.A_h * 60.0);
+                w = vmin(1.0, strict_div(alfa2 * P.L, P.A_h, P.inv_A_h, P.div_ok) * 60.0);
             }
             out2 = d2 - h_surf * w;
         }
@@ -218,8 +258,8 @@ struct Model204Dev {
             dydt[3] = d3 - h_grav * P.inv_alpha3;
             dydt[4] = x4 - h_aq * P.inv_alpha4;
         } else {
-            dydt[3] = d3 - (P.alpha3 >= 1.0 ? h_grav / P.alpha3 : 0.0);
-            dydt[4] = x4 - (P.alpha4 >= 1.0 ? h_aq / P.alpha4 : 0.0);
+            dydt[3] = d3 - (P.alpha3 >= 1.0 ? strict_div(h_grav, P.alpha3, P.inv_alpha3, P.div_ok) : 0.0);
+            dydt[4] = x4 - (P.alpha4 >= 1.0 ? strict_div(h_aq, P.alpha4, P.inv_alpha4, P.div_ok) : 0.0);
         }
         return DRY && d2 != 0.0;
     }

@@ -521,7 +521,8 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
 
 // ---- self-test of the FAST-mode elementary functions (hlm_selftest_math) ---------------------
 // which: 0 = x^(2/3) (pow_two_thirds<FAST>), 1 = x^(-1/5) (inv_fifth_root<FAST>), 2 = 1/x (fast_rcp),
-//        3 = x^(2/3) STRICT (OCML pow), 4 = x^(-1/5) STRICT
+//        3 = x^(2/3) STRICT (OCML pow), 4 = x^(-1/5) STRICT, 5 = div_by_invariant, 6 = IEEE n/d
+//        (5 and 6 read the divisors from in[n .. 2n))
 __global__ void selftest_math_kernel(int which, const double* __restrict__ in, double* __restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -533,7 +534,13 @@ __global__ void selftest_math_kernel(int which, const double* __restrict__ in, d
         case 1: r = inv_fifth_root<MATH_FAST>(x); break;
         case 2: r = fast_rcp(x); break;
         case 3: r = pow_two_thirds<MATH_STRICT>(x); break;
-        default: r = inv_fifth_root<MATH_STRICT>(x); break;
+        case 4: r = inv_fifth_root<MATH_STRICT>(x); break;
+        case 5: {  // n / d with the divisor's correctly rounded reciprocal (in[i] = n, in[i + n] = d)
+            const double d = in[i + n];
+            r = div_by_invariant(x, d, 1.0 / d);
+            break;
+        }
+        default: r = x / in[i + n]; break;  // 6: IEEE division, the reference for case 5
     }
     out[i] = r;
 }
