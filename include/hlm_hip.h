@@ -246,6 +246,13 @@ int hlm_host_free_pinned(void* hptr);
  * doubles.  0: x^(2/3) FAST, 1: x^(-1/5) FAST, 2: 1/x FAST, 3: x^(2/3) STRICT, 4: x^(-1/5) STRICT. */
 int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void* hip_stream);
 
+/* Single device evaluations of Model::rhs (the reference's debugRHS kernel, main.cpp:219-246):
+ * d_y [n][5], d_sp [n] SpatialParams, d_F [n][2] float forcing samples, d_out [n][5].
+ * fast_path != 0 evaluates the model's fast-path RHS instead and writes its "precondition
+ * broke" flag to d_broke[n] (nullable). */
+int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, const void* d_sp,
+                     const float* d_F, double* d_out, int32_t* d_broke, int n, void* hip_stream);
+
 /* Static facts about the compiled kernels (for DESIGN.md / bench output). */
 int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs,
                     int* lds_bytes, int* max_threads);

@@ -753,3 +753,57 @@ def test_division_by_invariant_is_ieee_exact(gpu):
     for n, d in cases:
         a, b = run(5, n, d), run(6, n, d)
         assert np.array_equal(a.view(np.uint64), b.view(np.uint64))
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_device_rhs_single_evaluations_vs_oracle(gpu, oracle, math_mode):
+    """Model::rhs on the device, one evaluation per random (state, parameters, forcing) triple,
+    against the oracle's rhs: the unit-level parity check under the integrator.  Includes the
+    negative-surface-store case (pow -> NaN -> fmin(1, NaN) = 1: no NaN may leave the RHS,
+    SURVEY A.1 note 6), cold and warm temperatures, saturated and unsaturated static stores."""
+    H = gpu
+    import torch
+    from tiger_hlm_gpu_amd import synth
+    n = 20000
+    rng = np.random.default_rng(99)
+    sp = synth.model204_params(0, n, seed=3)
+    sp["Hu"] = 10.0 ** rng.uniform(-3, 2.5, n)
+    sp["temp_thr"] = rng.uniform(-1, 2, n)
+    sp["alpha3"][:50] = 0.5  # alpha < 1: the store does not drain (model_204.hpp:110)
+    y = np.stack([rng.uniform(-1e-3, 0.05, n), rng.uniform(0, 3, n), rng.uniform(-1e-3, 0.02, n) * (rng.random(n) < 0.7),
+                  rng.uniform(0, 5, n), rng.uniform(0, 1, n)], axis=1)
+    F = np.stack([rng.uniform(0, 1e-3, n) * (rng.random(n) < 0.5), rng.uniform(-5, 20, n)], axis=1).astype(np.float32)
+    yd, Fd = torch.from_numpy(y).cuda(), torch.from_numpy(F).cuda()
+    spd = torch.from_numpy(sp.view(np.uint8).reshape(n, 136)).cuda()
+    out = torch.empty((n, 5), dtype=torch.float64, device="cuda")
+    L = H._lib.lib()
+    H._lib.check(L.hlm_selftest_rhs(H.UID_204, math_mode, 0, yd.data_ptr(), spd.data_ptr(), Fd.data_ptr(), out.data_ptr(), None, n, None))
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    ref = np.stack([oracle.rhs(oracle.UID_204, y[i], sp[i:i + 1], F[i]) for i in range(n)])
+    assert np.all(np.isfinite(got))
+    neg = y[:, 2] < 0
+    assert neg.sum() > 300 and np.allclose(got[neg, 2], ref[neg, 2], rtol=1e-14, atol=0)  # drains at rate 1/min
+    scale = np.maximum(np.abs(ref), 1e-300)
+    tol = 1e-15 if math_mode == 0 else 4e-15
+    # every term is a handful of roundings away; cancellation in d - s*Emax can amplify, so compare
+    # against the magnitude of the inputs of each equation as well
+    mag = np.abs(y).max(axis=1, keepdims=True) + np.abs(F[:, :1]) + 1e-300
+    assert np.all(np.abs(got - ref) <= tol * np.maximum(scale, mag) * 8)
+    # the fast path (dry surface store) is bit-identical to the general RHS where it applies
+    dry = y[:, 2] == 0
+    assert dry.sum() > 1000
+    out2 = torch.empty_like(out)
+    broke = torch.empty(n, dtype=torch.int32, device="cuda")
+    H._lib.check(L.hlm_selftest_rhs(H.UID_204, math_mode, 1, yd.data_ptr(), spd.data_ptr(), Fd.data_ptr(), out2.data_ptr(),
+                                    broke.data_ptr(), n, None))
+    torch.cuda.synchronize()
+    g2, br = out2.cpu().numpy(), broke.cpu().numpy()
+    assert np.array_equal(g2[dry], got[dry])
+    assert np.array_equal(br[dry] != 0, got[dry, 2] != 0.0)  # "broke" <=> inflow reached the surface store
+    # DummyModel
+    outd = torch.empty_like(out)
+    H._lib.check(L.hlm_selftest_rhs(H.UID_DUMMY, 0, 0, yd.data_ptr(), None, Fd.data_ptr(), outd.data_ptr(), None, n, None))
+    torch.cuda.synchronize()
+    refd = np.stack([oracle.rhs(oracle.UID_DUMMY, y[i]) for i in range(0, n, 20)])
+    assert np.allclose(outd.cpu().numpy()[::20], refd, rtol=1e-14, atol=2e-15)  # FMA-contracted products

@@ -101,6 +101,8 @@ SIGNATURES = {
     "hlm_host_free_pinned": (C.c_int, [C.c_void_p]),
     "hlm_rk45_time_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     "hlm_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hlm_selftest_rhs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_void_p]),
     "hlm_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

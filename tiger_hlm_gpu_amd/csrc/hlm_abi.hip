@@ -697,6 +697,28 @@ int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void*
     return HLM_SUCCESS;
 }
 
+int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, const void* d_sp, const float* d_F,
+                     double* d_out, int32_t* d_broke, int n, void* hip_stream)
+{
+    if (n < 0 || (n > 0 && (!d_y || !d_F || !d_out))) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest_rhs buffers");
+    if (math_mode != HLM_MATH_STRICT && math_mode != HLM_MATH_FAST) return fail(HLM_ERR_INVALID_ARGUMENT, "math mode %d", math_mode);
+    if (uid == HLM_UID_204 && n > 0 && !d_sp) return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs d_sp");
+    if (n == 0) return HLM_SUCCESS;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    using namespace hlm;
+    if (uid == HLM_UID_204 && math_mode == HLM_MATH_FAST)
+        hipLaunchKernelGGL((selftest_rhs_kernel<Model204Dev, MATH_FAST>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, fast_path, n);
+    else if (uid == HLM_UID_204)
+        hipLaunchKernelGGL((selftest_rhs_kernel<Model204Dev, MATH_STRICT>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, fast_path, n);
+    else if (uid == HLM_UID_DUMMY)
+        hipLaunchKernelGGL((selftest_rhs_kernel<DummyDev, MATH_STRICT>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, 0, n);
+    else
+        return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    HLM_HIP_TRY(hipGetLastError());
+    return HLM_SUCCESS;
+}
+
 int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs, int* lds_bytes,
                     int* max_threads)
 {

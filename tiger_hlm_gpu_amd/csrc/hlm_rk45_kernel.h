@@ -545,6 +545,29 @@ __global__ void selftest_math_kernel(int which, const double* __restrict__ in, d
     out[i] = r;
 }
 
+// ---- single RHS evaluations (hlm_selftest_rhs): the reference's debugRHS kernel, main.cpp:219-246 ----
+// y: [n][5] states, sp: [n] SpatialParams, F: [n][2] forcing values (as the float samples the
+// gather would deliver), out: [n][5] = Model::rhs.  fast_path != 0 evaluates rhs_fast instead
+// (valid where Model::fastpath_ok(y) holds) and stores its "left the regime" flag in broke[n].
+template <class Model, int MATH>
+__global__ void selftest_rhs_kernel(const double* __restrict__ y, const void* sp, const float* __restrict__ F,
+                                    double* __restrict__ out, int* __restrict__ broke, int fast_path, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const typename Model::Local P = Model::template load<MATH>(sp, i);
+    const typename Model::Forc FV = Model::prep_forcing(P, (double)F[2 * i], (double)F[2 * i + 1]);
+    double yy[NEQ], d[NEQ];
+#pragma unroll
+    for (int c = 0; c < NEQ; ++c) yy[c] = y[(size_t)i * NEQ + c];
+    bool b = false;
+    if (fast_path) b = Model::template rhs_fast<MATH>(P, FV, yy, d);
+    else Model::template rhs<MATH>(P, FV, yy, d);
+#pragma unroll
+    for (int c = 0; c < NEQ; ++c) out[(size_t)i * NEQ + c] = d[c];
+    if (broke) broke[i] = b ? 1 : 0;
+}
+
 // ---- tile-major window -> host order -------------------------------------------------------
 // Transposes one query window from the kernel's tile-major layout [blk][W][64][5] to the
 // host-facing order dst[(sys*nq + q)*5 + c] (rk45_api.hpp:255-267).  dst is normally PINNED
