@@ -218,6 +218,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     // a final-ulp tie of the quotient, a measure-zero difference from the reference.)
     [[maybe_unused]] size_t fcol = 0;
     [[maybe_unused]] double tb0 = -__builtin_inf(), tb1 = -__builtin_inf();
+    [[maybe_unused]] double tb_next = -__builtin_inf();  // min(tb0, tb1): when the held samples expire
     double F0 = 0.0, F1 = 0.0;
     const bool use_f0 = Model::NF > 0 && A.nforc > 0;
     const bool use_f1 = Model::NF > 1 && A.nforc > 1;
@@ -305,7 +306,6 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         tq_next = next_q < A.nq ? A.query[next_q] : __builtin_inf();
     }
 
-    bool t_moved = true;   // forcing must be (re)sampled at the step's start time
     // k0 = rhs(t, y, F) is recomputed by the reference on every attempt (no FSAL,
     // rk45_kernel.cu:114).  It is a pure function of (t, y, F): after a reject or a
     // slope-jump retry none of them changed, and after an accepted step k6 was evaluated at
@@ -318,7 +318,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
     // t_stop (time chunks / checkpoints): a lane whose t has reached it pauses BEFORE its next
     // attempt, so the continuation in the next launch repeats nothing and changes nothing.
     const double t_end = RESUMABLE ? fmin(tf, A.t_stop) : tf;
-    while (t < t_end && status == HLM_SYS_OK) {
+    while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
         if constexpr (DENSE) {
             // slide the query-time window when the wave's first active lane nears its end
             const int qf = __builtin_amdgcn_readfirstlane(next_q);
@@ -332,25 +332,25 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
                 qwin_base = nb;
             }
         }
-        if (n_attempt >= A.cap) { status = HLM_SYS_CAPPED; break; }
         if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
 
         if constexpr (Model::NF > 0) {
-            if (t_moved) {
+            // one rarely-taken branch per attempt: has t (which only moves on an accepted step)
+            // reached the end of a held forcing sample?
+            if (!(t < tb_next)) {
                 if (use_f0 && !(t < tb0)) {
                     const unsigned long long i0 = forcing_index(t, A.forc_dtmin[0], A.forc_nT[0]);
                     tb0 = (i0 + 1ull < A.forc_nT[0]) ? (double)(i0 + 1ull) * A.forc_dtmin[0] : __builtin_inf();
                     F0 = (double)A.forc[A.forc_base[0] + (RESUMABLE ? forcing_row(i0, A.forc_first[0], A.forc_rows[0]) : (size_t)i0) * (size_t)A.forc_ld + fcol];
-                    have_k0 = false;
                 }
                 if (use_f1 && !(t < tb1)) {
                     const unsigned long long i1 = forcing_index(t, A.forc_dtmin[1], A.forc_nT[1]);
                     tb1 = (i1 + 1ull < A.forc_nT[1]) ? (double)(i1 + 1ull) * A.forc_dtmin[1] : __builtin_inf();
                     F1 = (double)A.forc[A.forc_base[1] + (RESUMABLE ? forcing_row(i1, A.forc_first[1], A.forc_rows[1]) : (size_t)i1) * (size_t)A.forc_ld + fcol];
-                    have_k0 = false;
                 }
-                if (!have_k0) FV = Model::prep_forcing(P, F0, F1);
-                t_moved = false;
+                tb_next = fmin(use_f0 ? tb0 : __builtin_inf(), use_f1 ? tb1 : __builtin_inf());
+                FV = Model::prep_forcing(P, F0, F1);
+                have_k0 = false;
             }
         }
 
@@ -481,12 +481,12 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
             k0[i] = k6[i];  // = rhs(t1, y_new, F): next attempt's k0 unless the forcing moves
         }
         t = t1;
-        t_moved = true;
         ++n_accept;
         if constexpr (FIXED) h = A.fixed_step;
         else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
     }
 
+    if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
     if (RESUMABLE && status == HLM_SYS_OK && t < tf) status = SYS_PAUSED;  // stopped by t_stop
     if (resume_i) {
         resume_i[(size_t)4 * A.ns + sys] = status;
