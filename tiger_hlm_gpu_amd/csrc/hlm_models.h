@@ -234,12 +234,15 @@ struct Model204Dev {
         dydt[1] = d1 - s * Emax;
 
         // surface (:101-105).  pow(0, 2/3) == 0 exactly, hence alfa2 == 0, w == 0 and
-        // dydt[2] == d2 - 0: a dry surface store skips the transcendental bit-exactly;
-        // a wave whose 64 hillslopes are all dry skips it entirely (s_cbranch_execz).
+        // dydt[2] == d2 - 0: a dry surface store needs no transcendental.  Waves whose 64
+        // hillslopes are all dry take the DRY variant (rk_stages' fast path); the general
+        // variant evaluates the term for every lane WITHOUT a per-lane branch -- a dry lane in
+        // a mixed wave gets w == 0 from the arithmetic itself (pow_two_thirds(0) == 0 in both
+        // math modes), and seven branches per attempt cost more than they could ever skip.
         const double x3 = vmin(x2, P.infil);
         const double d2 = x2 - x3;
         double out2 = d2;
-        if (!DRY && h_surf != 0.0) {
+        if constexpr (!DRY) {
             double w;
             if constexpr (MATH == MATH_FAST) {
                 w = vmin(1.0, P.manning * pow_two_thirds<MATH>(h_surf));
