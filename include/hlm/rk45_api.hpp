@@ -118,6 +118,10 @@ inline void set_forcings_host(const std::vector<const float*>& h_tables, const s
                   "set_forcings_host");
 }
 
+// Radau-IIA fallback for the systems RK45 flags (the pass rk45_api.hpp:189-247 of the reference
+// attempts inside retrieve_and_free); off by default = the reference's observable behaviour.
+inline void set_radau_fallback(bool on) { detail::check(hlm_set_radau_fallback(on ? 1 : 0), "set_radau_fallback"); }
+
 // ---- 1) allocate device buffers & copy inputs ------------------------------------------------
 template <class Model>
 auto setup_gpu_buffers(const std::vector<double>& h_y0, const std::vector<double>& h_query_times)

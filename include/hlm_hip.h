@@ -88,6 +88,10 @@ int hlm_get_model_parameters(int uid, double p[6]);
 int hlm_set_fixed_step(int uid, double h);
 int hlm_set_attempt_cap(uint32_t cap);
 int hlm_set_math_mode(int mode);
+/* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
+ * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free); 0 (default): flagged systems
+ * keep stiff = 1 and zero rows, the reference's observable behaviour. */
+int hlm_set_radau_fallback(int enabled);
 
 /* ---- forcing symbols (I_O/forcing_data.cu:5-10; uploads at main.cpp:559-574) -------
  * d_forc: DEVICE pointer, float [sum_j nT[j]][ld] forcing-major then time then column
@@ -201,6 +205,15 @@ size_t hlm_resume_bytes(int num_systems);
 /* Enqueue the integration on `hip_stream` (a hipStream_t, NULL = default stream) of the
  * current device.  Asynchronous: returns after the launch. */
 int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream);
+
+/* Radau-IIA fallback (replaces radau_kernel.cu:20-140 / radau_step_dense.cuh, re-derived as
+ * the standard RADAU5 scheme -- see csrc/hlm_radau_kernel.h): every system of `job` whose
+ * d_stiff entry is 1 is re-integrated from (t0, y0) with the implicit 3-stage method; its
+ * y_final and dense rows are overwritten, d_n_attempt is incremented by the implicit attempts,
+ * d_n_accept replaced.  d_stiff stays 1 on success and becomes 2 if the attempt cap ends the run
+ * (final row zero).  Enqueue on the same stream after hlm_rk45_integrate_device(job).  The job
+ * must be a plain one-launch job (no d_resume / t_stop / query window / forcing chunk). */
+int hlm_radau_fallback_device(const hlm_device_job* job, void* hip_stream);
 
 /* Kernel timing helper for bench.py: runs the job `iters` times on `hip_stream`,
  * bracketing EACH launch with HIP events on that stream; ms[i] receives the elapsed

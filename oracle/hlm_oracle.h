@@ -85,6 +85,20 @@ typedef struct {
 /* The whole integration, rk45_kernel.cu:17-176.  Returns 0, or -1 on bad arguments. */
 int hlm_oracle_rk45_run(const hlm_oracle_job* job);
 
+/* Radau-IIA fallback: every system whose stiff[] entry equals
+ * HLM_ORACLE_STIFF is re-integrated from (t0, y0) with the implicit 3-stage Radau IIA method
+ * (order 5) and its y_final / dense rows / n_attempt are overwritten; stiff[] stays 1 on
+ * success (as rk45_api.hpp:189-247 leaves d_stiff) and becomes HLM_ORACLE_CAPPED if the
+ * attempt cap is hit.  The reference's radau_step_dense.cuh cannot be restated as written
+ * (inconsistent dense interpolant, ad-hoc error weights, wrong forcing indexing, results never
+ * copied back -- SURVEY A.3), so this is the standard RADAU5 formulation of Hairer & Wanner
+ * re-derived on the reference's skeleton (radau_kernel.cu:20-140): finite-difference Jacobian
+ * as approx_jacobian (radau_step_dense.cuh:13-31), <= 10 simplified-Newton iterations on the
+ * 15x15 system (pivoted LU), the RADAU5 error estimator and collocation dense output, the same
+ * forcing hold / query / controller conventions as the RK45 loop.  Parity for this row is
+ * NOT pinned by any reference artifact; it is validated against SciPy's Radau. */
+int hlm_oracle_radau_run(const hlm_oracle_job* job);
+
 /* rk45_api.hpp:255-267: [sys][comp][q] -> [sys][q][comp]. */
 void hlm_oracle_reorder_dense(const double* raw, double* out, int ns, int nq);
 

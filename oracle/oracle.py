@@ -61,6 +61,8 @@ def lib():
         _lib = C.CDLL(_SO)
         _lib.hlm_oracle_rk45_run.argtypes = [C.POINTER(_Job)]
         _lib.hlm_oracle_rk45_run.restype = C.c_int
+        _lib.hlm_oracle_radau_run.argtypes = [C.POINTER(_Job)]
+        _lib.hlm_oracle_radau_run.restype = C.c_int
         _lib.hlm_oracle_reorder_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib.hlm_oracle_reorder_dense.restype = None
         _lib.hlm_oracle_rhs.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -118,8 +120,11 @@ def rk45_dense(y, k, h, theta):
 
 def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT=None,
         params=DEFAULT_PARAMS, forc_stub_f64=None, fixed_step=0.0, attempt_cap=0, nthreads=0,
-        reorder=True):
-    """Integrate; returns dict(y_final[ns,5], dense[ns,nq,5] (or raw [ns,5,nq]), stiff, n_attempt, n_accept)."""
+        reorder=True, radau=False, radau_only=False):
+    """Integrate; returns dict(y_final[ns,5], dense[ns,nq,5] (or raw [ns,5,nq]), stiff, n_attempt, n_accept).
+
+    radau=True re-integrates the systems RK45 flagged with the Radau-IIA fallback
+    (hlm_oracle_radau_run); radau_only=True skips RK45 and sends every system through it."""
     y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, NEQ)
     ns = y0.shape[0]
     q = np.zeros(0) if query is None else np.ascontiguousarray(query, dtype=np.float64)
@@ -152,9 +157,17 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     treach = np.zeros(ns)
     j.y_final, j.dense_raw, j.stiff, j.n_attempt, j.n_accept = _p(yf), _p(raw), _p(stiff), _p(na), _p(nacc)
     j.t_reached = _p(treach)
-    rc = lib().hlm_oracle_rk45_run(C.byref(j))
+    if radau_only:
+        stiff[:] = 1
+        yf[:] = 0.0
+        rc = 0
+    else:
+        rc = lib().hlm_oracle_rk45_run(C.byref(j))
     if rc != 0:
         raise ValueError("hlm_oracle_rk45_run: bad arguments")
+    if radau or radau_only:
+        if lib().hlm_oracle_radau_run(C.byref(j)) != 0:
+            raise ValueError("hlm_oracle_radau_run: bad arguments")
     dense = raw
     if nq and reorder:
         dense = np.empty((ns, nq, NEQ))

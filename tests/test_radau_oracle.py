@@ -1,0 +1,96 @@
+"""The Radau-IIA fallback's CPU restatement (oracle/hlm_oracle_radau.c) against independent
+solutions: SciPy's Radau at tight tolerance, the matrix exponential of the linear DummyModel,
+and a piecewise SciPy integration over the forcing samples.  No reference artifact exists for
+this row (the reference never copies its Radau results back) -- parity for it is
+"validated against SciPy", not pinned.  CPU only.
+
+Errors are in units of the solver tolerance: |d| / (1e-9 + 1e-6 |y|)."""
+import numpy as np
+from scipy.integrate import solve_ivp
+from scipy.linalg import expm
+
+from tiger_hlm_gpu_amd import synth
+
+
+def _scaled(a, b):
+    return np.abs(a - b) / (1e-9 + 1e-6 * np.abs(b))
+
+
+def test_radau_dummy_linear_system_vs_matrix_exponential(oracle):
+    """DummyModel is y' = A y + b: the exact flow is known."""
+    A = np.array([[-0.5, 0, 0, 0, 0], [0.5, -0.9, 0, 0, 0], [0, 0.3, 0, 0, 0], [0, 0.6, 0, -0.4, 0], [0, 0, 0, 0.4, 0]])
+    b = np.array([1.0, 0.8, -0.2, -0.3, -0.1])
+    y0 = synth.dummy_y0(0, 6)
+    # the model really is that affine map
+    for y in y0:
+        assert np.allclose(oracle.rhs(oracle.UID_DUMMY, y), A @ y + b, rtol=0, atol=1e-15)
+    q = synth.dummy_query_times(5.0, 50)
+    r = oracle.run(oracle.UID_DUMMY, y0, 0.0, 5.0, query=q, radau_only=True)
+    assert (r["stiff"] == 1).all()  # success leaves the RK45 flag in place
+
+    def exact(y, t):  # augmented system [[A, b], [0, 0]]
+        M = np.zeros((6, 6))
+        M[:5, :5], M[:5, 5] = A, b
+        return (expm(M * t) @ np.append(y, 1.0))[:5]
+
+    for s in range(6):
+        assert _scaled(r["y_final"][s], exact(y0[s], 5.0)).max() <= 1.0
+        for k in (0, 17, 49):
+            assert _scaled(r["dense"][s, k], exact(y0[s], q[k])).max() <= 1.0
+    assert r["n_attempt"].max() <= 40  # a smooth linear problem: a couple of dozen implicit steps
+
+
+def test_radau_model204_constant_forcing_vs_scipy_radau(oracle):
+    ns = 4
+    sp = synth.model204_params(0, ns, seed=3)
+    y0 = synth.model204_y0(ns, wet_surface=True)
+    stub = np.array([np.float32(2e-5), np.float32(8.0)], dtype=np.float64)
+    q = synth.minute_queries(0, 2880.0, 60.0)
+    r = oracle.run(oracle.UID_204, y0, 0.0, 2880.0, query=q, sp=sp, forc_stub_f64=stub, radau_only=True)
+    k = oracle.run(oracle.UID_204, y0, 0.0, 2880.0, sp=sp, forc_stub_f64=stub)
+    assert (r["n_attempt"] < k["n_attempt"] / 3).all()  # mildly stiff: far fewer implicit steps
+    for s in range(ns):
+        f = lambda t, y: oracle.rhs(oracle.UID_204, y, sp[s:s + 1], stub.astype(np.float32), t)
+        ref = solve_ivp(f, (0, 2880.0), y0[s], method="Radau", rtol=1e-11, atol=1e-14, t_eval=q[q > 0])
+        assert _scaled(r["y_final"][s], ref.y[:, -1]).max() <= 1.0
+        assert _scaled(r["dense"][s][q > 0], ref.y.T).max() <= 1.0
+        assert np.all(r["dense"][s][q <= 0] == 0.0)  # queries at t0 are never produced
+
+
+def test_radau_rescues_flagged_systems_and_matches_piecewise_scipy(oracle):
+    """Cold cells flag ~1/6 of these hillslopes in RK45; the fallback finishes all of them, leaves
+    the others untouched, and agrees with an independent integration that restarts SciPy's Radau
+    at every forcing sample (which is what clipping the implicit steps to the sample boundaries
+    amounts to)."""
+    ns, days = 128, 5
+    sp = synth.model204_params(0, ns, seed=3)
+    y0 = synth.model204_y0(ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, ncell=16, seed=5, tmin=-5.0)
+    cells = synth.cell_of_system(0, ns, ncell=16, run_len=16)
+    forc = synth.expand_per_stream(pr, t2m, cells)
+    tf = days * 1440.0
+    k = oracle.run(oracle.UID_204, y0, 0.0, tf, sp=sp, forc=forc, forc_dt_h=dt, forc_nT=nT)
+    r = oracle.run(oracle.UID_204, y0, 0.0, tf, sp=sp, forc=forc, forc_dt_h=dt, forc_nT=nT, radau=True)
+    fl = k["stiff"] == 1
+    assert 0 < fl.sum() < ns
+    assert np.array_equal(r["stiff"], k["stiff"])
+    assert np.all(k["y_final"][fl] == 0.0) and np.all(np.isfinite(r["y_final"]))
+    assert np.all(np.abs(r["y_final"][fl]).sum(axis=1) > 0)
+    assert np.array_equal(r["y_final"][~fl], k["y_final"][~fl])
+    assert np.array_equal(r["n_attempt"][~fl], k["n_attempt"][~fl])
+    assert (r["t_reached"][fl] == tf).all()
+    s = int(np.nonzero(fl)[0][0])
+    y = y0[s].copy()
+    for hr in range(24 * days):
+        F = np.array([pr[hr, cells[s]], t2m[hr // 24, cells[s]]], dtype=np.float32)
+        sol = solve_ivp(lambda t, yy: oracle.rhs(oracle.UID_204, yy, sp[s:s + 1], F, t), (hr * 60.0, (hr + 1) * 60.0), y,
+                        method="Radau", rtol=1e-9, atol=1e-12)
+        y = sol.y[:, -1]
+    assert _scaled(r["y_final"][s], y).max() <= 5.0  # global error over 120 restarts, kink at Hu included
+
+
+def test_radau_attempt_cap_flags_and_zeroes(oracle):
+    y0 = synth.dummy_y0(0, 3)
+    r = oracle.run(oracle.UID_DUMMY, y0, 0.0, 5.0, query=synth.dummy_query_times(5.0, 20), radau_only=True, attempt_cap=4)
+    assert (r["stiff"] == 2).all() and np.all(r["y_final"] == 0.0) and (r["n_attempt"] == 4).all()
+    assert np.all(r["dense"][:, -1] == 0.0)  # rows past the cap stay zero

@@ -79,6 +79,7 @@ SIGNATURES = {
     "hlm_set_fixed_step": (C.c_int, [C.c_int, C.c_double]),
     "hlm_set_attempt_cap": (C.c_int, [C.c_uint32]),
     "hlm_set_math_mode": (C.c_int, [C.c_int]),
+    "hlm_set_radau_fallback": (C.c_int, [C.c_int]),
     "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
                                    C.c_int64, C.c_void_p]),
     "hlm_set_forcings_host": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
@@ -91,6 +92,7 @@ SIGNATURES = {
     "hlm_run_rk45": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int,
                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hlm_rk45_integrate_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p]),
+    "hlm_radau_fallback_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p]),
     "hlm_resume_bytes": (C.c_size_t, [C.c_int]),
     "hlm_rk45_integrate_streamed": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p,
                                               C.POINTER(StreamStats)]),

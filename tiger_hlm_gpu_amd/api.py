@@ -105,6 +105,11 @@ def set_math_mode(mode):
     check(lib().hlm_set_math_mode(int(mode)))
 
 
+def set_radau_fallback(enabled):
+    """Host API (run_rk45 / launch_rk45_kernel): re-integrate flagged systems with Radau IIA."""
+    check(lib().hlm_set_radau_fallback(int(bool(enabled))))
+
+
 class Forcings:
     """Device-resident forcing block + metadata (the reference's c_forc_dt / c_forc_nT /
     d_forc_data / nForc symbols, forcing_data.cu:5-10)."""
@@ -227,6 +232,13 @@ def integrate_device(job, stream=None):
     """Enqueue on ``stream`` (a torch.cuda.Stream, a raw hipStream_t int, or None)."""
     s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
     check(lib().hlm_rk45_integrate_device(C.byref(job), s))
+
+
+def radau_fallback_device(job, stream=None):
+    """Enqueue the Radau-IIA pass over the systems the RK45 pass of ``job`` flagged
+    (hlm_radau_fallback_device); same stream, after integrate_device(job)."""
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    check(lib().hlm_radau_fallback_device(C.byref(job), s))
 
 
 def integrate_streamed(job, window_queries, h_dense, stream=None):

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "hlm_hip.h"
+#include "hlm_radau_kernel.h"
 #include "hlm_rk45_kernel.h"
 
 namespace {
@@ -50,6 +51,7 @@ ModelState g_models[2] = {
 uint32_t g_cap = 1u << 24;
 int g_stream_path = 0;  // hlm_set_stream_path(): 0 copy engine (default), 1 transposing transfer kernel
 int g_math = HLM_MATH_STRICT;
+int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
 
 struct ForcingState {
     const float* d_forc = nullptr;
@@ -229,6 +231,33 @@ int launch(const hlm_device_job* j, hipStream_t stream)
     const unsigned blocks = (unsigned)((j->num_systems + hlm::WAVE - 1) / hlm::WAVE);
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a);
     HLM_HIP_TRY(hipGetLastError());
+    return HLM_SUCCESS;
+}
+
+// Radau-IIA pass over the systems the RK45 launch of the same job flagged (stream-ordered after it)
+int launch_radau(const hlm_device_job* j, hipStream_t stream)
+{
+    if (job_is_resumable(j))
+        return fail(HLM_ERR_INVALID_ARGUMENT,
+                    "the Radau fallback restarts from t0: it needs the whole query range and forcing series "
+                    "in one launch (no d_resume / t_stop / query window / forcing chunk)");
+    if (j->fixed_step > 0.0) return HLM_SUCCESS;  // fixed-step runs never flag
+    const int ns = j->num_systems;
+    int* scratch = nullptr;  // [0] = count, [1 .. ns] = compacted indices of flagged systems
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + 1), stream));
+    HLM_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(int), stream));
+    hipLaunchKernelGGL(hlm::radau_collect_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream,
+                       j->d_stiff, ns, scratch + 1, scratch);
+    const hlm::Rk45Args a = make_args(j);
+    const unsigned blocks = (unsigned)((ns + hlm::WAVE - 1) / hlm::WAVE);  // blocks past the count exit at once
+    if (j->uid == HLM_UID_204)
+        hipLaunchKernelGGL(hlm::radau_fallback_kernel<hlm::Model204Dev>, dim3(blocks), dim3(hlm::WAVE), 0, stream, a,
+                           scratch + 1, scratch);
+    else
+        hipLaunchKernelGGL(hlm::radau_fallback_kernel<hlm::DummyDev>, dim3(blocks), dim3(hlm::WAVE), 0, stream, a,
+                           scratch + 1, scratch);
+    HLM_HIP_TRY(hipGetLastError());
+    HLM_HIP_TRY(hipFreeAsync(scratch, stream));
     return HLM_SUCCESS;
 }
 
@@ -428,6 +457,22 @@ int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream)
     if (rc != HLM_SUCCESS) return rc;
     if (job->num_systems == 0) return HLM_SUCCESS;
     return launch(job, static_cast<hipStream_t>(hip_stream));
+}
+
+int hlm_radau_fallback_device(const hlm_device_job* job, void* hip_stream)
+{
+    int rc = validate_job(job);
+    if (rc != HLM_SUCCESS) return rc;
+    if (job->num_systems == 0) return HLM_SUCCESS;
+    return launch_radau(job, static_cast<hipStream_t>(hip_stream));
+}
+
+int hlm_set_radau_fallback(int enabled)
+{
+    if (enabled != 0 && enabled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "radau fallback flag %d (want 0 or 1)", enabled);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_radau = enabled;
+    return HLM_SUCCESS;
 }
 
 size_t hlm_resume_bytes(int ns)
@@ -789,16 +834,23 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     j.d_n_accept = b->d_n_accept;
     const float* host_tables[HLM_MAX_FORCINGS];
     double chunk_minutes = 0.0;
+    int radau = 0;
     {
         std::lock_guard<std::mutex> lk(g_mu);
         const ForcingState& F = g_forc;
         chunk_minutes = F.chunk_minutes;
         std::memcpy(host_tables, F.h_tables, sizeof(host_tables));
+        radau = g_radau;
     }
-    if (chunk_minutes > 0.0 && uid != HLM_UID_DUMMY)
+    const bool streamed = chunk_minutes > 0.0 && uid != HLM_UID_DUMMY;
+    if (streamed && radau)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "the Radau fallback needs the forcing series resident in HBM "
+                                              "(hlm_set_forcings), not streamed in time chunks");
+    if (streamed)
         rc = hlm_rk45_integrate_forcing_streamed(&j, host_tables, chunk_minutes, nullptr, nullptr);
     else
         rc = hlm_rk45_integrate_device(&j, nullptr);
+    if (rc == HLM_SUCCESS && radau) rc = hlm_radau_fallback_device(&j, nullptr);  // rk45_api.hpp:189-247
     if (rc != HLM_SUCCESS) return rc;
     HLM_HIP_TRY(hipDeviceSynchronize());  // rk45_api.hpp:150
     return HLM_SUCCESS;

@@ -1,0 +1,393 @@
+// Radau-IIA fallback for the systems the RK45 loop flags as stiff.
+//
+// The reference launches a second kernel over the flagged systems (rk45_api.hpp:189-247 ->
+// radau_kernel.cu:20-140 -> radau_step_dense.cuh) but never copies its results back, and the
+// step it implements is not a consistent method (the dense interpolant, the error
+// weights and the forcing indexing are wrong).  What is built here is the standard RADAU5
+// formulation (Hairer & Wanner, Solving ODEs II, IV.8) on the reference's skeleton -- restart
+// from (t0, y0), finite-difference Jacobian as approx_jacobian (radau_step_dense.cuh:13-31),
+// <= 10 simplified-Newton iterations (:87), steps clipped to the forcing sample boundaries (an
+// implicit step would otherwise hold one sample across many).  The CPU restatement the parity
+// tests check it against lives under oracle/; both are validated against SciPy's Radau.
+//
+// Mapping to CDNA4: one lane per flagged system (the flag list is compacted first so a wave
+// holds 64 stiff systems).  The 15x15 Newton system is block-diagonalised with the RADAU5
+// transformation (T, TI) into one real and one complex 5x5 system per attempt, small enough to
+// factor and solve entirely in VGPRs: partial pivoting is done with per-lane selects (a row swap
+// is 5 conditional exchanges), so no lane-indexed memory is needed at all.  A first version
+// that kept the full 15x15 matrix in LDS ([element][lane], 140 KB per wave) took 100-160 us per
+// attempt (LDS latency with one wave per CU, then instruction-cache misses once unrolled); this
+// one is ~1/5 of the arithmetic and fits the instruction cache.  Cold path: a fraction of a
+// percent of the systems in a production run.
+#pragma once
+
+#include "hlm_rk45_kernel.h"
+
+namespace hlm {
+namespace radau {
+
+constexpr int NS = 3;
+constexpr double SQRT6 = 2.449489742783178;
+// Lambda = TI A^-1 T = [[g,0,0],[0,a,b],[0,-b,a]] (Hairer & Wanner, Solving ODEs II, IV.8)
+constexpr double MU_REAL = 3.637834252744496;  // g
+constexpr double MU_CRE = 2.6810828736277523;  // a
+constexpr double MU_CIM = 3.050430199247411;   // b (the complex eigenvalue used is a - ib)
+constexpr double T[NS][NS] = {{0.09443876248897524, -0.1412552950209542, 0.03002919410514742},
+                              {0.2502131229653333, 0.20412935229379994, -0.3829421127572619},
+                              {1.0, 1.0, 0.0}};
+constexpr double TI[NS][NS] = {{4.178718591551904, 0.32768282076106237, 0.5233764454994495},
+                               {-4.178718591551904, -0.32768282076106237, 0.47662355450055044},
+                               {0.5028726349457868, -2.571926949855605, 0.5960392048282249}};
+constexpr double E[NS] = {(-13.0 - 7.0 * SQRT6) / 3.0, (-13.0 + 7.0 * SQRT6) / 3.0, -1.0 / 3.0};
+constexpr double PD[NS][3] = {
+    {13.0 / 3.0 + 7.0 * SQRT6 / 3.0, -23.0 / 3.0 - 22.0 * SQRT6 / 3.0, 10.0 / 3.0 + 5.0 * SQRT6},
+    {13.0 / 3.0 - 7.0 * SQRT6 / 3.0, -23.0 / 3.0 + 22.0 * SQRT6 / 3.0, 10.0 / 3.0 - 5.0 * SQRT6},
+    {1.0 / 3.0, -8.0 / 3.0, 10.0 / 3.0}};
+constexpr int NEWTON_MAXITER = 10;
+constexpr double NEWTON_TOL = 1e-3;
+constexpr double FD_EPS = 1e-8;
+
+__device__ __forceinline__ void cswap(bool sw, double& a, double& b)
+{
+    const double u = a, v = b;
+    a = sw ? v : u;
+    b = sw ? u : v;
+}
+
+// real 5x5 LU with partial pivoting, all indices compile-time (registers); inv = reciprocal pivots
+__device__ __forceinline__ bool lu_real(double (&a)[NEQ][NEQ], int (&piv)[NEQ], double (&inv)[NEQ])
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NEQ; ++k) {
+        int p = k;
+        double best = fabs(a[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            const double v = fabs(a[i][k]);
+            if (v > best) { best = v; p = i; }
+        }
+        piv[k] = p;
+        ok = ok && best > 1e-300;
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            const bool sw = p == i;
+#pragma unroll
+            for (int j = 0; j < NEQ; ++j) cswap(sw, a[k][j], a[i][j]);
+        }
+        inv[k] = 1.0 / a[k][k];
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            const double m = a[i][k] * inv[k];
+            a[i][k] = m;
+#pragma unroll
+            for (int j = k + 1; j < NEQ; ++j) a[i][j] -= m * a[k][j];
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ void solve_real(const double (&a)[NEQ][NEQ], const int (&piv)[NEQ],
+                                           const double (&inv)[NEQ], double (&b)[NEQ])
+{
+#pragma unroll
+    for (int k = 0; k < NEQ; ++k) {
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) cswap(piv[k] == i, b[k], b[i]);
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) b[i] -= a[i][k] * b[k];
+    }
+#pragma unroll
+    for (int i = NEQ - 1; i >= 0; --i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = i + 1; j < NEQ; ++j) s -= a[i][j] * b[j];
+        b[i] = s * inv[i];
+    }
+}
+
+// the same for a complex matrix held as (re, im); pivot on |re| + |im|
+__device__ __forceinline__ bool lu_cplx(double (&ar)[NEQ][NEQ], double (&ai)[NEQ][NEQ], int (&piv)[NEQ],
+                                        double (&ir)[NEQ], double (&ii)[NEQ])
+{
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NEQ; ++k) {
+        int p = k;
+        double best = fabs(ar[k][k]) + fabs(ai[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            const double v = fabs(ar[i][k]) + fabs(ai[i][k]);
+            if (v > best) { best = v; p = i; }
+        }
+        piv[k] = p;
+        ok = ok && best > 1e-300;
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            const bool sw = p == i;
+#pragma unroll
+            for (int j = 0; j < NEQ; ++j) {
+                cswap(sw, ar[k][j], ar[i][j]);
+                cswap(sw, ai[k][j], ai[i][j]);
+            }
+        }
+        const double d = 1.0 / (ar[k][k] * ar[k][k] + ai[k][k] * ai[k][k]);
+        ir[k] = ar[k][k] * d;
+        ii[k] = -ai[k][k] * d;
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            const double mr = ar[i][k] * ir[k] - ai[i][k] * ii[k];
+            const double mi = ar[i][k] * ii[k] + ai[i][k] * ir[k];
+            ar[i][k] = mr;
+            ai[i][k] = mi;
+#pragma unroll
+            for (int j = k + 1; j < NEQ; ++j) {
+                ar[i][j] -= mr * ar[k][j] - mi * ai[k][j];
+                ai[i][j] -= mr * ai[k][j] + mi * ar[k][j];
+            }
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ void solve_cplx(const double (&ar)[NEQ][NEQ], const double (&ai)[NEQ][NEQ],
+                                           const int (&piv)[NEQ], const double (&ir)[NEQ], const double (&ii)[NEQ],
+                                           double (&br)[NEQ], double (&bi)[NEQ])
+{
+#pragma unroll
+    for (int k = 0; k < NEQ; ++k) {
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            const bool sw = piv[k] == i;
+            cswap(sw, br[k], br[i]);
+            cswap(sw, bi[k], bi[i]);
+        }
+#pragma unroll
+        for (int i = k + 1; i < NEQ; ++i) {
+            br[i] -= ar[i][k] * br[k] - ai[i][k] * bi[k];
+            bi[i] -= ar[i][k] * bi[k] + ai[i][k] * br[k];
+        }
+    }
+#pragma unroll
+    for (int i = NEQ - 1; i >= 0; --i) {
+        double sr = br[i], si = bi[i];
+#pragma unroll
+        for (int j = i + 1; j < NEQ; ++j) {
+            sr -= ar[i][j] * br[j] - ai[i][j] * bi[j];
+            si -= ar[i][j] * bi[j] + ai[i][j] * br[j];
+        }
+        br[i] = sr * ir[i] - si * ii[i];
+        bi[i] = sr * ii[i] + si * ir[i];
+    }
+}
+
+}  // namespace radau
+
+// compacts the indices of the systems flagged HLM_SYS_STIFF into list[0 .. *count)
+__global__ void radau_collect_kernel(const int32_t* __restrict__ stiff, int ns, int* __restrict__ list,
+                                     int* __restrict__ count)
+{
+    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+    if (i < ns && stiff[i] == HLM_SYS_STIFF) list[atomicAdd(count, 1)] = i;
+}
+
+template <class Model>
+__global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args A, const int* __restrict__ list,
+                                                                 const int* __restrict__ count)
+{
+    using namespace radau;
+    constexpr int MATH = MATH_STRICT;
+    const int lane = (int)threadIdx.x;
+    const int slot = (int)(blockIdx.x * WAVE) + lane;
+    if (slot >= *count) return;
+    const int sys = list[slot];
+
+    const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
+    double y[NEQ];
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
+
+    const bool use_f0 = Model::NF > 0 && A.nforc > 0;
+    const bool use_f1 = Model::NF > 1 && A.nforc > 1;
+    size_t fcol = 0;
+    if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
+    double tb0 = -__builtin_inf(), tb1 = -__builtin_inf(), F0 = 0.0, F1 = 0.0;
+    typename Model::Forc FV = Model::prep_forcing(P, F0, F1);
+
+    const size_t q_stride = A.dense_tiled ? (size_t)WAVE * NEQ : (size_t)NEQ;
+    double* dense_row = nullptr;
+    if (A.nq > 0)
+        dense_row = A.dense_tiled ? A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride + (size_t)(sys % WAVE) * NEQ
+                                  : A.dense + (size_t)sys * (size_t)A.nq * NEQ;
+
+    double t = A.t0, h = A.h0;
+    const double tf = A.tf;
+    int next_q = 0;
+    uint32_t n_attempt = 0, n_accept = 0;
+    // queries at or before t0 are never produced: zero rows
+    while (next_q < A.nq && A.query[next_q] <= t) {
+#pragma unroll
+        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
+        ++next_q;
+    }
+
+    auto sample = [&](int j, double& tb) -> double {
+        // zero-order hold (rk45_kernel.cu:90-98); the index is nudged so that its interval
+        // really contains t (a step clipped to a boundary lands exactly on it)
+        unsigned long long idx = forcing_index(t, A.forc_dtmin[j], A.forc_nT[j]);
+        while (idx + 1ull < A.forc_nT[j] && (double)(idx + 1ull) * A.forc_dtmin[j] <= t) ++idx;
+        tb = (idx + 1ull < A.forc_nT[j]) ? (double)(idx + 1ull) * A.forc_dtmin[j] : __builtin_inf();
+        return (double)A.forc[A.forc_base[j] + (size_t)idx * (size_t)A.forc_ld + fcol];
+    };
+
+    bool capped = false;
+#pragma unroll 1
+    while (t < tf) {
+        if (n_attempt >= A.cap) { capped = true; break; }
+        if constexpr (Model::NF > 0) {
+            bool moved = false;
+            if (use_f0 && !(t < tb0)) { F0 = sample(0, tb0); moved = true; }
+            if (use_f1 && !(t < tb1)) { F1 = sample(1, tb1); moved = true; }
+            if (moved) FV = Model::prep_forcing(P, F0, F1);
+        }
+        const double t_b = fmin(use_f0 ? tb0 : __builtin_inf(), use_f1 ? tb1 : __builtin_inf());
+        const double h_ctl = h;
+        double t_end = t + h;
+        bool clipped = false;
+        if (t_end > tf) { t_end = tf; clipped = true; }
+        if (t_end > t_b) { t_end = t_b; clipped = true; }
+        if (clipped) h = t_end - t;
+        ++n_attempt;
+
+        // f0 and the finite-difference Jacobian
+        double f0[NEQ], Jm[NEQ][NEQ];
+        Model::template rhs<MATH>(P, FV, y, f0);
+#pragma unroll
+        for (int j = 0; j < NEQ; ++j) {
+            double yp[NEQ], f1[NEQ];
+            const double d = FD_EPS * fmax(1.0, fabs(y[j]));
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) yp[i] = y[i];
+            yp[j] += d;
+            Model::template rhs<MATH>(P, FV, yp, f1);
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) Jm[i][j] = (f1[i] - f0[i]) / d;
+        }
+        // LU of (g/h) I - J (Newton's real block and the error estimator) and of ((a - ib)/h) I - J
+        double Mr[NEQ][NEQ], Cr[NEQ][NEQ], Ci[NEQ][NEQ], inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
+        int piv_r[NEQ], piv_c[NEQ];
+        const double g_h = MU_REAL / h, a_h = MU_CRE / h, b_h = MU_CIM / h;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i)
+#pragma unroll
+            for (int j = 0; j < NEQ; ++j) {
+                Mr[i][j] = ((i == j) ? g_h : 0.0) - Jm[i][j];
+                Cr[i][j] = ((i == j) ? a_h : 0.0) - Jm[i][j];
+                Ci[i][j] = (i == j) ? -b_h : 0.0;
+            }
+        bool ok = lu_real(Mr, piv_r, inv_r);
+        ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci) && ok;
+
+        // simplified Newton on W = (TI (x) I) Z,  Z_i = Y_i - y
+        double Z[NS][NEQ], W[NS][NEQ];
+#pragma unroll
+        for (int s = 0; s < NS; ++s)
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) Z[s][i] = W[s][i] = 0.0;
+        bool converged = false;
+        double prev = __builtin_inf();
+#pragma unroll 1
+        for (int it = 0; ok && it < NEWTON_MAXITER; ++it) {
+            double Fs[NS][NEQ], d0[NEQ], d1[NEQ], d2[NEQ];
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                double Y[NEQ];
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) Y[i] = y[i] + Z[s][i];
+                Model::template rhs<MATH>(P, FV, Y, Fs[s]);
+            }
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) {
+                d0[i] = (TI[0][0] * Fs[0][i] + TI[0][1] * Fs[1][i] + TI[0][2] * Fs[2][i]) - g_h * W[0][i];
+                d1[i] = (TI[1][0] * Fs[0][i] + TI[1][1] * Fs[1][i] + TI[1][2] * Fs[2][i]) - (a_h * W[1][i] + b_h * W[2][i]);
+                d2[i] = (TI[2][0] * Fs[0][i] + TI[2][1] * Fs[1][i] + TI[2][2] * Fs[2][i]) - (a_h * W[2][i] - b_h * W[1][i]);
+            }
+            solve_real(Mr, piv_r, inv_r, d0);
+            solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, d1, d2);
+            double nrm = 0.0, chk = 0.0;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) {
+                chk += d0[i] + d1[i] + d2[i];
+                W[0][i] += d0[i];
+                W[1][i] += d1[i];
+                W[2][i] += d2[i];
+                const double sc = A.atol + A.rtol * fabs(y[i]);
+                const double r = fmax(fmax(fabs(d0[i]), fabs(d1[i])), fabs(d2[i])) / sc;
+                if (r > nrm) nrm = r;
+#pragma unroll
+                for (int s = 0; s < NS; ++s) Z[s][i] = T[s][0] * W[0][i] + T[s][1] * W[1][i] + T[s][2] * W[2][i];
+            }
+            if (!(chk - chk == 0.0)) break;          // a NaN / Inf increment
+            if (it > 0 && nrm > 2.0 * prev) break;   // diverging
+            prev = nrm;
+            if (nrm <= NEWTON_TOL) { converged = true; break; }
+        }
+        if (!converged) { h *= 0.5; continue; }
+
+        double y_new[NEQ], ev[NEQ];
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) {
+            y_new[i] = y[i] + Z[2][i];
+            ev[i] = f0[i] + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) / h;
+        }
+        solve_real(Mr, piv_r, inv_r, ev);
+        double err = 0.0;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) {
+            const double r = fabs(ev[i]) / (A.atol + A.rtol * fmax(fabs(y[i]), fabs(y_new[i])));
+            if (r > err) err = r;
+        }
+        if (!(err == err)) { h *= 0.5; continue; }  // NaN estimate: treat like a failed Newton
+        const double fac = A.safety * pow(1.0 / (err + 1e-16), 0.25);
+        if (err <= 1.0) {
+            while (next_q < A.nq) {
+                const double tq = A.query[next_q];
+                if (!(tq <= t_end)) break;
+                const double th = (tq - t) / h;
+                double* o = dense_row + (size_t)next_q * q_stride;
+#pragma unroll
+                for (int c = 0; c < NEQ; ++c) {
+                    double acc = y[c], thp = th;
+#pragma unroll
+                    for (int m = 0; m < 3; ++m) {
+                        acc += (PD[0][m] * Z[0][c] + PD[1][m] * Z[1][c] + PD[2][m] * Z[2][c]) * thp;
+                        thp *= th;
+                    }
+                    o[c] = acc;
+                }
+                ++next_q;
+            }
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) y[i] = y_new[i];
+            t = t_end;
+            ++n_accept;
+            h *= fmin(fmax(fac, A.min_scale), A.max_scale);
+            if (clipped && h < h_ctl) h = h_ctl;
+        } else {
+            h *= fmin(fmax(fmin(fac, 1.0), A.min_scale), A.max_scale);
+        }
+    }
+
+    if (A.n_attempt) A.n_attempt[sys] += n_attempt;
+    if (A.n_accept) A.n_accept[sys] = n_accept;
+    const bool failed = capped && t < tf;
+    if (failed) A.stiff[sys] = HLM_SYS_CAPPED;  // success leaves the RK45 flag in place (rk45_api.hpp:189-247 does)
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = failed ? 0.0 : y[i];
+    for (; next_q < A.nq; ++next_q) {  // rows never reached (later than tf, or after the cap): zero
+#pragma unroll
+        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
+    }
+}
+
+}  // namespace hlm

@@ -92,11 +92,12 @@ class ShardEngine:
         j.dense_tiled = int(self.dense_tiled and self.dense is not None)
         return j
 
-    def integrate(self, stream=None, t_stop=None, resume_in=False):
+    def integrate(self, stream=None, t_stop=None, resume_in=False, radau=False):
         """Enqueue one pass of the hot path on ``stream`` (default: torch's current stream).
         ``t_stop``: pause every hillslope once its t reaches it (state kept in the engine's
         resume buffer); ``resume_in``: continue from that buffer.  A sequence of such launches
-        gives the same bits as one uninterrupted pass."""
+        gives the same bits as one uninterrupted pass.  ``radau``: follow the pass with the
+        Radau-IIA fallback over the hillslopes it flagged as stiff."""
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         j = self.job()
         if t_stop is not None or resume_in:
@@ -104,6 +105,8 @@ class ShardEngine:
             if t_stop is not None:
                 j.use_t_stop, j.t_stop = 1, float(t_stop)
         api.integrate_device(j, s)
+        if radau:
+            api.radau_fallback_device(j, s)
 
     def _resume_buffer(self):
         if getattr(self, "_resume", None) is None:

@@ -55,6 +55,7 @@ struct Options {
     int nc_compression = 0;
     int device = 0;
     int gpus = 1;               // shard the hillslopes over this many GPUs (one host thread each)
+    bool radau = false;         // re-integrate flagged systems with the Radau-IIA fallback
     bool oversubscribe = false; // allow --gpus > visible devices (shards share GPUs round-robin)
     bool quiet = false;
 };
@@ -65,7 +66,7 @@ struct Options {
     std::fprintf(stderr,
                  "usage: rk45_solver [--model dummy|204] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
-                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast]\n"
+                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
                  "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L]\n"
                  "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
@@ -95,6 +96,7 @@ Options parse(int argc, char** argv)
         else if (a == "--rtol") o.rtol = std::atof(val());
         else if (a == "--atol") o.atol = std::atof(val());
         else if (a == "--math") o.math = val();
+        else if (a == "--radau") o.radau = true;
         else if (a == "--out-final") o.out_final = val();
         else if (a == "--out-dense") o.out_dense = val();
         else if (a == "--forcing-nc") o.forcing_nc.push_back(val());
@@ -230,6 +232,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
     }
     rk45_api::setModelParameters<Model>(hp);
     rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
+    rk45_api::set_radau_fallback(o.radau);
 
     // ---- initial state and query grid --------------------------------------------------------------------
     std::vector<double> h_y0((size_t)ns * N_EQ);
@@ -339,16 +342,17 @@ int run(const Options& o, hlm_io::CsvStyle style)
     }
 
     unsigned long long attempts = 0;
-    int flagged = 0;
+    int flagged = 0, unsolved = 0;  // flagged by RK45; of those, not finished by the Radau fallback either
     for (int s = 0; s < ns; ++s) {
         attempts += n_attempt[s];
         flagged += stiff[s] != 0;
+        unsolved += o.radau ? stiff[s] == HLM_SYS_CAPPED : stiff[s] != 0;
     }
     if (!o.quiet)
         std::printf("{\"model\": %d, \"num_systems\": %d, \"num_queries\": %zu, \"t0\": %g, \"tf\": %g, "
-                    "\"initial_step\": %g, \"gpus\": %d, \"attempted_steps\": %llu, \"flagged\": %d, "
+                    "\"initial_step\": %g, \"gpus\": %d, \"attempted_steps\": %llu, \"flagged\": %d, \"radau\": %s, \"unsolved\": %d, "
                     "\"run_rk45_seconds\": %.6f, \"final\": \"%s\", \"dense\": \"%s\"}\n",
-                    (int)Model::UID, ns, nq, t0, tf, hp.initialStep, G, attempts, flagged, secs,
+                    (int)Model::UID, ns, nq, t0, tf, hp.initialStep, G, attempts, flagged, o.radau ? "true" : "false", unsolved, secs,
                     o.out_final.c_str(), o.out_dense.c_str());
     return 0;
 }
