@@ -196,6 +196,7 @@ struct Model204Dev {
     // w == 0 and dydt[2] == d2 - 0 (model_204.hpp:103-105), so the Manning term can be
     // left out bit-exactly.  rhs_fast reports d2 != 0 (inflow: the next stage state is wet).
     static constexpr bool HAS_FASTPATH = true;
+    static constexpr int FAST_ZERO_COMP = 2;  // rhs_fast: dydt[2] == 0 unless it reports "broke"
     static __device__ __forceinline__ bool fastpath_ok(const double (&y)[HLM_NEQ]) { return y[2] == 0.0; }
 
     template <int MATH>
@@ -279,6 +280,7 @@ struct DummyDev {
     struct Local {};
     struct Forc {};
     static constexpr bool HAS_FASTPATH = false;
+    static constexpr int FAST_ZERO_COMP = 0;
     static __device__ __forceinline__ bool fastpath_ok(const double (&)[HLM_NEQ]) { return false; }
     template <int MATH>
     static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[HLM_NEQ],

@@ -114,58 +114,71 @@ __device__ __forceinline__ size_t forcing_row(unsigned long long idx, unsigned l
 
 // ---- the 7 stages of one attempt ---------------------------------------------------------
 // k0 = rhs(y) unless still valid, k1..k6, and yt = the stage-6 state (= the 5th-order solution).
-// FAST selects Model::rhs_fast (exact while Model::fastpath_ok holds); the return value tells
-// whether any stage left that regime (always false for the general path).
-template <class Model, int MATH, bool FAST>
+// PATH selects the RHS variant: PATH_GENERAL = Model::rhs; PATH_DRY = Model::rhs_fast, exact while
+// Model::fastpath_ok holds -- and on that path component Model::FAST_ZERO_COMP has zero slope in
+// every stage, so it is left out of the stage arithmetic (y + sum h*a*0 == y, bit for bit).  The
+// return value tells whether any stage left the regime (always false for PATH_GENERAL).
+constexpr int PATH_GENERAL = 0, PATH_DRY = 1;
+
+template <class Model, int MATH, int PATH>
 __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const typename Model::Forc& FV,
                                           const double (&y)[NEQ], double h, bool have_k0, double (&k0)[NEQ],
                                           double (&k1)[NEQ], double (&k2)[NEQ], double (&k3)[NEQ], double (&k4)[NEQ],
                                           double (&k5)[NEQ], double (&k6)[NEQ], double (&yt)[NEQ])
 {
     using namespace dp;
+    // components that move: all five, or all but the one the fast path pins
+    constexpr int Z = PATH == PATH_DRY ? Model::FAST_ZERO_COMP : NEQ;
+    constexpr int NC = PATH == PATH_DRY ? NEQ - 1 : NEQ;
+    constexpr int COMP[NEQ] = {0 < Z ? 0 : 1, 1 < Z ? 1 : 2, 2 < Z ? 2 : 3, 3 < Z ? 3 : 4, 4};
     bool broke = false;
     auto f = [&](const double (&state)[NEQ], double (&slope)[NEQ]) {
-        if constexpr (FAST) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
+        if constexpr (PATH == PATH_DRY) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
         else Model::template rhs<MATH>(P, FV, state, slope);
     };
+    if constexpr (PATH == PATH_DRY) yt[Z] = y[Z];
     if (!have_k0) f(y, k0);  // no FSAL in the reference: see the have_k0 comment in the kernel
     {
         const double a10 = h * A10;
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a10, k0[i]);
+        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a10, k0[i]); }
         f(yt, k1);
     }
     {
         const double a20 = h * A20, a21 = h * A21;
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a20, k0[i], a21, k1[i]);
+        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a20, k0[i], a21, k1[i]); }
         f(yt, k2);
     }
     {
         const double a30 = h * A30, a31 = h * A31, a32 = h * A32;
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]);
+        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]); }
         f(yt, k3);
     }
     {
         const double a40 = h * A40, a41 = h * A41, a42 = h * A42, a43 = h * A43;
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i) yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]);
+        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]); }
         f(yt, k4);
     }
     {
         const double a50 = h * A50, a51 = h * A51, a52 = h * A52, a53 = h * A53, a54 = h * A54;
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i)
+        for (int c = 0; c < NC; ++c) {
+            const int i = COMP[c];
             yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
+        }
         f(yt, k5);
     }
     {
         // stage 6 state: row 6 of a is b (rk45_step_dense.cuh:66-68)
         const double hb0 = h * B0, hb2 = h * B2, hb3 = h * B3, hb4 = h * B4, hb5 = h * B5;
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i)
+        for (int c = 0; c < NC; ++c) {
+            const int i = COMP[c];
             yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
+        }
         f(yt, k6);
     }
     return broke;
@@ -365,12 +378,12 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         bool general = true;
         if constexpr (Model::HAS_FASTPATH) {
             if (__builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
-                const bool broke = rk_stages<Model, MATH, true>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+                const bool broke = rk_stages<Model, MATH, PATH_DRY>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
                 have_k0 = true;  // k0 of a qualifying state is exact
                 general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
             }
         }
-        if (general) rk_stages<Model, MATH, false>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+        if (general) rk_stages<Model, MATH, PATH_GENERAL>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
         have_k0 = true;  // stays valid through a reject / slope-jump retry
         // 5th-order solution (rk45_step_dense.cuh:111-117).  b[6] = 0, so it is the same
         // chain of operations as the stage-6 state: identical bits, reuse it.
