@@ -601,7 +601,8 @@ def test_fast_math_elementary_functions(gpu):
         return out.cpu().numpy()
 
     ld = np.longdouble
-    x = np.concatenate([10.0 ** rng.uniform(-280, 300, 200000), 10.0 ** rng.uniform(-12, 1, 200000), [1.0, 8.0, 1e-9, 0.125]])
+    x = np.concatenate([10.0 ** rng.uniform(-307, 307, 200000), 10.0 ** rng.uniform(-12, 1, 200000),
+                        2.0 ** rng.uniform(0, 3, 200000), [1.0, 8.0, 1e-9, 0.125, 2.3e-308, 1.7e308]])
     # the reference computes pow(x, 2.0/3.0) with the DOUBLE constant 0.6666666666666666 =
     # 2/3 - 3.7e-17, i.e. x^(2/3) * x^(-3.7e-17); FAST computes the mathematical x^(2/3)
     ref23 = (x.astype(ld) ** (ld(2) / ld(3))).astype(np.float64)
@@ -615,7 +616,7 @@ def test_fast_math_elementary_functions(gpu):
     es = np.abs(strict - ref_pow) / ref_pow
     assert es.max() < 2e-13 and es[(x > 1e-12) & (x < 10)].max() < 6e-15
     assert np.all(np.isnan(run(0, np.array([-1.0, -1e-300, -np.inf]))))  # like pow(): NaN for x < 0
-    assert np.all(run(0, np.array([1e-300, 5e-324])) == 0.0)       # below 1e-290: flushed (value < 1e-193)
+    assert np.all(run(0, np.array([0.0, 2e-308, 1e-310, 5e-324])) == 0.0)  # zero and subnormals: 0 (true value < 1e-205)
     xe = np.concatenate([10.0 ** rng.uniform(-16, 30, 400000), [1e-16, 1.0, 32.0]])
     ref5 = (xe.astype(ld) ** (ld(-1) / ld(5))).astype(np.float64)
     assert np.max(np.abs(run(1, xe) - ref5) / ref5) < 8e-16

@@ -86,33 +86,39 @@ __device__ __forceinline__ bool divisor_in_safe_range(double d)
 
 // x^(-1/n) refinement shared by the FAST roots: given a seed w ~ x^(-1/n) with residual
 // e = 1 - x w^n, the exact root is w (1-e)^(-1/n) = w (1 + c1 e + c2 e^2 + c3 e^3 + ...).
-// With an f32 exp2/log2 seed |e| < ~1e-4, so three series terms leave ~e^4 < 1e-16.
 
 // x^(2/3) for the Manning term (model_204.hpp:103).
 // STRICT: OCML pow (<1 ulp; the reference makes the same call through libdevice).
-// FAST:   x * x^(-1/3); the seed is taken on the frexp-split argument so the whole double
-//         range works (a draining surface store decays algebraically to 1e-11 and below).
-//         Result within a few ulp of pow().  x < 0 must stay NaN like pow() so that
-//         fmin(1.0, NaN) == 1.0 keeps the reference's behaviour for a negative surface
-//         store (SURVEY A.1 note 6); x == 0 never reaches here (caller's exact shortcut).
+// FAST:   x * x^(-1/3) with x^(-1/3) from an integer seed and two series refinements, all in
+//         ordinary VALU instructions -- no f32 log/exp (quarter rate), no frexp/ldexp/convert
+//         shuffling:
+//           seed   hi32(w0) = 0x553ee979 - hi32(x)/3          |1 - x w0^3| <= 0.103 (all normal x)
+//           step 1 w1 = w0 (1 + e0/3 + 2/9 e0^2 + 14/81 e0^3 + 35/243 e0^4)   |e1| <= 4.4e-6
+//           step 2 r  = x w1 (1 + e1/3 + 2/9 e1^2 + 14/81 e1^3)               remainder ~1e-22
+//         Result within 2 ulp of cbrt(x)^2 (hlm_selftest_math, tests).  x < 0 must stay NaN like
+//         pow() so that fmin(1.0, NaN) == 1.0 keeps the reference's behaviour for a negative
+//         surface store (SURVEY A.1 note 6); subnormal x (seed out of range) returns 0, 1e-205
+//         away from the true value; x == 0 gives 0 through the same select.
 template <int MATH>
 __device__ __forceinline__ double pow_two_thirds(double x)
 {
     if constexpr (MATH == MATH_STRICT) {
         return pow(x, 2.0 / 3.0);
     } else {
-        const int ex = __builtin_amdgcn_frexp_exp(x);          // x = m * 2^ex, m in [0.5, 1)
-        const float m = (float)__builtin_amdgcn_frexp_mant(x);
-        const float lg = (float)ex + __builtin_amdgcn_logf(m);  // log2(x)
-        const float v = lg * (-1.0f / 3.0f);
-        const float vi = __builtin_rintf(v);
-        const double w = __builtin_amdgcn_ldexp((double)__builtin_amdgcn_exp2f(v - vi), (int)vi);
-        const double e = __builtin_fma(-x, w * w * w, 1.0);
-        double p = __builtin_fma(e, 14.0 / 81.0, 2.0 / 9.0);
-        p = __builtin_fma(e, p, 1.0 / 3.0);
-        const double xw = x * w;
-        double r = __builtin_fma(xw * e, p, xw);
-        r = x < 1e-290 ? 0.0 : r;  // w^3 would overflow below ~2^-1023; x^(2/3) < 1e-193 there
+        const unsigned hi = (unsigned)__double2hiint(x);
+        const unsigned whi = 0x553ee979u - __umulhi(hi, 0x55555556u);
+        const double w0 = __hiloint2double((int)whi, 0);
+        const double e0 = __builtin_fma(-x, w0 * w0 * w0, 1.0);
+        double p = __builtin_fma(e0, 35.0 / 243.0, 14.0 / 81.0);
+        p = __builtin_fma(e0, p, 2.0 / 9.0);
+        p = __builtin_fma(e0, p, 1.0 / 3.0);
+        const double w1 = __builtin_fma(w0 * e0, p, w0);
+        const double e1 = __builtin_fma(-x, w1 * w1 * w1, 1.0);
+        double q = __builtin_fma(e1, 14.0 / 81.0, 2.0 / 9.0);
+        q = __builtin_fma(e1, q, 1.0 / 3.0);
+        const double xw = x * w1;
+        double r = __builtin_fma(xw * e1, q, xw);
+        r = x < 2.3e-308 ? 0.0 : r;
         return x < 0.0 ? __builtin_nan("") : r;
     }
 }
