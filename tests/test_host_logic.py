@@ -168,3 +168,25 @@ def test_shard_bounds_is_the_reference_split(total, world):
         assert s == start and c == base + (1 if (r + 1) <= rem else 0)
         start += c
     assert start == total
+
+
+def test_config_yaml_reader_cpp(tmp_path):
+    """include/hlm/config_yaml.hpp: YAML-subset parser + data/config.yaml schema mapping
+    (tests/cpp/test_config_yaml.cpp), and the driver's handling of a bad config (no GPU needed:
+    the configuration is read before anything touches the device)."""
+    import subprocess
+    exe = str(tmp_path / "test_config_yaml")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-Wall", "-Wextra", "-I" + os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cpp", "test_config_yaml.cpp"), "-o", exe], check=True)
+    out = subprocess.run([exe, os.path.join(ROOT, "tools", "examples", "run_204.yaml")], capture_output=True, text=True)
+    assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
+    drv = os.path.join(ROOT, "tools", "rk45_solver")
+    if not os.path.exists(drv):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True)
+    bad = tmp_path / "bad.yaml"
+    bad.write_text("model:\n  uid: 204\nsolver:\n  method: Radau\n")
+    r = subprocess.run([drv, "--config", str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "solver.method 'Radau' is not supported" in r.stderr
+    bad.write_text("model:\n  uid: 7\n")
+    r = subprocess.run([drv, "--config", str(bad)], capture_output=True, text=True)
+    assert r.returncode == 1 and "model.uid 7 is not registered" in r.stderr

@@ -972,3 +972,131 @@ def test_cpp_driver_radau_flag(gpu, golden, tmp_path):
     assert infos["on"]["radau"] is True and infos["on"]["unsolved"] == 0
     assert np.all(np.abs(on[flagged]).sum(axis=1) > 0)
     assert np.array_equal(on[~flagged], off[~flagged])
+
+
+def test_cpp_driver_yaml_config_equals_flags(gpu, golden, tmp_path):
+    """rk45_solver --config run.yaml (the reference's data/config.yaml schema) gives the same files
+    as the equivalent command-line flags; initial.mode hot, output.states and flag overrides."""
+    import json
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = _driver_exe()
+    cfg = os.path.join(ROOT, "tools", "examples", "run_204.yaml")
+
+    def run(args, tag):
+        f, d = str(tmp_path / f"final_{tag}.csv"), str(tmp_path / f"dense_{tag}.csv")
+        out = subprocess.run([exe] + args + ["--out-final", f, "--out-dense", d], check=True, timeout=300,
+                             capture_output=True, text=True).stdout
+        return json.loads(out.strip().splitlines()[-1]), open(f).read(), open(d).read()
+
+    a_info, a_final, a_dense = run(["--config", cfg], "cfg")
+    b_info, b_final, b_dense = run(["--model", "204", "--params", golden["small_test_csv"], "--tf", "2880",
+                                    "--query-stride", "60", "--scipy-h0"], "flags")
+    assert a_info["num_systems"] == 10 and a_info["tf"] == 2880 and a_info["num_queries"] == 49
+    assert a_info["initial_step"] == b_info["initial_step"] == 1e-6
+    assert a_final == b_final and a_dense == b_dense
+    # a flag after --config overrides the file
+    c_info, _, _ = run(["--config", cfg, "--tf", "1440"], "override")
+    assert c_info["tf"] == 1440 and c_info["num_queries"] == 25
+    # hot start + tolerances + explicit first step from a config written here
+    y0 = np.tile([0.02, 2.5, 0.0, 4.0, 0.3], (10, 1)) * (1.0 + 0.01 * np.arange(10)[:, None])
+    init = tmp_path / "init.csv"
+    np.savetxt(init, y0, delimiter=",", header="h_snow,h_stat,h_surf,h_grav,h_aq", comments="")
+    hot = tmp_path / "hot.yaml"
+    hot.write_text(f"""model:
+  uid: 204
+time:
+  start: "2021-06-01T00:00:00"
+  end: "2021-06-01T12:00:00"
+initial:
+  mode: hot
+  file: {init}
+local_params:
+  file: {golden["small_test_csv"]}
+output:
+  print_interval: 30m
+  states: [1, 4]
+solver:
+  tolerances:
+    rtol: 1e-7
+    atol: 1e-10
+  initial_step: 0.001
+""")
+    h_info, h_final, _ = run(["--config", str(hot)], "hot")
+    g_info, g_final, _ = run(["--model", "204", "--params", golden["small_test_csv"], "--tf", "720", "--query-stride", "30",
+                              "--rtol", "1e-7", "--atol", "1e-10", "--initial-step", "0.001", "--init-file", str(init)], "hotflags")
+    assert h_info["tf"] == 720 and h_info["num_queries"] == 25 and h_info["initial_step"] == 1e-3
+    assert h_final == g_final and h_final != a_final
+    assert h_info["attempted_steps"] == g_info["attempted_steps"]
+
+
+def test_cpp_driver_yaml_folder_nc_forcings_and_state_subset(gpu, golden, tmp_path):
+    """config forcings.type folder_nc (<path>/<var>.nc, roles precipitation = 1 h, temperature = 24 h,
+    lookup CSV) and output.states: the NetCDF outputs hold the selected states of the run that the
+    equivalent --forcing-nc flags produce, with the model's state indices as the variable coordinate."""
+    import os
+    import subprocess
+    hdf5 = os.environ.get("HDF5_DIR", "/opt/conda")
+    if not os.path.exists(os.path.join(hdf5, "include", "hdf5_hl.h")):
+        pytest.skip("no HDF5 in this image")
+    from conftest import ROOT
+    H = gpu
+    exe = _driver_exe()
+    helper = str(tmp_path / "nchelper")
+    libs = [os.path.join(hdf5, "lib", n) for n in ("libhdf5_hl.so", "libhdf5.so")]
+    subprocess.run(["g++", "-O1", "-std=c++17", "-DHLM_WITH_HDF5", "-I" + os.path.join(ROOT, "include"), "-isystem",
+                    os.path.join(hdf5, "include"), os.path.join(ROOT, "tests", "cpp", "test_netcdf4_io.cpp"), "-o", helper] + libs,
+                   check=True)
+    env = dict(os.environ, LD_PRELOAD=":".join(libs))
+    folder = tmp_path / "forcings"
+    folder.mkdir()
+    subprocess.run([helper, "write_forcing", str(folder / "PRCP.nc"), "PRCP", "24", "4", "5", "0"], check=True, env=env)
+    subprocess.run([helper, "write_forcing", str(folder / "Tair.nc"), "Tair", "1", "4", "5", "1"], check=True, env=env)
+    sp = H.load_spatial_params(golden["small_test_csv"])
+    lookup = tmp_path / "lut.csv"
+    lookup.write_text("stream,lat_index,lon_index\n" + "".join(f"{int(sp['stream'][i])},{i % 4},{(2 * i + 1) % 5}\n" for i in range(10)))
+    cfg = tmp_path / "run.yaml"
+    cfg.write_text(f"""model:
+  uid: 204
+time:
+  start: "2021-06-01T00:00:00"
+  end: "2021-06-02T00:00:00"
+local_params:
+  file: {golden["small_test_csv"]}
+forcings:
+  type: folder_nc
+  path: {folder}
+  lookup: lut.csv          # relative to this file
+  vars:
+    precipitation: PRCP
+    temperature: Tair
+output:
+  print_interval: 2h
+  states:
+    - 1
+    - 4
+solver:
+  initial_step: 0.01
+""")
+    h5dump = os.path.join(hdf5, "bin", "h5dump")
+
+    def outputs(args, tag, k):
+        f, d = str(tmp_path / f"final_{tag}.csv"), str(tmp_path / f"dense_{tag}.csv")
+        subprocess.run([exe] + args + ["--out-final", f, "--out-dense", d, "--out-format", "nc", "--quiet"], check=True, timeout=300)
+        res = []
+        for path, shape in ((f[:-4] + ".nc", (10, k)), (d[:-4] + ".nc", (10, 13, k))):
+            b = str(tmp_path / "o.bin")
+            subprocess.run([h5dump, "-d", "/outputs", "-b", "LE", "-o", b, path], check=True, capture_output=True)
+            res.append(np.fromfile(b, dtype="<f8").reshape(shape))
+        b = str(tmp_path / "v.bin")
+        subprocess.run([h5dump, "-d", "/variable", "-b", "LE", "-o", b, d[:-4] + ".nc"], check=True, capture_output=True)
+        return res[0], res[1], np.fromfile(b, dtype="<i4")
+
+    sub_f, sub_d, sub_v = outputs(["--config", str(cfg)], "cfg", 2)
+    all_f, all_d, all_v = outputs(["--model", "204", "--params", golden["small_test_csv"], "--tf", "1440", "--query-stride", "120",
+                                   "--initial-step", "0.01", "--forcing-nc", f"{folder}/PRCP.nc:PRCP:1",
+                                   "--forcing-nc", f"{folder}/Tair.nc:Tair:24", "--lookup", str(lookup)], "flags", 5)
+    assert list(sub_v) == [1, 4] and list(all_v) == [0, 1, 2, 3, 4]
+    assert np.array_equal(sub_f, all_f[:, [1, 4]]) and np.array_equal(sub_d, all_d[:, :, [1, 4]])
+    assert np.all(all_f[:, 1] > 0) and all_f[:, 0].std() > 0

@@ -6,6 +6,8 @@
 // tolerances :621; query grid :653-656) is a command-line option with the reference's value
 // as default.  All GPU work goes through include/hlm/*.hpp -> libhlm_hip.so (C ABI).
 //
+//   rk45_solver --config run.yaml       the reference's data/config.yaml schema (include/hlm/config_yaml.hpp);
+//                                       flags given as well override the file
 //   rk45_solver                         DummyModel, 64 systems, t 0..5, nq 10000  (README.md:88-93)
 //   rk45_solver --model 204 --params data/small_test.csv --tf 2880 --query-stride 60
 #include <array>
@@ -14,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <fstream>
 #include <iostream>
 #include <algorithm>
 #include <string>
@@ -21,6 +24,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "hlm/config_yaml.hpp"
 #include "hlm/forcing.hpp"
 #ifdef HLM_WITH_HDF5
 #include "hlm/netcdf4_io.hpp"  // NetCDFLoader, write_final_netcdf, write_dense_netcdf
@@ -43,6 +47,10 @@ struct Options {
     double query_stride = -1.0;
     double rain = 0.001, temp = 1.0;  // the reference's stub forcings, model_204.hpp:76-77
     double initial_step = -1.0, rtol = 1e-6, atol = 1e-9;
+    double safety = -1.0, min_scale = -1.0, max_scale = -1.0;  // < 0: the model's Parameters defaults
+    std::string config;           // YAML run configuration (schema of the reference's data/config.yaml)
+    std::string init_file;        // "hot" start: CSV, one row of N_EQ states per hillslope (parameter-file order)
+    std::vector<int> states;      // subset of states written to the NetCDF outputs (empty = all)
     bool scipy_h0 = false;
     std::string math = "strict";
     std::string out_final = "final.csv", out_dense = "dense.csv";
@@ -64,7 +72,7 @@ struct Options {
 {
     if (msg) std::fprintf(stderr, "rk45_solver: %s\n", msg);
     std::fprintf(stderr,
-                 "usage: rk45_solver [--model dummy|204] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
+                 "usage: rk45_solver [--config run.yaml] [--init-file states.csv] [--model dummy|204] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
@@ -73,16 +81,49 @@ struct Options {
     std::exit(msg ? 2 : 0);
 }
 
+// data/config.yaml schema -> Options (what the reference hard-codes in main.cpp)
+void apply_config(Options& o, const std::string& path)
+{
+    const size_t slash = path.rfind('/');
+    const hlm_config::RunConfig c = hlm_config::from_yaml(hlm_config::load_yaml_file(path), slash == std::string::npos ? std::string() : path.substr(0, slash));
+    if (c.model_uid == 0) o.model = "dummy";
+    else if (c.model_uid == 204) o.model = "204";
+    else throw std::runtime_error("config: model.uid " + std::to_string(c.model_uid) + " is not registered (0 = DummyModel, 204)");
+    if (c.has_time) { o.t0 = 0.0; o.tf = c.tf_minutes; }  // t counts minutes from time.start (main.cpp:610-611)
+    if (!c.params_file.empty()) o.params = c.params_file;
+    if (c.initial_mode == "hot") o.init_file = c.initial_file;
+    if (c.print_interval_min > 0) o.query_stride = c.print_interval_min;
+    o.states = c.states;
+    o.rtol = c.rtol; o.atol = c.atol; o.safety = c.safety; o.min_scale = c.min_scale; o.max_scale = c.max_scale;
+    if (c.auto_initial_step) o.scipy_h0 = true;  // "null -> auto-scaled": the driver's SciPy-style guess (main.cpp:615-631)
+    else o.initial_step = c.initial_step;
+    if (c.forcing_type == "folder_nc") {
+        // one file per variable, <path>/<variable>.nc; sample spacing by role as main.cpp:513-514 (pr 1 h, t2m 24 h)
+        for (const auto& rv : c.forcing_vars) {
+            double dt_h;
+            if (rv.first == "precipitation") dt_h = 1.0;
+            else if (rv.first == "temperature") dt_h = 24.0;
+            else throw std::runtime_error("config: forcings.vars." + rv.first + ": unknown role (precipitation, temperature)");
+            o.forcing_nc.push_back(c.forcing_path + "/" + rv.second + ".nc:" + rv.second + ":" + std::to_string(dt_h));
+        }
+        o.lookup = c.forcing_lookup;
+    }
+}
+
 Options parse(int argc, char** argv)
 {
     Options o;
+    for (int i = 1; i + 1 < argc; ++i)
+        if (std::string(argv[i]) == "--config") { o.config = argv[i + 1]; apply_config(o, o.config); }
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> const char* {
             if (i + 1 >= argc) usage(("missing value for " + a).c_str());
             return argv[++i];
         };
-        if (a == "--model") o.model = val();
+        if (a == "--config") (void)val();
+        else if (a == "--init-file") o.init_file = val();
+        else if (a == "--model") o.model = val();
         else if (a == "--params") o.params = val();
         else if (a == "--num-systems") o.num_systems = std::atoi(val());
         else if (a == "--t0") o.t0 = std::atof(val());
@@ -223,6 +264,9 @@ int run(const Options& o, hlm_io::CsvStyle style)
     typename Model::Parameters hp;
     hp.rtol = o.rtol;
     hp.atol = o.atol;
+    if (o.safety > 0) hp.safety = o.safety;
+    if (o.min_scale > 0) hp.minScale = o.min_scale;
+    if (o.max_scale > 0) hp.maxScale = o.max_scale;
     if (o.initial_step > 0) hp.initialStep = o.initial_step;
     else if (o.scipy_h0) {
         std::vector<float> f0;  // forcing samples of system 0 at t0
@@ -238,6 +282,37 @@ int run(const Options& o, hlm_io::CsvStyle style)
     std::vector<double> h_y0((size_t)ns * N_EQ);
     for (int s = 0; s < ns; ++s)
         for (int i = 0; i < N_EQ; ++i) h_y0[(size_t)s * N_EQ + i] = streams[s].y0[i];
+    if (!o.init_file.empty()) {
+        // hot start (config initial.mode: hot).  The reference names a ".uini" file but has no reader for
+        // it; here: CSV, N_EQ numbers per row, one row per hillslope in parameter-file order, an
+        // optional header line.
+        std::ifstream in(o.init_file);
+        if (!in) throw std::runtime_error("cannot open initial-state file " + o.init_file);
+        std::string line;
+        int row = 0, lineno = 0;
+        while (std::getline(in, line)) {
+            ++lineno;
+            if (line.empty() || line[0] == '#') continue;
+            std::vector<double> vals;
+            const char* p = line.c_str();
+            bool numeric = true;
+            while (*p) {
+                char* end = nullptr;
+                const double v = std::strtod(p, &end);
+                if (end == p) { numeric = false; break; }
+                vals.push_back(v);
+                p = end;
+                while (*p == ',' || *p == ' ' || *p == '\t' || *p == '\r') ++p;
+            }
+            if (!numeric && row == 0 && vals.empty()) continue;  // header
+            if (!numeric || (int)vals.size() != N_EQ)
+                throw std::runtime_error(o.init_file + ":" + std::to_string(lineno) + ": expected " + std::to_string(N_EQ) + " numbers");
+            if (row >= ns) throw std::runtime_error(o.init_file + ": more rows than hillslopes (" + std::to_string(ns) + ")");
+            for (int i = 0; i < N_EQ; ++i) h_y0[(size_t)row * N_EQ + i] = vals[i];
+            ++row;
+        }
+        if (row != ns) throw std::runtime_error(o.init_file + ": " + std::to_string(row) + " rows for " + std::to_string(ns) + " hillslopes");
+    }
     std::vector<double> h_query_times;
     if (o.query_stride > 0 || (is204 && o.nq < 0)) {
         const double stride = o.query_stride > 0 ? o.query_stride : 60.0;
@@ -333,9 +408,24 @@ int run(const Options& o, hlm_io::CsvStyle style)
         for (int s = 0; s < ns; ++s) linkid_vals[s] = s;
         for (int v = 0; v < N_EQ; ++v) state_vals[v] = v;
         auto nc_name = [](std::string p) { const size_t d = p.rfind('.'); return (d == std::string::npos ? p : p.substr(0, d)) + ".nc"; };
-        write_final_netcdf(nc_name(o.out_final), h_y_final.data(), linkid_vals.data(), state_vals.data(), ns, N_EQ, o.nc_compression);
-        write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
-                           (int)nq, ns, N_EQ, o.nc_compression);
+        if (o.states.empty()) {
+            write_final_netcdf(nc_name(o.out_final), h_y_final.data(), linkid_vals.data(), state_vals.data(), ns, N_EQ, o.nc_compression);
+            write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
+                               (int)nq, ns, N_EQ, o.nc_compression);
+        } else {
+            // config output.states: only these columns; the "variable" coordinate keeps their model indices
+            const int K = (int)o.states.size();
+            for (int v : o.states)
+                if (v < 0 || v >= N_EQ) throw std::runtime_error("output.states: " + std::to_string(v) + " is not a state of this model");
+            std::vector<double> yf((size_t)ns * K), dn((size_t)ns * nq * K);
+            for (size_t r = 0; r < (size_t)ns; ++r)
+                for (int k = 0; k < K; ++k) yf[r * K + k] = h_y_final[r * N_EQ + o.states[k]];
+            for (size_t r = 0; r < (size_t)ns * nq; ++r)
+                for (int k = 0; k < K; ++k) dn[r * K + k] = h_dense[r * N_EQ + o.states[k]];
+            write_final_netcdf(nc_name(o.out_final), yf.data(), linkid_vals.data(), o.states.data(), ns, K, o.nc_compression);
+            write_dense_netcdf(nc_name(o.out_dense), dn.data(), h_query_times.data(), linkid_vals.data(), o.states.data(), (int)nq, ns, K,
+                               o.nc_compression);
+        }
 #else
         usage("--out-format nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
 #endif
@@ -361,8 +451,8 @@ int run(const Options& o, hlm_io::CsvStyle style)
 
 int main(int argc, char** argv)
 {
-    const Options o = parse(argc, argv);
     try {
+        const Options o = parse(argc, argv);
         if (o.model == "204") return run<Model204>(o, hlm_io::CsvStyle::Model204);
         if (o.model == "dummy") return run<DummyModel>(o, hlm_io::CsvStyle::Dummy);
         usage("--model must be dummy or 204");
