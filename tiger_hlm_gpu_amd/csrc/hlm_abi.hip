@@ -245,7 +245,10 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     const int ns = j->num_systems;
     int* scratch = nullptr;  // [0] = count, [1 .. ns] = compacted indices of flagged systems
     HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + 1), stream));
-    HLM_HIP_TRY(hipMemsetAsync(scratch, 0, sizeof(int), stream));
+    if (hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int), stream); e != hipSuccess) {
+        (void)hipFreeAsync(scratch, stream);
+        return fail(HLM_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
     hipLaunchKernelGGL(hlm::radau_collect_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream,
                        j->d_stiff, ns, scratch + 1, scratch);
     const hlm::Rk45Args a = make_args(j);
@@ -256,8 +259,9 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     else
         hipLaunchKernelGGL(hlm::radau_fallback_kernel<hlm::DummyDev>, dim3(blocks), dim3(hlm::WAVE), 0, stream, a,
                            scratch + 1, scratch);
-    HLM_HIP_TRY(hipGetLastError());
-    HLM_HIP_TRY(hipFreeAsync(scratch, stream));
+    const hipError_t launched = hipGetLastError();
+    HLM_HIP_TRY(hipFreeAsync(scratch, stream));  // stream-ordered: after the kernels above
+    HLM_HIP_TRY(launched);
     return HLM_SUCCESS;
 }
 

@@ -140,6 +140,7 @@ struct Model204Dev {
         // correctly rounded reciprocals RN(1/d) that strict_div() needs for its exact 3-FMA form.
         double inv_Hu, manning, inv_alpha3, inv_alpha4, inv_A_h;
         bool div_ok;  // STRICT: all four divisors are within [1e-100, 1e100]
+        bool nonneg;  // infil >= 0 && perco >= 0: min(0, infil) == min(0, perco) == 0 (no-rain path)
     };
 
     // Values that depend only on the held forcing samples; recomputed when a sample
@@ -168,6 +169,7 @@ struct Model204Dev {
         P.temp_thr = S.temp_thr;
         P.inv_n = 1.0 / S.n_mann;
         P.sqrt_slope = sqrt(S.slope);
+        P.nonneg = S.infil >= 0.0 && S.perco >= 0.0;
         if constexpr (MATH == MATH_FAST) {
             P.inv_Hu = 1.0 / S.Hu;
             P.manning = P.inv_n * P.sqrt_slope * (S.L / S.A_h * 60.0);
@@ -204,6 +206,42 @@ struct Model204Dev {
     static constexpr bool HAS_FASTPATH = true;
     static constexpr int FAST_ZERO_COMP = 2;  // rhs_fast: dydt[2] == 0 unless it reports "broke"
     static __device__ __forceinline__ bool fastpath_ok(const double (&y)[HLM_NEQ]) { return y[2] == 0.0; }
+
+    // No-rain path: a dry surface store AND no rainfall in the held sample.  Then x1 is the
+    // snowmelt alone and, while the static store stays below Hu, x2 = max(0, x1 + h_stat - Hu) = 0
+    // takes x3, x4, d2, d3 with it (model_204.hpp:94-113, given infil, perco >= 0): the cascade
+    // below the static store is not evaluated at all.  rhs_norain reports x1 + h_stat > Hu.  The
+    // expressions are the general ones with rain, x2, x3, x4, d2, d3 replaced by the literal 0.0
+    // they evaluate to: same values.
+    static constexpr bool HAS_NORAINPATH = true;
+    static __device__ __forceinline__ bool norainpath_ok(const Local& P, const Forc& F, const double (&y)[HLM_NEQ])
+    {
+        return y[2] == 0.0 && F.rain == 0.0 && P.nonneg;
+    }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_norain(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
+                                                      double (&dydt)[HLM_NEQ])
+    {
+        const double h_snow = y[0], h_stat = y[1], h_grav = y[3], h_aq = y[4];
+        const double x1 =
+            __longlong_as_double(__double_as_longlong(vmin(h_snow, F.melt_pot)) & (long long)F.warm_mask);
+        dydt[0] = 0.0 - x1;
+        const bool wet = x1 + h_stat - P.Hu > 0.0;
+        const double Emax = vmin(F.e_pot, h_stat);
+        dydt[2] = 0.0;
+        if constexpr (MATH == MATH_FAST) {
+            const double s = h_stat * P.inv_Hu;
+            dydt[1] = x1 - s * Emax;
+            dydt[3] = 0.0 - h_grav * P.inv_alpha3;
+            dydt[4] = 0.0 - h_aq * P.inv_alpha4;
+        } else {
+            const double s = strict_div(h_stat, P.Hu, P.inv_Hu, P.div_ok);
+            dydt[1] = x1 - s * Emax;
+            dydt[3] = 0.0 - (P.alpha3 >= 1.0 ? strict_div(h_grav, P.alpha3, P.inv_alpha3, P.div_ok) : 0.0);
+            dydt[4] = 0.0 - (P.alpha4 >= 1.0 ? strict_div(h_aq, P.alpha4, P.inv_alpha4, P.div_ok) : 0.0);
+        }
+        return wet;
+    }
 
     template <int MATH>
     static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
@@ -286,7 +324,12 @@ struct DummyDev {
     struct Local {};
     struct Forc {};
     static constexpr bool HAS_FASTPATH = false;
+    static constexpr bool HAS_NORAINPATH = false;
     static constexpr int FAST_ZERO_COMP = 0;
+    static __device__ __forceinline__ bool norainpath_ok(const Local&, const Forc&, const double (&)[HLM_NEQ]) { return false; }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_norain(const Local&, const Forc&, const double (&)[HLM_NEQ],
+                                                      double (&)[HLM_NEQ]) { return true; }
     static __device__ __forceinline__ bool fastpath_ok(const double (&)[HLM_NEQ]) { return false; }
     template <int MATH>
     static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[HLM_NEQ],

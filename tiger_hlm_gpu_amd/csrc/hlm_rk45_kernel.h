@@ -15,8 +15,17 @@
 
 namespace hlm {
 
+// Waves per SIMD the register allocator is asked to make room for.  2 (<= 256 VGPRs) fits every
+// variant without spills.  The FAST kernel without dense output needs 182 VGPRs; capping it at 168
+// for a third wave spills 14 of them (60 B/lane of scratch, touched outside the stage arithmetic)
+// and is 6 % faster (176 -> 165 ms on the C3 pass): the extra wave fills issue slots the other two
+// leave while they wait on each other's VALU results.  The dense and STRICT variants need 230-256
+// VGPRs and would spill into the loop (measured earlier: 276 ms vs 206 ms), so they stay at 2.
 #ifndef HLM_MIN_WAVES_PER_SIMD
-#define HLM_MIN_WAVES_PER_SIMD 2  // <= 256 VGPRs; the loop is VALU-issue-bound, see DESIGN.md
+#define HLM_MIN_WAVES_PER_SIMD 2
+#endif
+#ifndef HLM_MIN_WAVES_PER_SIMD_LEAN
+#define HLM_MIN_WAVES_PER_SIMD_LEAN 3
 #endif
 
 constexpr int NEQ = HLM_NEQ;
@@ -118,7 +127,8 @@ __device__ __forceinline__ size_t forcing_row(unsigned long long idx, unsigned l
 // Model::fastpath_ok holds -- and on that path component Model::FAST_ZERO_COMP has zero slope in
 // every stage, so it is left out of the stage arithmetic (y + sum h*a*0 == y, bit for bit).  The
 // return value tells whether any stage left the regime (always false for PATH_GENERAL).
-constexpr int PATH_GENERAL = 0, PATH_DRY = 1;
+// PATH_NORAIN = Model::rhs_norain: the dry path's regime with no rainfall in the held sample.
+constexpr int PATH_GENERAL = 0, PATH_DRY = 1, PATH_NORAIN = 2;
 
 template <class Model, int MATH, int PATH>
 __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const typename Model::Forc& FV,
@@ -128,15 +138,16 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
 {
     using namespace dp;
     // components that move: all five, or all but the one the fast path pins
-    constexpr int Z = PATH == PATH_DRY ? Model::FAST_ZERO_COMP : NEQ;
-    constexpr int NC = PATH == PATH_DRY ? NEQ - 1 : NEQ;
+    constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : NEQ;
+    constexpr int NC = PATH != PATH_GENERAL ? NEQ - 1 : NEQ;
     constexpr int COMP[NEQ] = {0 < Z ? 0 : 1, 1 < Z ? 1 : 2, 2 < Z ? 2 : 3, 3 < Z ? 3 : 4, 4};
     bool broke = false;
     auto f = [&](const double (&state)[NEQ], double (&slope)[NEQ]) {
-        if constexpr (PATH == PATH_DRY) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
+        if constexpr (PATH == PATH_NORAIN) broke |= Model::template rhs_norain<MATH>(P, FV, state, slope);
+        else if constexpr (PATH == PATH_DRY) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
         else Model::template rhs<MATH>(P, FV, state, slope);
     };
-    if constexpr (PATH == PATH_DRY) yt[Z] = y[Z];
+    if constexpr (PATH != PATH_GENERAL) yt[Z] = y[Z];
     if (!have_k0) f(y, k0);  // no FSAL in the reference: see the have_k0 comment in the kernel
     {
         const double a10 = h * A10;
@@ -184,6 +195,69 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     return broke;
 }
 
+// ---- one attempt: the stages plus the two norms the step control needs ------------------------
+// err  = scaled infinity-norm of the embedded error estimate (rk45_step_dense.cuh:123-142; "ratio >
+//        max" comparisons ignore NaN components exactly like the reference);
+// jump = |k0 - k1|_inf for the slope-jump detector (rk45_kernel.cu:132-136, event_detector.cuh:46-53).
+// They are computed inside the path-specific code so that a pinned component (zero slope in every
+// stage: error term 0, tolerance atol, slope difference 0) drops out at compile time, and so that
+// only y_new, k0 and k6 -- not all seven slope vectors -- have to meet in the same registers where
+// the paths join.
+template <class Model, int MATH, int PATH, bool FIXED>
+__device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const typename Model::Forc& FV,
+                                           const Rk45Args& A, const double (&y)[NEQ], double h, bool have_k0,
+                                           double (&k0)[NEQ], double (&k1)[NEQ], double (&k2)[NEQ], double (&k3)[NEQ],
+                                           double (&k4)[NEQ], double (&k5)[NEQ], double (&k6)[NEQ], double (&yt)[NEQ],
+                                           double& err, double& jump)
+{
+    using namespace dp;
+    const bool broke = rk_stages<Model, MATH, PATH>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+    if constexpr (!FIXED) {
+        constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : -1;  // pinned component, if any
+        const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5, he6 = h * E6;
+        // yt is the 5th-order solution: b[6] = 0 makes it the same chain of operations as the
+        // stage-6 state (rk45_step_dense.cuh:111-117)
+        if constexpr (MATH == MATH_FAST) {
+            // max_i |e_i| / tol_i with ONE reciprocal: max_i(|e_i| * prod_{j != i} tol_j) / prod_j tol_j
+            // (tol_i in [atol, ~rtol*|y|]: the 5-fold products stay far from the double range)
+            static_assert(NEQ == 5, "the product tree below is written for 5 components");
+            double e[NEQ], tl[NEQ];
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) {
+                if (i == Z) {
+                    e[i] = 0.0;
+                    tl[i] = A.atol;  // fma(rtol, max(|0|, |0|), atol)
+                } else {
+                    e[i] = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                    tl[i] = __builtin_fma(A.rtol, vmax_abs(y[i], yt[i]), A.atol);
+                }
+            }
+            const double a = tl[0] * tl[1], b = tl[2] * tl[3];
+            const double ab = a * b, all = ab * tl[4], bt4 = b * tl[4], at4 = a * tl[4];
+            const double others[NEQ] = {tl[1] * bt4, tl[0] * bt4, tl[3] * at4, tl[2] * at4, ab};
+            double num = 0.0;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i)
+                if (i != Z) num = vmax_abs2(num, e[i] * others[i]);
+            err = num * fast_rcp(all);
+        } else {
+            err = 0.0;
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) {
+                if (i == Z) continue;  // 0 / atol
+                const double y_err = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                const double tol = __builtin_fma(A.rtol, vmax_abs(y[i], yt[i]), A.atol);
+                err = vmax_abs2(err, y_err / tol);  // "if (fabs(ratio) > max) max = fabs(ratio)"
+            }
+        }
+        jump = 0.0;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i)
+            if (i != Z) jump = vmax_abs2(jump, k0[i] - k1[i]);
+    }
+    return broke;
+}
+
 // ---- dense output ---------------------------------------------------------------------------
 // The host-facing dense layout is [sys][query][comp]: a lane's rows are contiguous in memory
 // (40 B per query) but the 64 lanes of a wave are nq*40 B apart, so a row store touches 64
@@ -204,7 +278,8 @@ constexpr int DENSE_QWIN = 256;
 // (one uninterrupted launch, all forcings resident) carries none of that state: keeping it
 // out of the default kernel is worth 3.5 % (199 -> 192 ms on the C3 pass).
 template <class Model, int MATH, bool DENSE, bool FIXED, bool RESUMABLE>
-__global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kernel(const Rk45Args A)
+__global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
+    rk45_multi_kernel(const Rk45Args A)
 {
     using namespace dp;
     // XCD-aware block -> hillslope-chunk map: workgroups are dealt round-robin over the
@@ -375,15 +450,24 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
         // during the step (inflow reached the surface store); if it did for any lane the
         // attempt is simply recomputed with the general RHS -- same bits either way.
         double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
+        [[maybe_unused]] double err = 0.0, jump = 0.0;
         bool general = true;
-        if constexpr (Model::HAS_FASTPATH) {
-            if (__builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
-                const bool broke = rk_stages<Model, MATH, PATH_DRY>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+        if constexpr (Model::HAS_NORAINPATH) {
+            // between storms (no rain in the held sample, dry surface): the cascade below the static store is idle
+            if (__builtin_amdgcn_ballot_w64(!Model::norainpath_ok(P, FV, y)) == 0ull) {
+                const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
                 have_k0 = true;  // k0 of a qualifying state is exact
                 general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
             }
         }
-        if (general) rk_stages<Model, MATH, PATH_GENERAL>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+        if constexpr (Model::HAS_FASTPATH) {
+            if (general && __builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
+                const bool broke = rk_attempt<Model, MATH, PATH_DRY, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                have_k0 = true;  // k0 of a qualifying state is exact
+                general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+            }
+        }
+        if (general) rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
         have_k0 = true;  // stays valid through a reject / slope-jump retry
         // 5th-order solution (rk45_step_dense.cuh:111-117).  b[6] = 0, so it is the same
         // chain of operations as the stage-6 state: identical bits, reuse it.
@@ -392,50 +476,13 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_multi_kerne
 
         [[maybe_unused]] double fac = 1.0;
         if constexpr (!FIXED) {
-            // scaled infinity-norm error (rk45_step_dense.cuh:123-142); "ratio > max"
-            // comparisons ignore NaN components exactly like the reference.
-            const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5,
-                         he6 = h * E6;
-            double err = 0.0;
-            if constexpr (MATH == MATH_FAST) {
-                // max_i |e_i| / tol_i with ONE reciprocal: max_i(|e_i| * prod_{j != i} tol_j) / prod_j tol_j
-                // (tol_i in [atol, ~rtol*|y|]: the 5-fold products stay far from the double range)
-                static_assert(NEQ == 5, "the product tree below is written for 5 components");
-                double e[NEQ], tl[NEQ];
-#pragma unroll
-                for (int i = 0; i < NEQ; ++i) {
-                    e[i] = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
-                    tl[i] = __builtin_fma(A.rtol, vmax_abs(y[i], yn[i]), A.atol);
-                }
-                const double a = tl[0] * tl[1], b = tl[2] * tl[3];
-                const double ab = a * b, all = ab * tl[4], bt4 = b * tl[4], at4 = a * tl[4];
-                double num = vmax_abs(e[0] * (tl[1] * bt4), e[1] * (tl[0] * bt4));
-                num = vmax_abs2(num, e[2] * (tl[3] * at4));
-                num = vmax_abs2(num, e[3] * (tl[2] * at4));
-                num = vmax_abs2(num, e[4] * ab);
-                err = num * fast_rcp(all);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NEQ; ++i) {
-                    const double y_err =
-                        lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
-                    const double tol = __builtin_fma(A.rtol, vmax_abs(y[i], yn[i]), A.atol);
-                    err = vmax_abs2(err, y_err / tol);  // "if (fabs(ratio) > max) max = fabs(ratio)"
-                }
-            }
             // step-size factor shared by the accept and the reject branch
             // (rk45_kernel.cu:151,156)
             fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);
 
             if (err <= 1.0) {
                 reject_count = 0;
-                // slope-jump detector (rk45_kernel.cu:132-136, event_detector.cuh:46-53)
-                double jump = 0.0;
-#pragma unroll
-                for (int i = 0; i < NEQ; ++i) {
-                    jump = vmax_abs2(jump, k0[i] - k1[i]);
-                }
-                if (jump > SLOPE_JUMP_THRESH) {
+                if (jump > SLOPE_JUMP_THRESH) {  // slope-jump detector (rk45_kernel.cu:132-136)
                     h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
                     continue;
                 }
