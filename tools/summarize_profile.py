@@ -41,7 +41,7 @@ out = {"kernel": kstat["Name"], "calls": int(kstat["Calls"]), "avg_duration_ms":
 counters = {}
 for sub in ("pmc_fetch", "pmc_write", "pmc_grbm"):
     for r in rows(sub):
-        if "rk45_multi_kernel" in r["Kernel_Name"]:
+        if r["Kernel_Name"] == kstat["Name"]:  # the dominant kernel only (bench.py also runs the dense section)
             counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             out.setdefault("vgpr_count", int(r["VGPR_Count"]))
             out.setdefault("accum_vgpr_count", int(r.get("Accum_VGPR_Count") or 0))
