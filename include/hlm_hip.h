@@ -261,8 +261,9 @@ int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void*
 
 /* Single device evaluations of Model::rhs (the reference's debugRHS kernel, main.cpp:219-246):
  * d_y [n][5], d_sp [n] SpatialParams, d_F [n][2] float forcing samples, d_out [n][5].
- * fast_path != 0 evaluates the model's fast-path RHS instead and writes its "precondition
- * broke" flag to d_broke[n] (nullable). */
+ * fast_path = 1 evaluates the model's dry-surface RHS instead, fast_path = 2 its no-rain RHS
+ * (each valid where its precondition holds); both write their "precondition broke" flag to
+ * d_broke[n] (nullable). */
 int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, const void* d_sp,
                      const float* d_F, double* d_out, int32_t* d_broke, int n, void* hip_stream);
 

@@ -802,6 +802,24 @@ def test_device_rhs_single_evaluations_vs_oracle(gpu, oracle, math_mode):
     g2, br = out2.cpu().numpy(), broke.cpu().numpy()
     assert np.array_equal(g2[dry], got[dry])
     assert np.array_equal(br[dry] != 0, got[dry, 2] != 0.0)  # "broke" <=> inflow reached the surface store
+    # the no-rain path (dry surface store, rain == 0, infil/perco >= 0) likewise; its flag says
+    # "snowmelt + static store exceed Hu" (then x2 > 0 and the cascade below is not idle)
+    F0 = F.copy()
+    F0[:, 0] = 0.0
+    F0d = torch.from_numpy(F0).cuda()
+    gen0 = torch.empty_like(out)
+    H._lib.check(L.hlm_selftest_rhs(H.UID_204, math_mode, 0, yd.data_ptr(), spd.data_ptr(), F0d.data_ptr(), gen0.data_ptr(), None, n, None))
+    out3 = torch.empty_like(out)
+    H._lib.check(L.hlm_selftest_rhs(H.UID_204, math_mode, 2, yd.data_ptr(), spd.data_ptr(), F0d.data_ptr(), out3.data_ptr(),
+                                    broke.data_ptr(), n, None))
+    torch.cuda.synchronize()
+    g0, g3, br3 = gen0.cpu().numpy(), out3.cpu().numpy(), broke.cpu().numpy() != 0
+    T = F0[:, 1].astype(np.float64)
+    melt = np.where(T >= sp["temp_thr"], np.minimum(y[:, 0], T * sp["melt_f"]), 0.0)
+    over = melt + y[:, 1] - sp["Hu"] > 0
+    assert np.array_equal(br3, over) and 100 < (dry & over).sum() and 500 < (dry & ~over).sum()
+    ok = dry & ~over
+    assert np.array_equal(g3[ok], g0[ok])  # bit-identical wherever the path is valid
     # DummyModel
     outd = torch.empty_like(out)
     H._lib.check(L.hlm_selftest_rhs(H.UID_DUMMY, 0, 0, yd.data_ptr(), None, Fd.data_ptr(), outd.data_ptr(), None, n, None))

@@ -607,8 +607,9 @@ __global__ void selftest_math_kernel(int which, const double* __restrict__ in, d
 
 // ---- single RHS evaluations (hlm_selftest_rhs): the reference's debugRHS kernel, main.cpp:219-246 ----
 // y: [n][5] states, sp: [n] SpatialParams, F: [n][2] forcing values (as the float samples the
-// gather would deliver), out: [n][5] = Model::rhs.  fast_path != 0 evaluates rhs_fast instead
-// (valid where Model::fastpath_ok(y) holds) and stores its "left the regime" flag in broke[n].
+// gather would deliver), out: [n][5] = Model::rhs.  fast_path = 1 evaluates rhs_fast instead
+// (valid where Model::fastpath_ok(y) holds), fast_path = 2 rhs_norain (valid where
+// Model::norainpath_ok holds); both store their "left the regime" flag in broke[n].
 template <class Model, int MATH>
 __global__ void selftest_rhs_kernel(const double* __restrict__ y, const void* sp, const float* __restrict__ F,
                                     double* __restrict__ out, int* __restrict__ broke, int fast_path, int n)
@@ -621,7 +622,8 @@ __global__ void selftest_rhs_kernel(const double* __restrict__ y, const void* sp
 #pragma unroll
     for (int c = 0; c < NEQ; ++c) yy[c] = y[(size_t)i * NEQ + c];
     bool b = false;
-    if (fast_path) b = Model::template rhs_fast<MATH>(P, FV, yy, d);
+    if (fast_path == 2) b = Model::template rhs_norain<MATH>(P, FV, yy, d);
+    else if (fast_path) b = Model::template rhs_fast<MATH>(P, FV, yy, d);
     else Model::template rhs<MATH>(P, FV, yy, d);
 #pragma unroll
     for (int c = 0; c < NEQ; ++c) out[(size_t)i * NEQ + c] = d[c];
