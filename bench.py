@@ -190,6 +190,38 @@ def dense_section(args):
             "pcie_GBps": st["dense_bytes"] / (st["copy_ms"] * 1e-3) / 1e9}
 
 
+def c2_dummy_section(args):
+    """BASELINE config 2: DummyModel, 100 000 hillslopes, y0_i = 1 + 0.5 u_i, fixed step
+    (h = 0.05, controller off) against adaptive.  [0, 5] needs 12 adaptive attempts, so the rate is
+    taken on tf = 5000 (thousands of attempts, the kernel runs >> 1 ms); the difference between
+    the two modes is reported on [0, 5]."""
+    ns = 100_000
+    y0 = synth.dummy_y0(0, ns)
+    dev = f"cuda:{torch.cuda.current_device()}"
+    math = H.MATH_FAST if args.math == "fast" else H.MATH_STRICT
+    out = {"workload": f"DummyModel, {ns} hillslopes, y0 = 1 + 0.5u, math={args.math}"}
+    finals = {}
+    for mode, h in (("adaptive", 0.0), ("fixed_h0.05", 0.05)):
+        short = ShardEngine(H.DummyModel, y0, 0.0, 5.0, fixed_step=h, math_mode=math, device=dev)
+        short.integrate()
+        finals[mode] = short.results()["y_final"]
+        eng = ShardEngine(H.DummyModel, y0, 0.0, 5000.0, fixed_step=h, math_mode=math, device=dev)
+        eng.integrate()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        eng.integrate()
+        b.record()
+        torch.cuda.synchronize()
+        ms = a.elapsed_time(b)
+        att = eng.total_attempts()
+        out[mode] = {"steps_per_s": att / (ms * 1e-3), "kernel_ms": ms, "attempts_per_hillslope": att / ns}
+        if h == 0.0:  # 442 flop/step (SURVEY 8d) counts the error estimate and controller the fixed mode skips
+            out[mode]["valu_fp64_frac"] = att * 442.0 / (ms * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS
+    out["max_abs_diff_fixed_vs_adaptive_tf5"] = float(np.abs(finals["adaptive"] - finals["fixed_h0.05"]).max())
+    return out
+
+
 def cpu_baseline(args):
     """The oracle (CPU restatement, kind "port") on a bounded sample of the SAME workload:
     chunks of 2048 hillslopes of the dry C3 shard until ~cpu_seconds of CPU work."""
@@ -329,6 +361,8 @@ def main():
 
     if rank == 0 and world == 1 and not args.no_dense:
         out["dense_output"] = dense_section(args)
+    if rank == 0 and world == 1 and not args.no_variants:
+        out["c2_dummy"] = c2_dummy_section(args)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args)
