@@ -828,6 +828,27 @@ def test_device_rhs_single_evaluations_vs_oracle(gpu, oracle, math_mode):
     assert np.allclose(outd.cpu().numpy()[::20], refd, rtol=1e-14, atol=2e-15)  # FMA-contracted products
 
 
+def test_dense_tile_layout_holds_the_same_rows(gpu, layout=1):
+    """dense_tiled 1 ([tile][q][lane][c]) is a re-ordering of the host layout: same bits for
+    every (hillslope, query, state), flagged rows and tails zero alike, also after the Radau
+    pass and for a ragged last tile."""
+    H = gpu
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    sp, y0, cells, pr, t2m, dt, nT, q, tf = _cold_case(ns=200, days=5)
+    res = []
+    for lay in (0, layout):
+        eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, dense_tiled=lay)
+        eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+        eng.integrate()
+        a = eng.results()
+        eng.integrate(radau=True)
+        res.append((a, eng.results()))
+    for k in (0, 1):
+        for name in ("dense", "y_final", "stiff", "n_attempt"):
+            assert np.array_equal(res[0][k][name], res[1][k][name]), (k, name)
+    assert (res[0][0]["stiff"] == 1).sum() > 0 and res[0][0]["dense"].shape == (200, len(q), 5)
+
+
 # ---- Radau-IIA fallback for flagged systems (SURVEY 8f rank 4) ------------------------------------
 # No reference artifact pins this row (the reference never copies its Radau results back); the
 # oracle restatement is validated against SciPy in tests/test_radau_oracle.py and the HIP kernel

@@ -47,7 +47,7 @@ class ShardEngine:
         self.y_final = self.result_blob[:o].view(torch.float64).view(self.ns, model.N_EQ)
         # dense_tiled: tile-major [ceil(ns/64)][nq][64][5] device layout (what the streamed path
         # uses internally); only for measuring the kernel -- results() then returns that layout
-        self.dense_tiled = bool(dense_tiled)
+        self.dense_tiled = int(bool(dense_tiled))  # 0 host order, 1 [tile][q][lane][c]
         rows = -(-self.ns // 64) * 64 if self.dense_tiled else self.ns
         self.dense = (torch.empty((rows, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
                       if self.nq and alloc_dense else None)
@@ -89,7 +89,7 @@ class ShardEngine:
             forc_col=self.forc_col, params=self.params, fixed_step=self.fixed_step,
             attempt_cap=self.attempt_cap, math_mode=self.math_mode, y_final=self.y_final,
             dense=self.dense, stiff=self.stiff, n_attempt=self.n_attempt, n_accept=self.n_accept)
-        j.dense_tiled = int(self.dense_tiled and self.dense is not None)
+        j.dense_tiled = self.dense_tiled if self.dense is not None else 0
         return j
 
     def integrate(self, stream=None, t_stop=None, resume_in=False, radau=False):
@@ -223,11 +223,21 @@ class ShardEngine:
         i32 = lambda k: blob[o + k * ns8 * 4:o + (k + 1) * ns8 * 4].view(torch.int32)[:ns]
         return y, i32(0), i32(1), i32(2)
 
+    def dense_host_order(self):
+        """The dense buffer as a [ns, nq, 5] device tensor whatever its device layout."""
+        if self.dense is None or self.dense_tiled == 0:
+            return self.dense
+        tiles = self.dense.shape[0] // 64
+        n_eq = self.model.N_EQ
+        d = self.dense.view(tiles, self.nq, 64, n_eq).permute(0, 2, 1, 3)  # [tile][q][lane][c]
+        return d.reshape(tiles * 64, self.nq, n_eq)[:self.ns]
+
     def results(self):
         """Host copies: dict(y_final[ns,5], dense[ns,nq,5] or None, stiff, n_attempt, n_accept)."""
         torch.cuda.synchronize(self.device)
         u32 = lambda t: t.cpu().numpy().view(np.uint32)
+        dense = self.dense_host_order()
         return {"y_final": self.y_final.cpu().numpy(),
-                "dense": None if self.dense is None else self.dense.cpu().numpy(),
+                "dense": None if dense is None else dense.cpu().numpy(),
                 "stiff": self.stiff.cpu().numpy(), "n_attempt": u32(self.n_attempt),
                 "n_accept": u32(self.n_accept)}
