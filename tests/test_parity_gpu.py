@@ -1011,6 +1011,11 @@ def test_cpp_driver_radau_flag(gpu, golden, tmp_path):
     assert infos["on"]["radau"] is True and infos["on"]["unsolved"] == 0
     assert np.all(np.abs(on[flagged]).sum(axis=1) > 0)
     assert np.array_equal(on[~flagged], off[~flagged])
+    # the implicit pass restarts from t0 and needs the whole forcing series in HBM
+    r = subprocess.run([exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "14400", "--temp", "-4",
+                        "--stream-forcings", "600", "--radau", "--out-final", str(tmp_path / "x.csv"),
+                        "--out-dense", str(tmp_path / "y.csv")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "resident in HBM" in r.stderr
 
 
 def test_cpp_driver_yaml_config_equals_flags(gpu, golden, tmp_path):
