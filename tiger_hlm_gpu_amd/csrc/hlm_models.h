@@ -226,7 +226,8 @@ struct Model204Dev {
         const double x1 =
             __longlong_as_double(__double_as_longlong(vmin(h_snow, F.melt_pot)) & (long long)F.warm_mask);
         dydt[0] = 0.0 - x1;
-        const bool wet = x1 + h_stat - P.Hu > 0.0;
+        // x2 = max(0, x1 + h_stat - Hu) > 0; (a - b > 0) == (a > b) exactly in IEEE arithmetic
+        const bool wet = x1 + h_stat > P.Hu;
         const double Emax = vmin(F.e_pot, h_stat);
         dydt[2] = 0.0;
         if constexpr (MATH == MATH_FAST) {
