@@ -652,6 +652,37 @@ def test_streamed_forcings_equal_resident_bitwise(gpu, layout, chunk):
             assert np.array_equal(got[k], ref[k]), (method.__name__, k)
 
 
+def test_host_api_streamed_forcings_equal_resident_bitwise(gpu):
+    """hlm_set_forcings_host: run_rk45 with the series left in host memory (time chunks through
+    HBM) returns the bits of the run with the block resident (hlm_set_forcings)."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 300, 4
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days)
+    q = synth.minute_queries(0.0, days * 1440.0, 90.0)
+    d_sp = H.api.upload_spatial_params(sp)
+    H.api.set_model_parameters(H.Model204, H.Parameters())
+    res = {}
+    try:
+        f = H.api.set_forcings(np.concatenate([pr, t2m]), dt, nT, ld=pr.shape[1], col=cells)
+        res["resident"] = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, q, d_sp, with_info=True)
+        f.free()
+        for chunk in (333.0, 1440.0):
+            f = H.api.set_forcings_host((pr, t2m), dt, pr.shape[1], chunk, col=cells)
+            res[chunk] = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, q, d_sp, with_info=True)
+            f.free()
+    finally:
+        H.api.clear_forcings()
+        d_sp.free()
+    a = res["resident"]
+    assert a[2]["n_attempt"].sum() > 1000 * ns
+    for chunk in (333.0, 1440.0):
+        b = res[chunk]
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        for k in ("stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(a[2][k], b[2][k]), (chunk, k)
+
+
 def test_checkpoint_restore_continues_bitwise(gpu):
     """Pause at t_stop, copy the 76-byte-per-hillslope state to the host, restore it into a NEW
     engine and finish: finals, flags and counters equal the uninterrupted run."""

@@ -142,6 +142,40 @@ def set_forcings(data, dt_hours, nT, ld, col=None):
     return f
 
 
+class HostForcings:
+    """Forcing series kept in HOST memory and streamed through HBM in time chunks by
+    launch_rk45_kernel / run_rk45 (hlm_set_forcings_host; BASELINE config 3 "forcings
+    streamed").  ``tables``: one float32 array [nT_j][ld] per forcing; the object keeps them
+    alive until free()."""
+
+    def __init__(self, tables, dt_hours, ld, chunk_minutes, col=None):
+        self.tables = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
+        self.dt_hours = [float(x) for x in dt_hours]
+        self.ld = int(ld)
+        assert all(t.ndim == 2 and t.shape[1] == self.ld for t in self.tables)
+        self.chunk_minutes = float(chunk_minutes)
+        self.col = None if col is None else DeviceBuffer.from_host(np.ascontiguousarray(col, dtype=np.int32))
+
+    def register(self):
+        n = len(self.tables)
+        ptrs = (C.c_void_p * n)(*[t.ctypes.data for t in self.tables])
+        dt = (C.c_double * n)(*self.dt_hours)
+        nt = (C.c_uint64 * n)(*[t.shape[0] for t in self.tables])
+        check(lib().hlm_set_forcings_host(ptrs, dt, nt, n, self.ld, self.col.ptr if self.col else None, self.chunk_minutes))
+
+    def free(self):
+        check(lib().hlm_clear_forcings())
+        self.tables = []
+        if self.col:
+            self.col.free()
+
+
+def set_forcings_host(tables, dt_hours, ld, chunk_minutes, col=None):
+    f = HostForcings(tables, dt_hours, ld, chunk_minutes, col)
+    f.register()
+    return f
+
+
 def clear_forcings():
     check(lib().hlm_clear_forcings())
 
