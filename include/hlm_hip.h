@@ -211,7 +211,7 @@ int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream);
  * d_stiff entry is 1 is re-integrated from (t0, y0) with the implicit 3-stage method; its
  * y_final and dense rows are overwritten, d_n_attempt is incremented by the implicit attempts,
  * d_n_accept replaced.  d_stiff stays 1 on success and becomes 2 if the attempt cap ends the run
- * (final row zero).  Enqueue on the same stream after hlm_rk45_integrate_device(job).  The job
+ * (final row zero; job.attempt_cap, default 2^20 implicit attempts per system for this pass).  Enqueue on the same stream after hlm_rk45_integrate_device(job).  The job
  * must be a plain one-launch job (no d_resume / t_stop / query window / forcing chunk). */
 int hlm_radau_fallback_device(const hlm_device_job* job, void* hip_stream);
 

@@ -251,7 +251,10 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     }
     hipLaunchKernelGGL(hlm::radau_collect_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream,
                        j->d_stiff, ns, scratch + 1, scratch);
-    const hlm::Rk45Args a = make_args(j);
+    hlm::Rk45Args a = make_args(j);
+    // an implicit attempt costs ~30 us of a wave: the default cap of this pass is 2^20 attempts per
+    // system (half a minute), not the RK45 loop's 2^24, so a hopeless system cannot hold a wave for long
+    if (!j->attempt_cap) a.cap = 1u << 20;
     const unsigned blocks = (unsigned)((ns + hlm::WAVE - 1) / hlm::WAVE);  // blocks past the count exit at once
     if (j->uid == HLM_UID_204)
         hipLaunchKernelGGL(hlm::radau_fallback_kernel<hlm::Model204Dev>, dim3(blocks), dim3(hlm::WAVE), 0, stream, a,
