@@ -19,9 +19,37 @@ static bool throws(F f, const char* needle)
     return false;
 }
 
+// "dump FILE": the parsed tree as one "path=value" line per scalar (sequence items as [i], null as ~),
+// for the comparison with PyYAML in tests/test_host_logic.py
+static void dump(const hlm_config::Node& n, const std::string& path)
+{
+    using hlm_config::Node;
+    if (n.kind == Node::Map) {
+        if (n.map.empty()) std::printf("%s={}\n", path.c_str());
+        for (const auto& kv : n.map) dump(kv.second, path.empty() ? kv.first : path + "." + kv.first);
+    } else if (n.kind == Node::Seq) {
+        if (n.seq.empty()) std::printf("%s=[]\n", path.c_str());
+        for (size_t i = 0; i < n.seq.size(); ++i) dump(n.seq[i], path + "[" + std::to_string(i) + "]");
+    } else if (n.kind == Node::Null) {
+        std::printf("%s=~\n", path.c_str());
+    } else {
+        std::printf("%s=%s\n", path.c_str(), n.scalar.c_str());
+    }
+}
+
 int main(int argc, char** argv)
 {
     using namespace hlm_config;
+    if (argc > 2 && std::string(argv[1]) == "dump") {
+        try {
+            dump(load_yaml_file(argv[2]), "");
+            (void)from_yaml(load_yaml_file(argv[2]), "");
+        } catch (const std::exception& e) {
+            std::printf("ERROR %s\n", e.what());
+            return 1;
+        }
+        return 0;
+    }
     // ---- parser ------------------------------------------------------------------------------
     const char* doc =
         "# header comment\n"

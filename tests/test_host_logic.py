@@ -180,6 +180,34 @@ def test_config_yaml_reader_cpp(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "test_config_yaml.cpp"), "-o", exe], check=True)
     out = subprocess.run([exe, os.path.join(ROOT, "tools", "examples", "run_204.yaml")], capture_output=True, text=True)
     assert out.returncode == 0 and "all checks passed" in out.stdout, out.stdout + out.stderr
+    # the same tree as PyYAML builds, for the shipped example and -- where the reference is mounted
+    # (this container, not the GPU box) -- for the reference's own data/config.yaml
+    import yaml
+
+    def flatten(v, path=""):
+        if isinstance(v, dict):
+            if not v:
+                return [f"{path}={{}}"]
+            return [ln for k, x in v.items() for ln in flatten(x, f"{path}.{k}" if path else str(k))]
+        if isinstance(v, list):
+            if not v:
+                return [f"{path}=[]"]
+            return [ln for i, x in enumerate(v) for ln in flatten(x, f"{path}[{i}]")]
+        if v is None:
+            return [f"{path}=~"]
+        if isinstance(v, bool):
+            return [f"{path}={'true' if v else 'false'}"]
+        return [f"{path}={v}"]
+
+    docs = [os.path.join(ROOT, "tools", "examples", "run_204.yaml")]
+    if os.path.exists("/root/reference/data/config.yaml"):
+        docs.append("/root/reference/data/config.yaml")
+    for doc in docs:
+        got = subprocess.run([exe, "dump", doc], capture_output=True, text=True)
+        assert got.returncode == 0, got.stdout
+        want = flatten(yaml.safe_load(open(doc)))
+        norm = lambda ln: ln.split("=", 1)[0] + "=" + ln.split("=", 1)[1].strip()
+        assert [norm(x) for x in got.stdout.splitlines()] == [norm(x) for x in want], doc
     drv = os.path.join(ROOT, "tools", "rk45_solver")
     if not os.path.exists(drv):
         subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True)
