@@ -514,6 +514,38 @@ def test_wide_parameter_ranges_vs_oracle(gpu, oracle, math_mode):
     assert np.all(got["y_final"][fl] == 0.0)
 
 
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_negative_capacities_disable_the_no_rain_path(gpu, oracle, math_mode):
+    """min(0, infil) and min(0, perco) are only 0 for non-negative capacities.  Hillslopes with a
+    negative infil or perco (nonsense physically, defined arithmetically: model_204.hpp:101-113
+    then leaks -infil into the surface store every minute) must not take the no-rain shortcut --
+    neither they nor the lanes that share a wave with them.  The ordinary hillslopes must meet
+    the solver tolerance; the leaking ones sit on the x3/x4 kinks all the time (a 1000x tighter
+    tolerance moves the ORACLE's own answer by 1 % there), so they are held to 5e-3."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 320, 3
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days)
+    sp["infil"][5::7] = -1e-5       # mixed waves: every wave holds both kinds
+    sp["perco"][3::11] = -2e-6
+    sp["infil"][256:] = -3e-5       # and one wave with negative capacities only
+    q = synth.minute_queries(0.0, days * 1440.0, 30.0)
+    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp,
+                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    assert np.array_equal(got["stiff"], ref["stiff"]) and (ref["stiff"] == 0).all()
+    odd = (sp["infil"] < 0) | (sp["perco"] < 0)
+    assert 60 < odd.sum() < ns - 60
+    assert_parity(got["y_final"][~odd], ref["y_final"][~odd], "final, ordinary hillslopes")
+    assert_parity(got["dense"][~odd], ref["dense"][~odd], "dense, ordinary hillslopes")
+    for name in ("y_final", "dense"):
+        assert np.all(np.abs(got[name][odd] - ref[name][odd]) <= 1e-9 + 5e-3 * np.abs(ref[name][odd])), name
+    leak = sp["infil"] < 0
+    assert np.all(got["y_final"][leak, 2] > 0) and np.all(got["y_final"][~odd, 2] == 0)
+    assert np.array_equal(got["n_attempt"][~odd], ref["n_attempt"][~odd])
+    assert np.abs(got["n_attempt"].astype(np.int64) - ref["n_attempt"].astype(np.int64)).max() <= 0.02 * ref["n_attempt"].max()
+
+
 def test_c2_dummy_100k_fixed_vs_adaptive(gpu, oracle):
     """BASELINE config 2 at its stated size: DummyModel, 100 000 hillslopes, fp64."""
     H = gpu
