@@ -261,6 +261,32 @@ def test_dense_endpoint_consistency_large(gpu):
     assert np.all(got["dense"][:, 0, :] == 0.0)
 
 
+def test_c5_query_grid_thirty_days_one_minute_vs_oracle(gpu, oracle):
+    """BASELINE config 5's query grid at a hillslope count the oracle finishes in seconds:
+    1-minute stride over 30 days (nq = 43 201), one shot and streamed in windows, against the
+    oracle at the solver tolerance; the streamed result equals the one-shot result bit for bit."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 130, 30
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, run_len=32)
+    q = synth.minute_queries(0.0, days * 1440.0, 1.0)
+    assert len(q) == 43201
+    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, math_mode=H.MATH_FAST)
+    eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+    eng.integrate()
+    one = eng.results()
+    host, stats = eng.integrate_streamed(5000)
+    assert stats["windows"] == 9 and np.array_equal(np.asarray(host), one["dense"])
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp,
+                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    assert (one["stiff"] == 0).all() and (ref["stiff"] == 0).all()
+    assert_parity(one["y_final"], ref["y_final"], "final")
+    assert_parity(one["dense"], ref["dense"], "dense, 43 201 queries")
+    assert np.all(one["dense"][:, 0] == 0.0)                       # the query at t0 is never produced
+    assert_parity(one["dense"][:, -1], one["y_final"], "dense(tf) vs final")
+
+
 # ---- the C++ driver (rk45_solver) over the header-only template API ------------------------------
 def _driver_exe():
     import os
