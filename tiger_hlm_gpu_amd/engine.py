@@ -125,7 +125,7 @@ class ShardEngine:
         """Same as integrate_forcing_streamed, but the chunk loop runs inside the library
         (hlm_rk45_integrate_forcing_streamed): what a C / C++ host calls."""
         import ctypes as C
-        host = [torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).pin_memory() for t in tables]
+        host = [self.pin_forcing_table(t) for t in tables]
         ld = int(host[0].shape[1])
         col = None if cells is None else torch.from_numpy(np.ascontiguousarray(cells, dtype=np.int32)).to(self.device)
         j = self.job()
@@ -138,6 +138,16 @@ class ShardEngine:
         _lib.check(_lib.lib().hlm_rk45_integrate_forcing_streamed(C.byref(j), ptrs, float(chunk_minutes), s.cuda_stream, C.byref(n)))
         return n.value
 
+    @staticmethod
+    def pin_forcing_table(t):
+        """float32 [nT][ld] table in pinned host memory (a tensor that already is one is used as is,
+        so a caller streaming the same series repeatedly pins it once)."""
+        if torch.is_tensor(t) and t.is_pinned() and t.dtype == torch.float32 and t.is_contiguous():
+            return t
+        if torch.is_tensor(t):
+            t = t.cpu().numpy()
+        return torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).pin_memory()
+
     def integrate_forcing_streamed(self, tables, dt_hours, chunk_minutes, cells=None):
         """BASELINE config 3, "forcings streamed": the forcing series stay in (pinned) host
         memory and pass through HBM in time chunks.  While chunk k integrates (lanes pause at
@@ -146,7 +156,7 @@ class ShardEngine:
         index per hillslope when the tables are per grid cell (ld = ncell), None when they are
         per stream (ld = ns, the reference layout).  Bit-identical to the resident-forcing run."""
         dev = self.device
-        host = [torch.from_numpy(np.ascontiguousarray(t, dtype=np.float32)).pin_memory() for t in tables]
+        host = [self.pin_forcing_table(t) for t in tables]
         nT = [int(h.shape[0]) for h in host]
         ld = int(host[0].shape[1])
         assert all(h.shape[1] == ld for h in host) and (cells is not None or ld == self.ns)
