@@ -261,6 +261,39 @@ def test_dense_endpoint_consistency_large(gpu):
     assert np.all(got["dense"][:, 0, :] == 0.0)
 
 
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_time_window_edges_vs_oracle(gpu, oracle, math_mode):
+    """Windows that do not start at 0 or at a forcing boundary (the forcing index is
+    floor(t / dt), rk45_kernel.cu:90-98), that run past the end of the forcing series (index clamped
+    to the last sample), that are empty (tf == t0: the state is returned untouched) and single
+    hillslope / single query shapes."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 70, 3
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, run_len=16)
+    f = synth.expand_per_stream(pr, t2m, cells)
+    for t0, tf in ((725.5, 2100.25), (3000.0, 6000.0), (-90.0, 200.0)):
+        q = np.concatenate([[t0 - 1.0, t0], np.linspace(t0, tf, 37)[1:], [tf + 5.0]])
+        got = _run_engine(H, H.Model204, y0, t0, tf, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
+        ref = oracle.run(oracle.UID_204, y0, t0, tf, query=q, sp=sp, forc=f, forc_dt_h=dt, forc_nT=nT)
+        assert np.array_equal(got["stiff"], ref["stiff"]) and (ref["stiff"] == 0).all(), (t0, tf)
+        assert_parity(got["y_final"], ref["y_final"], f"final {t0}..{tf}")
+        assert_parity(got["dense"], ref["dense"], f"dense {t0}..{tf}")
+        assert np.all(got["dense"][:, :2] == 0.0) and np.all(got["dense"][:, -1] == 0.0)  # <= t0 and > tf: never produced
+        assert np.abs(got["n_attempt"].astype(np.int64) - ref["n_attempt"].astype(np.int64)).max() <= 3
+    # empty window
+    got = _run_engine(H, H.Model204, y0, 500.0, 500.0, sp=sp, query=np.array([499.0, 500.0, 501.0]),
+                      forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
+    assert np.array_equal(got["y_final"], y0) and (got["n_attempt"] == 0).all() and np.all(got["dense"] == 0.0)
+    # one hillslope, one query
+    got = _run_engine(H, H.Model204, y0[:1], 0.0, 333.0, sp=sp[:1], query=np.array([111.0]),
+                      forcing=(pr, t2m, cells[:1], dt, nT), math_mode=math_mode)
+    ref = oracle.run(oracle.UID_204, y0[:1], 0.0, 333.0, query=np.array([111.0]), sp=sp[:1],
+                     forc=np.ascontiguousarray(f[:, :1]), forc_dt_h=dt, forc_nT=nT)
+    assert_parity(got["y_final"], ref["y_final"], "1x1 final")
+    assert_parity(got["dense"], ref["dense"], "1x1 dense")
+
+
 def test_c5_query_grid_thirty_days_one_minute_vs_oracle(gpu, oracle):
     """BASELINE config 5's query grid at a hillslope count the oracle finishes in seconds:
     1-minute stride over 30 days (nq = 43 201), one shot and streamed in windows, against the
