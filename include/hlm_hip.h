@@ -51,7 +51,10 @@ typedef enum {
 
 /* math mode: 0 = strict (IEEE divide, OCML pow: same operation structure as the
  * reference, FMA-contracted like nvcc's default); 1 = fast (reciprocal multiplies,
- * specialised x^(2/3) and x^(1/5); within the stated parity tolerance). */
+ * specialised x^(2/3) and x^(1/5); within the stated parity tolerance).  One behavioural
+ * difference: a NaN / Inf state component is carried along silently in strict mode, as in the
+ * reference (its error norm skips NaN ratios); in fast mode it poisons the error norm, every
+ * attempt is rejected and the system is flagged (stiff = 1, zero rows) after six rejects. */
 #define HLM_MATH_STRICT 0
 #define HLM_MATH_FAST 1
 

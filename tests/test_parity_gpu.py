@@ -294,6 +294,48 @@ def test_time_window_edges_vs_oracle(gpu, oracle, math_mode):
     assert_parity(got["dense"], ref["dense"], "1x1 dense")
 
 
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_non_finite_states(gpu, oracle, math_mode):
+    """The reference's error norm skips NaN components ("if (fabs(ratio) > max)",
+    rk45_step_dense.cuh:135-140), so a NaN state component is carried along silently: not flagged,
+    NaN in, NaN out, the other components integrate on; -Inf snow never passes a step and runs
+    into the attempt cap.  STRICT reproduces exactly that (flags, NaN positions, step counts).
+    FAST forms the norm with one reciprocal of the product of the tolerances, which a non-finite
+    component poisons: every attempt is rejected and the system is FLAGGED after six rejects
+    (status 1, zero rows) -- a documented difference.  Wave neighbours are untouched in both."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days, cap = 96, 1, 20000
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, run_len=16)
+    bad = {3: (1, np.nan), 17: (3, np.inf), 40: (0, -np.inf), 64: (4, np.nan), 65: (2, np.nan)}
+    for s_, (c, v) in bad.items():
+        y0[s_, c] = v
+    idx = np.array(sorted(bad))
+    good = np.ones(ns, bool)
+    good[idx] = False
+    q = synth.minute_queries(0.0, days * 1440.0, 120.0)
+    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT),
+                      math_mode=math_mode, attempt_cap=cap)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, attempt_cap=cap,
+                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    assert ref["stiff"][40] == 2 and (np.delete(ref["stiff"], 40) == 0).all() and np.isnan(ref["y_final"][3, 1])
+    assert (got["stiff"][good] == 0).all()
+    assert_parity(got["y_final"][good], ref["y_final"][good], "neighbours, final")
+    assert_parity(got["dense"][good], ref["dense"][good], "neighbours, dense")
+    if math_mode == 0:
+        assert np.array_equal(got["stiff"], ref["stiff"]) and got["n_attempt"][40] == cap
+        for name in ("y_final", "dense"):
+            g, r = got[name], ref[name]
+            assert np.array_equal(np.isnan(g), np.isnan(r)), name
+            assert np.array_equal(np.isinf(g), np.isinf(r)), name
+            fin = np.isfinite(r)
+            assert np.all(np.abs(g[fin] - r[fin]) <= 1e-9 + 1e-6 * np.abs(r[fin])), name
+        assert np.abs(got["n_attempt"].astype(np.int64) - ref["n_attempt"].astype(np.int64)).max() <= 3
+    else:
+        assert (got["stiff"][idx] == 1).all() and (got["n_attempt"][idx] == 6).all()
+        assert np.all(got["y_final"][idx] == 0.0) and np.all(got["dense"][idx] == 0.0)
+
+
 def test_c5_query_grid_thirty_days_one_minute_vs_oracle(gpu, oracle):
     """BASELINE config 5's query grid at a hillslope count the oracle finishes in seconds:
     1-minute stride over 30 days (nq = 43 201), one shot and streamed in windows, against the
