@@ -294,6 +294,37 @@ def test_time_window_edges_vs_oracle(gpu, oracle, math_mode):
     assert_parity(got["dense"], ref["dense"], "1x1 dense")
 
 
+@pytest.mark.parametrize("dts", [(0.25, 6.0), (1.0 / 3.0, 7.3), (0.7, 0.1), (2.5, 1e6)])
+def test_odd_forcing_sample_spacings_vs_oracle(gpu, oracle, dts):
+    """The kernel holds a forcing sample until t crosses (idx + 1) * dt instead of redoing
+    floor(t / dt) on every attempt (rk45_kernel.cu:90-98).  Sample spacings that are not a whole
+    number of minutes (dt * 60 inexact in binary), much shorter than a step, or longer than the whole
+    run must give the oracle's result: same flags, same step counts, solver tolerance."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, tf = 130, 2.5 * 1440.0
+    sp = synth.model204_params(0, ns, seed=11)
+    y0 = synth.model204_y0(ns)
+    rng = np.random.default_rng(5)
+    nT = [int(np.ceil(tf / (d * 60.0))) + (2 if d < 100 else 0) for d in dts]
+    nT[0] = max(nT[0] - 40, 1)  # the first series ends before tf: the last sample is held
+    pr = (rng.random((nT[0], ns)) < 0.3) * rng.exponential(2e-4, (nT[0], ns))
+    t2m = rng.uniform(0.5, 15.0, (nT[1], ns))
+    block = np.concatenate([pr, t2m]).astype(np.float32)
+    q = synth.minute_queries(0.0, tf, 37.0)
+    for mm in (0, 1):
+        eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, math_mode=mm)
+        eng.set_forcings_per_stream(block, dts, nT)
+        eng.integrate()
+        got = eng.results()
+        ref = oracle.run(oracle.UID_204, y0, 0.0, tf, query=q, sp=sp, forc=block, forc_dt_h=dts, forc_nT=nT)
+        assert np.array_equal(got["stiff"], ref["stiff"]) and (ref["stiff"] == 0).all()
+        assert_parity(got["y_final"], ref["y_final"], f"final dt={dts} math={mm}")
+        assert_parity(got["dense"], ref["dense"], f"dense dt={dts} math={mm}")
+        assert np.abs(got["n_attempt"].astype(np.int64) - ref["n_attempt"].astype(np.int64)).max() <= 3
+
+
 @pytest.mark.parametrize("math_mode", [0, 1])
 def test_non_finite_states(gpu, oracle, math_mode):
     """The reference's error norm skips NaN components ("if (fabs(ratio) > max)",
