@@ -207,6 +207,17 @@ def test_empty_inputs_and_errors(gpu):
     with pytest.raises(H.HlmError) as e:
         H.api.set_model_parameters(777, (0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0))
     assert e.value.code == 2
+    # FAST's one-reciprocal error norm needs atol^5 inside the double range; STRICT takes any atol
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    for atol, mode, ok in ((0.0, H.MATH_FAST, False), (1e-70, H.MATH_FAST, False), (1e-70, H.MATH_STRICT, True), (1e-30, H.MATH_FAST, True)):
+        eng = ShardEngine(H.DummyModel, np.ones((3, 5)), 0.0, 1.0, params=H.Parameters(0.01, 1e-6, atol, 0.9, 0.2, 10.0), math_mode=mode)
+        if ok:
+            eng.integrate()
+            assert (eng.results()["stiff"] == 0).all()
+        else:
+            with pytest.raises(H.HlmError) as e:
+                eng.integrate()
+            assert e.value.code == 1 and "atol >= 1e-60" in str(e.value)
 
 
 def test_three_phase_api_equals_run_rk45(gpu):
