@@ -55,7 +55,7 @@ typedef enum {
  * difference: a NaN / Inf state component is carried along silently in strict mode, as in the
  * reference (its error norm skips NaN ratios); in fast mode it poisons the error norm, every
  * attempt is rejected and the system is flagged (stiff = 1, zero rows) after six rejects.
- * Fast mode needs atol >= 1e-60 (its error norm multiplies the five tolerances). */
+ * Fast mode needs 1e-60 <= atol <= 1e50 (its error norm multiplies the five tolerances). */
 #define HLM_MATH_STRICT 0
 #define HLM_MATH_FAST 1
 

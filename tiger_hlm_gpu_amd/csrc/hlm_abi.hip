@@ -154,8 +154,8 @@ int validate_job(const hlm_device_job* j)
     if (j->fixed_step < 0.0) return fail(HLM_ERR_INVALID_ARGUMENT, "fixed_step < 0");
     // FAST forms the error norm with ONE reciprocal of the product of the five per-component
     // tolerances (>= atol each): that product must stay inside the double range
-    if (j->math_mode == HLM_MATH_FAST && j->fixed_step == 0.0 && !(j->params[2] >= 1e-60))
-        return fail(HLM_ERR_INVALID_ARGUMENT, "math mode FAST needs atol >= 1e-60 (got %g); use HLM_MATH_STRICT", j->params[2]);
+    if (j->math_mode == HLM_MATH_FAST && j->fixed_step == 0.0 && !(j->params[2] >= 1e-60 && j->params[2] <= 1e50))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "math mode FAST needs atol >= 1e-60 and <= 1e50 (got %g); use HLM_MATH_STRICT", j->params[2]);
     if (j->query_end != 0 || j->query_begin != 0) {
         if (j->query_begin < 0 || j->query_end <= j->query_begin || j->query_end > j->num_queries)
             return fail(HLM_ERR_INVALID_ARGUMENT, "query window [%d,%d) outside [0,%d)", j->query_begin,
