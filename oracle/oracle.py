@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "libhlm_oracle.so")
+_SO_FMA = os.path.join(_HERE, "libhlm_oracle_fma.so")  # conditioning yardstick, see the Makefile
 
 UID_DUMMY = 0
 UID_204 = 204
@@ -46,19 +47,18 @@ class _Job(C.Structure):
 
 
 def build(force=False):
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(os.path.join(_HERE, "hlm_oracle.c")):
+    newest = max(os.path.getmtime(os.path.join(_HERE, f)) for f in ("hlm_oracle.c", "hlm_oracle_radau.c", "hlm_oracle.h"))
+    if force or any(not os.path.exists(so) or os.path.getmtime(so) < newest for so in (_SO, _SO_FMA)):
         subprocess.run(["make", "-C", _HERE, "-s"], check=True)
     return _SO
 
 
 _lib = None
+_lib_fma = None
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        build()
-        _lib = C.CDLL(_SO)
+def _declare(_lib):
+    if True:
         _lib.hlm_oracle_rk45_run.argtypes = [C.POINTER(_Job)]
         _lib.hlm_oracle_rk45_run.restype = C.c_int
         _lib.hlm_oracle_radau_run.argtypes = [C.POINTER(_Job)]
@@ -75,6 +75,16 @@ def lib():
         for n in ("c", "a", "b", "balt", "P"):
             getattr(_lib, "hlm_oracle_tableau_" + n).restype = C.POINTER(C.c_double)
     return _lib
+
+
+def lib(fma=False):
+    """The oracle library; fma=True: the FMA-contracted build of the same text (yardstick only)."""
+    global _lib, _lib_fma
+    if _lib is None:
+        build()
+        _lib = _declare(C.CDLL(_SO))
+        _lib_fma = _declare(C.CDLL(_SO_FMA))
+    return _lib_fma if fma else _lib
 
 
 def _p(a):
@@ -120,11 +130,13 @@ def rk45_dense(y, k, h, theta):
 
 def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT=None,
         params=DEFAULT_PARAMS, forc_stub_f64=None, fixed_step=0.0, attempt_cap=0, nthreads=0,
-        reorder=True, radau=False, radau_only=False):
+        reorder=True, radau=False, radau_only=False, fma=False):
     """Integrate; returns dict(y_final[ns,5], dense[ns,nq,5] (or raw [ns,5,nq]), stiff, n_attempt, n_accept).
 
     radau=True re-integrates the systems RK45 flagged with the Radau-IIA fallback
-    (hlm_oracle_radau_run); radau_only=True skips RK45 and sends every system through it."""
+    (hlm_oracle_radau_run); radau_only=True skips RK45 and sends every system through it.
+    fma=True runs the FMA-contracted build instead: NOT a reference, only the yardstick for how far
+    two valid roundings of the same computation separate on this input."""
     y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, NEQ)
     ns = y0.shape[0]
     q = np.zeros(0) if query is None else np.ascontiguousarray(query, dtype=np.float64)
@@ -162,11 +174,11 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
         yf[:] = 0.0
         rc = 0
     else:
-        rc = lib().hlm_oracle_rk45_run(C.byref(j))
+        rc = lib(fma).hlm_oracle_rk45_run(C.byref(j))
     if rc != 0:
         raise ValueError("hlm_oracle_rk45_run: bad arguments")
     if radau or radau_only:
-        if lib().hlm_oracle_radau_run(C.byref(j)) != 0:
+        if lib(fma).hlm_oracle_radau_run(C.byref(j)) != 0:
             raise ValueError("hlm_oracle_radau_run: bad arguments")
     dense = raw
     if nq and reorder:
