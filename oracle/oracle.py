@@ -83,7 +83,8 @@ def lib(fma=False):
     if _lib is None:
         build()
         _lib = _declare(C.CDLL(_SO))
-        _lib_fma = _declare(C.CDLL(_SO_FMA))
+    if fma and _lib_fma is None:
+        _lib_fma = _declare(C.CDLL(_SO_FMA))  # loaded only on request: a yardstick, not the checker
     return _lib_fma if fma else _lib
 
 
