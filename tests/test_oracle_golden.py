@@ -153,3 +153,20 @@ def test_empty_and_bad_arguments(oracle):
         oracle.run(999, np.ones((1, 5)), 0.0, 1.0)
     with pytest.raises(ValueError):
         oracle.run(oracle.UID_204, np.ones((1, 5)), 0.0, 1.0)  # Model 204 without params
+
+
+def test_fma_yardstick_build_tracks_the_oracle(oracle, golden):
+    """oracle/libhlm_oracle_fma.so is the same text compiled with FMA contraction.  It is not a
+    reference -- only a yardstick for how far two valid roundings of one computation separate on
+    an input (tests/fuzz_parity.py, the wide-parameter GPU test).  On the well-conditioned golden
+    case it must land on the plain build to ~1e-12, with the same step count."""
+    sp = load_spatial_params(golden["small_test_csv"])
+    y0 = synth.model204_y0(10)
+    q = np.arange(0.0, 2881.0, 60.0)
+    kw = dict(query=q, sp=sp, forc_stub_f64=[0.001, 1.0], params=G2_PARAMS)
+    a = oracle.run(oracle.UID_204, y0, 0.0, 2880.0, **kw)
+    b = oracle.run(oracle.UID_204, y0, 0.0, 2880.0, fma=True, **kw)
+    assert np.array_equal(a["n_attempt"], b["n_attempt"]) and np.array_equal(a["stiff"], b["stiff"])
+    assert np.max(np.abs(a["y_final"] - b["y_final"]) / (1e-300 + np.abs(a["y_final"]))) < 1e-10
+    assert np.max(np.abs(a["dense"] - b["dense"])) < 1e-10
+    assert np.abs(a["y_final"] - golden["g2_final"]).max() < 1e-12  # the plain build is the pinned one
