@@ -375,6 +375,35 @@ def test_solver_parameter_sets_vs_oracle(gpu, oracle, params, wet):
 
 
 @pytest.mark.parametrize("math_mode", [0, 1])
+def test_saturated_static_store_in_a_rain_free_dry_wave(gpu, oracle, math_mode):
+    """Every hillslope of the wave starts with the static store ABOVE its capacity, a dry surface and
+    no rain in the first hours, and an infiltration capacity that swallows the whole overflow (the
+    surface stays dry).  The wave qualifies for the no-rain shortcut by its cheap test, the shortcut
+    reports "saturated" in its very first RHS evaluation, and the attempt falls back -- the slope k0
+    it evaluated on the way must not be reused.  Solver tolerance against the oracle."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 128, 2
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days, run_len=16)
+    sp["Hu"] = np.linspace(0.5, 2.5, ns)        # y0[1] = 3 everywhere: overflow 0.5 .. 2.5
+    sp["infil"] = 10.0                          # min(x2, infil) = x2: nothing reaches the surface
+    sp["perco"] = np.linspace(1e-4, 1e-2, ns)
+    pr[:6] = 0.0                                # six rain-free hours first
+    q = synth.minute_queries(0.0, days * 1440.0, 20.0)
+    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp,
+                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    assert np.array_equal(got["stiff"], ref["stiff"])
+    ok = ref["stiff"] == 0          # dumping the overflow in the first minute is violent: the reference flags some
+    assert ok.sum() > 0.6 * ns
+    assert np.all(ref["dense"][ok][:, :, 2] == 0.0) and np.all(ref["dense"][ok][:, 3, 3] > 5.0)  # dry surface, overflow went down
+    assert_parity(got["y_final"][ok], ref["y_final"][ok], "final")
+    assert_parity(got["dense"][ok], ref["dense"][ok], "dense")
+    assert np.all(got["y_final"][~ok] == 0.0)
+    assert np.abs(got["n_attempt"].astype(np.int64) - ref["n_attempt"].astype(np.int64)).max() <= 3
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
 def test_non_finite_states(gpu, oracle, math_mode):
     """The reference's error norm skips NaN components ("if (fabs(ratio) > max)",
     rk45_step_dense.cuh:135-140), so a NaN state component is carried along silently: not flagged,

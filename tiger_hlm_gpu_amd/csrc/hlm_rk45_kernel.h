@@ -455,9 +455,13 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         if constexpr (Model::HAS_NORAINPATH) {
             // between storms (no rain in the held sample, dry surface): the cascade below the static store is idle
             if (__builtin_amdgcn_ballot_w64(!Model::norainpath_ok(P, FV, y)) == 0ull) {
+                const bool had_k0 = have_k0;
                 const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
-                have_k0 = true;  // k0 of a qualifying state is exact
                 general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+                // Unlike the dry path's, this path's precondition is not decided by y alone: "static
+                // store below capacity" is only discovered by the RHS evaluations themselves, the one
+                // for k0 included.  A k0 evaluated in an attempt that falls back is therefore not kept.
+                have_k0 = general ? had_k0 : true;
             }
         }
         if constexpr (Model::HAS_FASTPATH) {
