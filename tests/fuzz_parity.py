@@ -32,8 +32,14 @@ def one(seed, ns, days):
     sp["perco"] = 10.0 ** rng.uniform(-6, -3.5, ns)
     y0 = synth.model204_y0(ns)
     y0[:, 2] = np.where(rng.random(ns) < 0.3, rng.uniform(0, 0.02, ns), 0.0)
+    if seed % 3 == 1:
+        # whole waves that stay dry while their static stores overflow: every surface starts dry and the
+        # infiltration capacity swallows any overflow (exercises the fall-backs of the no-rain path)
+        y0[:, 2] = 0.0
+        sp["infil"] = 10.0 ** rng.uniform(-1, 1, ns)
+        sp["Hu"] = 10.0 ** rng.uniform(np.log10(3.05), 2.4, ns) * rng.choice([1.0, 0.9, 0.5], ns)
     y0[:, 0] = rng.uniform(0, 0.02, ns) * (rng.random(ns) < 0.5)
-    y0[:, 1] = rng.uniform(0.5, 3.0, ns)
+    y0[:, 1] = rng.uniform(0.5, 3.0, ns) if seed % 3 != 1 else rng.uniform(2.0, 3.2, ns)
     run_len = int(rng.choice([1, 7, 64, 512]))
     cells = synth.cell_of_system(0, ns, ncell=64, run_len=run_len)
     pr, t2m, dt, nT = synth.forcing_tables(days=days, ncell=64, seed=seed, wet_prob=float(rng.uniform(0.05, 0.5)),
