@@ -149,6 +149,9 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     };
     if constexpr (PATH != PATH_GENERAL) yt[Z] = y[Z];
     if (!have_k0) f(y, k0);  // no FSAL in the reference: see the have_k0 comment in the kernel
+    // a pinned component must really stand still: a carried-over k0 (k6 of a step the general path
+    // took) can hold the first inflow into a still-dry store, which the stage states below would ignore
+    if constexpr (PATH != PATH_GENERAL) broke |= k0[Z] != 0.0;
     {
         const double a10 = h * A10;
 #pragma unroll
