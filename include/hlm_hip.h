@@ -271,8 +271,10 @@ int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void*
 int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, const void* d_sp,
                      const float* d_F, double* d_out, int32_t* d_broke, int n, void* hip_stream);
 
-/* Static facts about the compiled kernels (for DESIGN.md / bench output). */
-int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs,
+/* Static facts about the compiled kernels (for DESIGN.md / bench output / the register-budget
+ * test): VGPRs per lane, scratch (spill) bytes per lane, static LDS bytes per workgroup,
+ * maximum workgroup size.  168 VGPRs = 3 waves per SIMD, 256 = 2. */
+int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* scratch_bytes,
                     int* lds_bytes, int* max_threads);
 
 #ifdef __cplusplus

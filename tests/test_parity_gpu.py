@@ -445,6 +445,21 @@ def test_non_finite_states(gpu, oracle, math_mode):
         assert np.all(got["y_final"][idx] == 0.0) and np.all(got["dense"][idx] == 0.0)
 
 
+def test_kernel_register_budgets(gpu):
+    """The occupancy the measurements rest on: the FAST kernel without dense
+    output must fit 168 VGPRs (3 waves per SIMD) with only its few cold values spilled; every other
+    variant must fit 256 (2 waves) without touching scratch in earnest.  A change that pushes a
+    variant over its budget would halve its occupancy or spill into the loop -- fail here first."""
+    H = gpu
+    lean = H.api.kernel_info(H.Model204, dense=False, math_mode=H.MATH_FAST)
+    assert lean["vgprs"] <= 168 and lean["scratch_bytes"] <= 96, lean
+    for dense, mode in ((True, H.MATH_FAST), (False, H.MATH_STRICT), (True, H.MATH_STRICT)):
+        k = H.api.kernel_info(H.Model204, dense=dense, math_mode=mode)
+        assert k["vgprs"] <= 256 and k["scratch_bytes"] <= 64 and k["max_threads"] >= 64, (dense, mode, k)
+    d = H.api.kernel_info(H.DummyModel, dense=False, math_mode=H.MATH_FAST)
+    assert d["vgprs"] <= 168 and d["scratch_bytes"] == 0, d
+
+
 def test_c5_query_grid_thirty_days_one_minute_vs_oracle(gpu, oracle):
     """BASELINE config 5's query grid at a hillslope count the oracle finishes in seconds:
     1-minute stride over 30 days (nq = 43 201), one shot and streamed in windows, against the

@@ -303,4 +303,4 @@ def time_device(job, iters, stream=None):
 def kernel_info(model, dense=False, math_mode=_lib.MATH_STRICT):
     v, s, l, m = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     check(lib().hlm_kernel_info(_uid(model), int(dense), int(math_mode), C.byref(v), C.byref(s), C.byref(l), C.byref(m)))
-    return {"vgprs": v.value, "lds_bytes": l.value, "max_threads": m.value}
+    return {"vgprs": v.value, "scratch_bytes": s.value, "lds_bytes": l.value, "max_threads": m.value}

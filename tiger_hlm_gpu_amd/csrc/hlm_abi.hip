@@ -775,7 +775,7 @@ int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, c
     return HLM_SUCCESS;
 }
 
-int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs, int* lds_bytes,
+int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* scratch_bytes, int* lds_bytes,
                     int* max_threads)
 {
     KernelFn fn = pick(uid, math_mode, dense != 0, false);
@@ -783,7 +783,7 @@ int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* sgprs, i
     hipFuncAttributes at;
     HLM_HIP_TRY(hipFuncGetAttributes(&at, reinterpret_cast<const void*>(fn)));
     if (vgprs) *vgprs = at.numRegs;
-    if (sgprs) *sgprs = 0;
+    if (scratch_bytes) *scratch_bytes = (int)at.localSizeBytes;
     if (lds_bytes) *lds_bytes = (int)at.sharedSizeBytes;
     if (max_threads) *max_threads = at.maxThreadsPerBlock;
     return HLM_SUCCESS;
