@@ -386,6 +386,35 @@ def main():
         del engs
         torch.cuda.empty_cache()
 
+        # cold cells (temperatures down to -5: the negative ET stub flags about one
+        # hillslope in six as stiff in RK45) with the Radau-IIA fallback finishing the flagged ones
+        def _cold(ns=262144, days=8):
+            spc = synth.model204_params(0, ns)
+            cc = synth.cell_of_system(0, ns)
+            prc, t2c, dtc, nTc = synth.forcing_tables(days=days, tmin=-5.0)
+            e = ShardEngine(H.Model204, synth.model204_y0(ns), 0.0, days * 1440.0, sp=spc,
+                            math_mode=H.MATH_FAST if args.math == "fast" else H.MATH_STRICT,
+                            device=f"cuda:{torch.cuda.current_device()}")
+            e.expand_forcings_on_device((prc, t2c), cc, dtc, nTc)
+            res = {}
+            for tag, radau in (("rk45_ms", False), ("rk45_plus_radau_ms", True)):
+                e.integrate(radau=radau)
+                torch.cuda.synchronize()
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                e.integrate(radau=radau)
+                b.record()
+                torch.cuda.synchronize()
+                res[tag] = a.elapsed_time(b)
+                if not radau:
+                    res["flagged_by_rk45"] = int((e.stiff == 1).sum().item())
+                    res["rk45_attempts"] = e.total_attempts()
+            res["radau_attempts"] = e.total_attempts() - res["rk45_attempts"]
+            res["unsolved_after_radau"] = int((e.stiff == 2).sum().item())
+            res["workload"] = f"Model 204, {ns} hillslopes, {days} days, T in [-5, 15], math={args.math}"
+            return res
+        out["variant_cold_cells_radau_fallback"] = _cold()
+
     if rank == 0 and world == 1 and not args.no_dense:
         out["dense_output"] = dense_section(args)
     if rank == 0 and world == 1 and not args.no_variants:
