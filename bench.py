@@ -14,6 +14,14 @@ precipitation + daily 2 m temperature over 30 days on a 32x32 forcing grid expan
 reference's per-stream device layout, rtol 1e-6, atol 1e-9, initialStep 0.01, no dense
 output.  At the end of every pass the final states, flags and step counters are gathered
 to rank 0 (RCCL over xGMI) -- the only exchange of the path.
+``--scaling strong --total-ns 4000000`` measures BASELINE config 4 instead (4 M hillslopes
+in total, split over the N GPUs by the reference's rank-0 rule, main.cpp:275-307).
+
+Launch: one process per GPU.  ``python bench.py --gpus N`` with N > 1 and no WORLD_SIZE in
+the environment starts the N ranks itself -- a fresh child ``python -m torch.distributed.run
+--nproc-per-node N bench.py ...`` (the reference's ``mpirun -np N ./rk45_solver``,
+README.md:120), started before this process has imported torch or touched a GPU -- relays
+rank 0's line and exits with the child's code.  Under torchrun (WORLD_SIZE set) it is a rank.
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,14 +38,20 @@ if ROOT not in sys.path:
 # buffer sharing fails with "hipIpcGetMemHandle: invalid argument" (normally exported already)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
-import numpy as np
-import torch
-import torch.distributed as dist
 
-import tiger_hlm_gpu_amd as H
-from tiger_hlm_gpu_amd import synth
-from tiger_hlm_gpu_amd.engine import ShardEngine
-from tiger_hlm_gpu_amd.shard import gather_to_root, shard_bounds
+
+def _load():
+    """Heavy imports, done by a RANK only -- the launcher process below must never import torch
+    or the HIP library (a process that has initialised the GPU must not start the ranks)."""
+    global np, torch, dist, H, synth, ShardEngine, gather_blobs, shard_bounds
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import tiger_hlm_gpu_amd as H
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    from tiger_hlm_gpu_amd.shard import gather_blobs, shard_bounds
+
 
 # SURVEY 8d / BASELINE.md section 3: algorithmic work per unit
 F_STEP_204 = 606.0        # FP64 flops per attempted step, Model 204
@@ -54,6 +68,14 @@ def parse():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--ns-per-gpu", type=int, default=1_000_000)
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --ns-per-gpu hillslopes on every GPU (C3 per GPU); strong: --total-ns hillslopes "
+                         "in total, split over the GPUs by the reference's rule (C4 = 4 000 000)")
+    ap.add_argument("--total-ns", type=int, default=4_000_000, help="with --scaling strong")
+    ap.add_argument("--master-port", type=int, default=0, help="self-launch only (0 = pick a free port)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="no GPU needed and NOTHING is measured: the ranks run launch, shard, gather and the "
+                         "max-over-ranks timing on signature data (CPU test of the N > 1 plumbing; implies gloo)")
     ap.add_argument("--days", type=int, default=30)
     ap.add_argument("--math", choices=["strict", "fast"], default="fast")
     ap.add_argument("--layout", choices=["per-stream", "per-cell"], default="per-stream")
@@ -85,14 +107,17 @@ def usable_cores():
     return n
 
 
-def build_engine(args, rank, world, wet, math=None):
-    ns = args.ns_per_gpu
-    total = ns * world
+def total_hillslopes(args, world):
+    return args.total_ns if args.scaling == "strong" else args.ns_per_gpu * world
+
+
+def build_engine(args, rank, world, wet, math=None, tmin=0.5):
+    total = total_hillslopes(args, world)
     start, count = shard_bounds(total, world, rank)
     sp = synth.model204_params(start, count)
     y0 = synth.model204_y0(count, wet_surface=wet)
     cells = synth.cell_of_system(start, count)
-    pr, t2m, dt, nT = synth.forcing_tables(days=args.days)
+    pr, t2m, dt, nT = synth.forcing_tables(days=args.days, tmin=tmin)
     tf = args.days * 1440.0
     q = synth.minute_queries(0.0, tf, args.dense_stride) if args.dense_stride > 0 else None
     eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q,
@@ -105,9 +130,9 @@ def build_engine(args, rank, world, wet, math=None):
     return eng, total
 
 
-def _per_gpu_key(args, nq):
+def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    return f"ns={args.ns_per_gpu};days={args.days};layout={args.layout};nq={nq};math={args.math}"
+    return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}"
 
 
 def _coll_device(dev):
@@ -115,49 +140,48 @@ def _coll_device(dev):
     return dev if dist.get_backend() == "nccl" else torch.device("cpu")
 
 
-def gather_results(eng, world):
+def gather_results(eng, total, world):
     """End-of-run gather (the path's only exchange): final states, flags and step counters of
     every rank's shard arrive on rank 0 in ONE collective -- the engine keeps them in a single
-    52-byte-per-hillslope allocation.  Equal shards (weak scaling), so no padding copy."""
-    blob = eng.result_blob
-    return gather_to_root(blob.view(1, -1), world)  # one row per rank
-
-
-def one_pass(eng, total, world):
-    """The hot path over one batch + the end-of-run gather (the path's only exchange)."""
-    eng.integrate()
-    if world > 1:
-        gather_results(eng, world)
+    52-byte-per-hillslope allocation.  Shards differ by at most one hillslope (strong scaling
+    with a remainder): the blobs are then padded to the longest one."""
+    return gather_blobs(eng.result_blob, total)  # list of per-rank blobs on rank 0
 
 
 def timed_passes(eng, total, world, warmup, steps):
+    """W untimed passes, then EXACTLY K timed ones between barrier + synchronize on both sides.
+    Returns (wall seconds: max over ranks, kernel ms per pass, gather ms per pass) of this rank;
+    the per-pass times are HIP events on the stream the kernel is launched on."""
     dev = eng.device
     for _ in range(warmup):
-        one_pass(eng, total, world)
+        eng.integrate()
+        if world > 1:
+            gather_results(eng, total, world)
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    # HIP events on the stream the kernel is launched on (torch's current stream)
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
     t0 = time.perf_counter()
     for i in range(steps):
         ev[i][0].record()
         eng.integrate()
         ev[i][1].record()
         if world > 1:
-            gather_results(eng, world)
+            gather_results(eng, total, world)
+        ev[i][2].record()
     torch.cuda.synchronize(dev)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
-    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    kernel_ms = [e[0].elapsed_time(e[1]) for e in ev]
+    gather_ms = [e[1].elapsed_time(e[2]) for e in ev] if world > 1 else [0.0] * steps
     if world > 1:
         w = torch.tensor([wall], dtype=torch.float64, device=_coll_device(dev))
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
-    return wall, kernel_ms
+    return wall, kernel_ms, gather_ms
 
 
 def dense_section(args):
@@ -249,16 +273,106 @@ def cpu_baseline(args):
                       f"{steps} attempted steps in {t_used:.1f} s (oracle/hlm_oracle.c, gcc -O2 -fopenmp)"}
 
 
+def self_launch(args):
+    """``python bench.py --gpus N`` outside torchrun: start the N ranks as a FRESH child process
+    tree (never a re-exec of this one; this process has imported neither torch nor the HIP
+    library), relay rank 0's JSON line and return the child's exit code."""
+    import socket
+    import subprocess
+    port = args.master_port
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")  # what torchrun would set (with a warning) for every rank
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # ranks' stderr passes through
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:  # rank 0's result line
+            line = ln
+        elif ln.strip():
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        print("bench.py: the ranks exited 0 without printing a result line", file=sys.stderr)
+        return 1
+    return p.returncode
+
+
+def rehearse(args):
+    """The N > 1 plumbing without a GPU (tests/test_bench_launcher.py): every rank builds the result
+    blob of its shard from a per-hillslope signature instead of integrating, then runs the same
+    gather + checks + timing protocol as a real pass.  Measures nothing: value is null."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.shard import gather_blobs, result_blob_bytes, shard_bounds
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    total = total_hillslopes(args, world)
+
+    def blob_of(r):
+        start, count = shard_bounds(total, world, r)
+        sp = synth.model204_params(start, count)
+        b = torch.zeros(result_blob_bytes(count), dtype=torch.uint8)
+        c8 = -(-count // 2) * 2
+        b[:count * 40].view(torch.float64).view(count, 5).copy_(
+            torch.from_numpy(np.stack([sp["Hu"], sp["n_mann"], sp["slope"], sp["L"], sp["A_h"]], axis=1)))
+        for k, mod in enumerate((3, 1000, 900)):
+            b[count * 40 + k * c8 * 4:count * 40 + (k + 1) * c8 * 4].view(torch.int32)[:count].copy_(
+                torch.from_numpy((sp["stream"] % mod).astype(np.int32)))
+        return b, count
+
+    mine, count = blob_of(rank)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.warmup + args.steps):
+        g = gather_blobs(mine, total) if world > 1 else [mine]
+    if world > 1:
+        dist.barrier()
+    wall = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    counts = torch.tensor([float(count)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(wall, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts)
+    ok = True
+    if rank == 0:
+        ok = len(g) == world and all(torch.equal(g[r], blob_of(r)[0]) for r in range(world))
+        print(json.dumps({"metric": "rehearsal (launch + shard + gather plumbing only; nothing integrated)",
+                          "value": None, "unit": "hillslope-ODE-steps/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "scaling": args.scaling, "data": "signature",
+                          "hillslopes_total": int(counts.item()), "gather_ok": bool(ok),
+                          "shards": [shard_bounds(total, world, r)[1] for r in range(world)],
+                          "wall_s_max_over_ranks": float(wall.item())}))
+    if world > 1:
+        dist.destroy_process_group()
+    if not ok:
+        sys.exit(3)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if args.rehearse:
+        return rehearse(args)
+    _load()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-        args.gpus = world
+    args.gpus = world  # under torchrun the launcher's world size is authoritative
     ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > max(ndev, 0):
+        raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, this node shows {ndev} "
+                         "(--backend gloo rehearses N ranks on fewer cards)")
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
     if world > 1:
@@ -269,22 +383,29 @@ def main():
             dist.init_process_group("gloo")
 
     eng, total = build_engine(args, rank, world, wet=False)
-    wall, kernel_ms = timed_passes(eng, total, world, args.warmup, args.steps)
+    wall, kernel_ms, gather_ms = timed_passes(eng, total, world, args.warmup, args.steps)
     cdev = _coll_device(eng.device) if world > 1 else eng.device
     attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=cdev)
     flagged = torch.tensor([float((eng.stiff != 0).sum().item())], dtype=torch.float64, device=cdev)
+    per_rank = None
     if world > 1:
         dist.all_reduce(attempts)
         dist.all_reduce(flagged)
-    if world > 1:
+        # per-rank view for the line: hillslopes, mean kernel ms, mean gather ms (as seen by that rank)
+        mine = torch.tensor([float(eng.ns), float(np.mean(kernel_ms)), float(np.mean(gather_ms))],
+                            dtype=torch.float64, device=cdev)
+        allr = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = [{"rank": r, "hillslopes": int(v[0].item()), "kernel_ms": float(v[1].item()),
+                     "gather_ms": float(v[2].item())} for r, v in enumerate(allr)]
         # sanity of the gather (outside the timed region): rank 0 must hold every shard's blob,
-        # and the step counters inside it must add up to the all-reduced total
-        g = gather_results(eng, world)
+        # and the step counters inside them must add up to the all-reduced total
+        g = gather_results(eng, total, world)
         if rank == 0:
-            assert g.shape[0] == world and torch.equal(g[0].to(eng.result_blob.device), eng.result_blob)
+            assert len(g) == world and torch.equal(g[0].to(eng.result_blob.device), eng.result_blob)
             tot = 0
             for r in range(world):
-                _, _, natt, _ = ShardEngine.split_result_blob(g[r], eng.ns)
+                _, _, natt, _ = ShardEngine.split_result_blob(g[r], shard_bounds(total, world, r)[1])
                 tot += int(natt.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
             assert tot == int(attempts.item()), (tot, attempts.item())
     attempts_all = float(attempts.item())          # over all ranks, per pass
@@ -303,35 +424,39 @@ def main():
     hbm_gbs = algo_bytes / (k_ms * 1e-3) / 1e9
     valu_tf = algo_flops / (k_ms * 1e-3) / 1e12
 
-    workload = ("C3: Model 204, %d hillslopes/GPU (%d total), %d-day window, hourly pr + daily t2m "
+    workload = ("%s: Model 204, %d hillslopes/GPU (%d total), %d-day window, hourly pr + daily t2m "
                 "on a 32x32 grid (%s layout), rtol 1e-6 atol 1e-9 h0 0.01, %s, math=%s"
-                % (eng.ns, total, args.days, args.layout,
+                % ("C3" if args.scaling == "weak" else "C4 (strong scaling, reference split rule)",
+                   eng.ns, total, args.days, args.layout,
                    "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})", args.math))
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/); only quoted
     # when they were collected on this same per-GPU workload
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("hillslopes_per_gpu") == eng.ns and tj.get("per_gpu_key") == _per_gpu_key(args, nq):
+            if tj.get("hillslopes_per_gpu") == eng.ns and tj.get("per_gpu_key") == _per_gpu_key(args, nq, eng.ns):
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_source = ("not measured in this run: rocprofv3 PMC passes committed as "
+                                  "profiles/traffic_latest.json (tag %s)" % tj.get("tag", "?"))
         except Exception:
             traffic = None
 
     out = {
         "metric": "hillslope-ODE-steps/sec", "value": value, "unit": "hillslope-ODE-steps/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": workload, "hillslopes_per_gpu": eng.ns, "parallelism": f"shard{world}",
-                   "per_gpu_key": _per_gpu_key(args, nq)},
+        "config": {"workload": workload, "hillslopes_per_gpu": eng.ns, "hillslopes_total": total,
+                   "parallelism": f"shard{world}", "backend": args.backend if world > 1 else None,
+                   "per_gpu_key": _per_gpu_key(args, nq, eng.ns)},
         # The kernel is an FP64 per-lane ODE integrator: its binding roofline is the FP64
         # vector ALU, not HBM and not MFMA (north_star: "no MFMA").  Both are reported:
         # "roofline" = HBM as BASELINE.json's north_star asks (algorithmic bytes / kernel
         # time), "roofline_valu_fp64" = the compute roofline that actually bounds it.
         "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                     "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": traffic,
+                     "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_ms,
                      "kernel": "hlm::rk45_multi_kernel<Model204Dev>",
                      "note": "0.19 algorithmic bytes per RK45 step: this kernel cannot be HBM-bound; its binding "
@@ -342,6 +467,10 @@ def main():
         "attempts_per_pass": attempts_all, "attempts_per_hillslope": attempts_all / total,
         "flagged_fraction": float(flagged.item()) / total, "kernel_ms_each": kernel_ms,
     }
+    if world > 1:
+        out["per_rank"] = per_rank   # hillslopes, mean kernel ms and mean end-of-run gather ms of every rank
+        out["gather_ms_rank0_each"] = gather_ms
+        out["gather_bytes_per_pass"] = 52.0 * total
 
     if not args.no_variants and rank == 0 and world == 1:
         # extra single passes of the same shard: wet surface store (the Manning x^(2/3)
@@ -353,7 +482,7 @@ def main():
                                 ("variant_%s_math" % other, False, other),
                                 ("variant_%s_math_wet_surface" % other, True, other)):
             engv, _ = build_engine(args, rank, world, wet=wet, math=math)
-            wallv, kms = timed_passes(engv, total, 1, 1, 1)
+            wallv, kms, _ = timed_passes(engv, total, 1, 1, 1)
             av = engv.total_attempts()
             out[name] = {"value": av / wallv, "unit": "hillslope-ODE-steps/s", "kernel_ms": kms[0], "math": math,
                          "attempts_per_hillslope": av / engv.ns,

@@ -49,13 +49,19 @@ typedef enum {
 #define HLM_SYS_STIFF 1
 #define HLM_SYS_CAPPED 2
 
-/* math mode: 0 = strict (IEEE divide, OCML pow: same operation structure as the
- * reference, FMA-contracted like nvcc's default); 1 = fast (reciprocal multiplies,
- * specialised x^(2/3) and x^(1/5); within the stated parity tolerance).  One behavioural
- * difference: a NaN / Inf state component is carried along silently in strict mode, as in the
- * reference (its error norm skips NaN ratios); in fast mode it poisons the error norm, every
- * attempt is rejected and the system is flagged (stiff = 1, zero rows) after six rejects.
- * Fast mode needs 1e-60 <= atol <= 1e50 (its error norm multiplies the five tolerances). */
+/* Math mode.  1 = FAST, the DEFAULT of the host API: divisions by per-system constants become
+ * multiplications by their reciprocals, x^(2/3) and x^(-1/5) are evaluated by division-free series
+ * from integer / f32 seeds (<= 8e-16 relative error over the whole double range -- closer to the
+ * correctly rounded value than the OCML pow STRICT calls), the error norm uses one reciprocal.
+ * 0 = STRICT: IEEE divides and OCML pow in the reference's own operation structure (FMA-contracted
+ * like nvcc's default); 2.4x slower.  STRICT exists for two behaviours FAST does not have:
+ *  (a) a NaN / Inf state component is carried along silently, as in the reference (its error norm
+ *      skips NaN ratios); in FAST it poisons the error norm, every attempt is rejected and the
+ *      system is flagged (stiff = 1, zero rows) after six rejects;
+ *  (b) any atol >= 0 is accepted; FAST needs 1e-60 <= atol <= 1e50 (its error norm multiplies the
+ *      five tolerances).  Until hlm_set_math_mode() is called the host API picks FAST where (b)
+ *      holds and STRICT otherwise; an explicit hlm_device_job.math_mode is never overridden.
+ * Neither mode reproduces libdevice's pow bit for bit; both meet the stated parity tolerance. */
 #define HLM_MATH_STRICT 0
 #define HLM_MATH_FAST 1
 
@@ -137,9 +143,10 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
                            const void* d_sp);
 /* retrieve_and_free<M>: D2H of final states (h_final [ns][neq]) and dense output
  * (h_dense [ns][nq][neq] = index (s*nq+q)*neq+c, rk45_api.hpp:255-267), then free.
- * h_stiff / h_n_attempt / h_n_accept are optional (NULL to skip).  The Radau relaunch
- * of rk45_api.hpp:189-247 is out of scope: flagged systems keep
- * zero rows, exactly what the reference's host receives (its copy precedes Radau). */
+ * h_stiff / h_n_attempt / h_n_accept are optional (NULL to skip).  The Radau relaunch the
+ * reference attempts in here (rk45_api.hpp:189-247, after its copies) runs in
+ * hlm_launch_rk45_kernel instead, and only when hlm_set_radau_fallback(1) was called; by default
+ * flagged systems keep zero rows, exactly what the reference's host receives. */
 int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense,
                           int32_t* h_stiff, uint32_t* h_n_attempt, uint32_t* h_n_accept);
 /* run_rk45<M> (rk45_api.hpp:273-313): the three phases composed. */
@@ -213,8 +220,8 @@ int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream);
 /* Radau-IIA fallback (replaces radau_kernel.cu:20-140 / radau_step_dense.cuh, re-derived as
  * the standard RADAU5 scheme -- see csrc/hlm_radau_kernel.h): every system of `job` whose
  * d_stiff entry is 1 is re-integrated from (t0, y0) with the implicit 3-stage method; its
- * y_final and dense rows are overwritten, d_n_attempt is incremented by the implicit attempts,
- * d_n_accept replaced.  d_stiff stays 1 on success and becomes 2 if the attempt cap ends the run
+ * y_final and dense rows are overwritten, d_n_attempt and d_n_accept are incremented by the implicit
+ * attempts / accepted steps (same convention for both: RK45 work up to the flag + this pass).  d_stiff stays 1 on success and becomes 2 if the attempt cap ends the run
  * (final row zero; job.attempt_cap, default 2^20 implicit attempts per system for this pass).  Enqueue on the same stream after hlm_rk45_integrate_device(job).  The job
  * must be a plain one-launch job (no d_resume / t_stop / query window / forcing chunk). */
 int hlm_radau_fallback_device(const hlm_device_job* job, void* hip_stream);

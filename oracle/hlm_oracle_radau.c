@@ -279,7 +279,7 @@ static void radau_one(const hlm_oracle_job* J, int sys)
     }
 
     if (J->n_attempt) J->n_attempt[sys] += n_attempt;
-    if (J->n_accept) J->n_accept[sys] = n_accept;
+    if (J->n_accept) J->n_accept[sys] += n_accept;
     if (J->t_reached) J->t_reached[sys] = t;
     if (capped && t < J->tf) {
         J->stiff[sys] = HLM_ORACLE_CAPPED;

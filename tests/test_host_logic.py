@@ -218,3 +218,34 @@ def test_config_yaml_reader_cpp(tmp_path):
     bad.write_text("model:\n  uid: 7\n")
     r = subprocess.run([drv, "--config", str(bad)], capture_output=True, text=True)
     assert r.returncode == 1 and "model.uid 7 is not registered" in r.stderr
+
+
+def test_cpp_driver_config_places_forcings_by_role(tmp_path, golden):
+    """A YAML run configuration names its forcing variables by role; a role Model 204 reads
+    (F[0] = precipitation, F[1] = temperature, model_204.hpp:82-83) that is missing is an error at
+    parse time -- never a silent shift of the remaining variables into its slot.  (The order
+    independence of the result is a GPU test: test_cpp_driver_yaml_folder_nc_forcings_and_state_subset.)"""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "rk45_solver")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "tools")], check=True)
+    base = ("model:\n  uid: 204\ntime:\n  start: \"2021-06-01T00:00:00\"\n  end: \"2021-06-02T00:00:00\"\n"
+            f"local_params:\n  file: {golden['small_test_csv']}\nforcings:\n  type: folder_nc\n  path: /nonexistent\n"
+            "  lookup: lut.csv\n  vars:\n")
+    for vars_, msg in (("    temperature: Tair\n", "forcings.vars.precipitation is missing"),
+                       ("    precipitation: PRCP\n", "forcings.vars.temperature is missing"),
+                       ("    precipitation: PRCP\n    humidity: Q\n", "unknown role")):
+        cfg = tmp_path / "c.yaml"
+        cfg.write_text(base + vars_)
+        p = subprocess.run([exe, "--config", str(cfg), "--quiet"], capture_output=True, text=True)
+        assert p.returncode == 1 and msg in p.stderr, (vars_, p.stderr)
+
+
+def test_forcing_registration_needs_a_device(hlm):
+    """The registry slot is per HIP device: without a device the call fails loudly instead of
+    aliasing device 0's slot."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(hlm.HlmError):
+        hlm.api.clear_forcings()

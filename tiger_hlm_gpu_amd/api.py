@@ -233,7 +233,7 @@ def run_rk45(model, h_y0, t0, tf, h_query_times, d_sp, with_info=False):
 # ---- device-resident path (torch tensors as HBM buffers) ------------------------------------------
 def make_device_job(model, *, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_hours=(), forc_nT=(),
                     forc_ld=0, forc_col=None, params=None, fixed_step=0.0, attempt_cap=0,
-                    math_mode=_lib.MATH_STRICT, y_final, dense=None, stiff, n_attempt=None, n_accept=None):
+                    math_mode=_lib.MATH_FAST, y_final, dense=None, stiff, n_attempt=None, n_accept=None):
     """Fill an hlm_device_job from torch CUDA tensors (or raw int device pointers)."""
     def dp(t):
         if t is None:
@@ -300,7 +300,7 @@ def time_device(job, iters, stream=None):
     return list(ms)
 
 
-def kernel_info(model, dense=False, math_mode=_lib.MATH_STRICT):
+def kernel_info(model, dense=False, math_mode=_lib.MATH_FAST):
     v, s, l, m = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     check(lib().hlm_kernel_info(_uid(model), int(dense), int(math_mode), C.byref(v), C.byref(s), C.byref(l), C.byref(m)))
     return {"vgprs": v.value, "scratch_bytes": s.value, "lds_bytes": l.value, "max_threads": m.value}

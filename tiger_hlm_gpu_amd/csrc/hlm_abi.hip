@@ -50,7 +50,12 @@ ModelState g_models[2] = {
 };
 uint32_t g_cap = 1u << 24;
 int g_stream_path = 0;  // hlm_set_stream_path(): 0 copy engine (default), 1 transposing transfer kernel
-int g_math = HLM_MATH_STRICT;
+// Default arithmetic of the host API: FAST (the measured-more-accurate and 2.4x faster of the two,
+// DESIGN.md "Math modes").  Until hlm_set_math_mode() is called the choice is automatic: FAST wherever
+// its one precondition holds (1e-60 <= atol <= 1e50), STRICT otherwise -- a reference-style caller
+// with any tolerances the reference accepts gets a result, and with the usual ones the fast kernel.
+int g_math = HLM_MATH_FAST;
+bool g_math_explicit = false;
 int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
 
 struct ForcingState {
@@ -63,17 +68,32 @@ struct ForcingState {
     const float* h_tables[HLM_MAX_FORCINGS] = {};  // hlm_set_forcings_host: series kept on the host
     double chunk_minutes = 0.0;                     // > 0: stream them in time chunks
 };
-// one registration per HIP device: d_forc is a device pointer, and a host process may drive
-// several GPUs (one thread each) through the host-buffer API
+// One registration per HIP device (d_forc is a device pointer, and a host process may drive several
+// GPUs, one thread each, through the host-buffer API) -- and, like the reference's global symbols,
+// ONE host-API integration in flight per device: hlm_launch_rk45_kernel marks the slot busy while it
+// runs and a registration change on a busy slot is refused (HLM_ERR_STATE) instead of racing with it.
 constexpr int kMaxDevices = 64;
-ForcingState g_forc_dev[kMaxDevices];
-ForcingState& forc_state()
+struct ForcingSlot {
+    ForcingState f;
+    int in_flight = 0;
+};
+ForcingSlot g_forc_dev[kMaxDevices];
+// slot of the calling thread's current device; NULL (with the error text set) when there is none
+ForcingSlot* forc_slot()
 {
     int d = 0;
-    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) { (void)hipGetLastError(); d = 0; }
-    return g_forc_dev[d];
+    const hipError_t e = hipGetDevice(&d);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        fail(HLM_ERR_HIP, "hipGetDevice failed: %s", hipGetErrorString(e));
+        return nullptr;
+    }
+    if (d < 0 || d >= kMaxDevices) {
+        fail(HLM_ERR_HIP, "device index %d outside the registry (%d slots)", d, kMaxDevices);
+        return nullptr;
+    }
+    return &g_forc_dev[d];
 }
-#define g_forc forc_state()
 
 ModelState* find_model(int uid)
 {
@@ -272,9 +292,8 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     return HLM_SUCCESS;
 }
 
-int fill_job_from_registry(hlm_device_job* j, int uid)
+int fill_job_from_registry(hlm_device_job* j, int uid, const ForcingState& F)
 {
-    std::lock_guard<std::mutex> lk(g_mu);
     ModelState* m = find_model(uid);
     if (!m) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
     j->uid = uid;
@@ -282,12 +301,26 @@ int fill_job_from_registry(hlm_device_job* j, int uid)
     j->fixed_step = m->fixed_step;
     j->attempt_cap = g_cap;
     j->math_mode = g_math;
-    j->d_forc = g_forc.d_forc;
-    j->d_forc_col = g_forc.d_col;
-    j->forc_ld = g_forc.ld;
-    j->nforc = g_forc.nforc;
-    std::memcpy(j->forc_dt_hours, g_forc.dt_h, sizeof(g_forc.dt_h));
-    std::memcpy(j->forc_nT, g_forc.nT, sizeof(g_forc.nT));
+    if (!g_math_explicit && !(m->p[2] >= 1e-60 && m->p[2] <= 1e50)) j->math_mode = HLM_MATH_STRICT;
+    j->d_forc = F.d_forc;
+    j->d_forc_col = F.d_col;
+    j->forc_ld = F.ld;
+    j->nforc = F.nforc;
+    std::memcpy(j->forc_dt_hours, F.dt_h, sizeof(F.dt_h));
+    std::memcpy(j->forc_nT, F.nT, sizeof(F.nT));
+    return HLM_SUCCESS;
+}
+
+// replace the calling device's registration (under g_mu); refused while an integration uses it
+int replace_forcings(const ForcingState& next)
+{
+    ForcingSlot* slot = forc_slot();
+    if (!slot) return HLM_ERR_HIP;
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (slot->in_flight)
+        return fail(HLM_ERR_STATE, "the forcing registration of this device is in use by a running "
+                                   "hlm_launch_rk45_kernel / hlm_run_rk45 (one host-API integration per device)");
+    slot->f = next;
     return HLM_SUCCESS;
 }
 
@@ -410,6 +443,7 @@ int hlm_set_math_mode(int mode)
         return fail(HLM_ERR_INVALID_ARGUMENT, "math mode %d", mode);
     std::lock_guard<std::mutex> lk(g_mu);
     g_math = mode;
+    g_math_explicit = true;
     return HLM_SUCCESS;
 }
 
@@ -420,17 +454,16 @@ int hlm_set_forcings(const float* d_forc, const double* dt_hours, const uint64_t
         return fail(HLM_ERR_INVALID_ARGUMENT, "nforc %d outside [0,%d]", nforc, HLM_MAX_FORCINGS);
     if (nforc > 0 && (!d_forc || !dt_hours || !nT || ld <= 0))
         return fail(HLM_ERR_INVALID_ARGUMENT, "forcings need d_forc, dt_hours, nT and ld > 0");
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_forc = ForcingState{};
-    g_forc.d_forc = d_forc;
-    g_forc.d_col = d_col;
-    g_forc.ld = ld;
-    g_forc.nforc = nforc;
+    ForcingState F;
+    F.d_forc = d_forc;
+    F.d_col = d_col;
+    F.ld = ld;
+    F.nforc = nforc;
     for (int k = 0; k < nforc; ++k) {
-        g_forc.dt_h[k] = dt_hours[k];
-        g_forc.nT[k] = nT[k];
+        F.dt_h[k] = dt_hours[k];
+        F.nT[k] = nT[k];
     }
-    return HLM_SUCCESS;
+    return replace_forcings(F);
 }
 
 int hlm_set_forcings_host(const float* const* h_tables, const double* dt_hours, const uint64_t* nT, int nforc,
@@ -438,9 +471,7 @@ int hlm_set_forcings_host(const float* const* h_tables, const double* dt_hours, 
 {
     if (nforc <= 0 || nforc > HLM_MAX_FORCINGS || !h_tables || !dt_hours || !nT || ld <= 0 || !(chunk_minutes > 0.0))
         return fail(HLM_ERR_INVALID_ARGUMENT, "set_forcings_host: need 1..%d host tables, dt, nT, ld > 0, chunk > 0", HLM_MAX_FORCINGS);
-    std::lock_guard<std::mutex> lk(g_mu);
-    ForcingState& F = g_forc;
-    F = ForcingState{};
+    ForcingState F;
     F.d_col = d_col;
     F.ld = ld;
     F.nforc = nforc;
@@ -451,15 +482,10 @@ int hlm_set_forcings_host(const float* const* h_tables, const double* dt_hours, 
         F.dt_h[k] = dt_hours[k];
         F.nT[k] = nT[k];
     }
-    return HLM_SUCCESS;
+    return replace_forcings(F);
 }
 
-int hlm_clear_forcings(void)
-{
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_forc = ForcingState{};
-    return HLM_SUCCESS;
-}
+int hlm_clear_forcings(void) { return replace_forcings(ForcingState{}); }
 
 // ---- device-resident core --------------------------------------------------------------
 int hlm_rk45_integrate_device(const hlm_device_job* job, void* hip_stream)
@@ -724,21 +750,19 @@ int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters,
     int rc = validate_job(job);
     if (rc != HLM_SUCCESS) return rc;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
-    hipEvent_t e0, e1;
-    HLM_HIP_TRY(hipEventCreate(&e0));
-    HLM_HIP_TRY(hipEventCreate(&e1));
-    for (int i = 0; i < iters; ++i) {
-        HLM_HIP_TRY(hipEventRecord(e0, s));
-        if (job->num_systems > 0) {
-            rc = launch(job, s);
-            if (rc != HLM_SUCCESS) break;
-        }
-        HLM_HIP_TRY(hipEventRecord(e1, s));
-        HLM_HIP_TRY(hipEventSynchronize(e1));
-        HLM_HIP_TRY(hipEventElapsedTime(&ms[i], e0, e1));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    for (int i = 0; i < iters && e == hipSuccess && rc == HLM_SUCCESS; ++i) {
+        e = hipEventRecord(e0, s);
+        if (e == hipSuccess && job->num_systems > 0) rc = launch(job, s);
+        if (e == hipSuccess && rc == HLM_SUCCESS) e = hipEventRecord(e1, s);
+        if (e == hipSuccess && rc == HLM_SUCCESS) e = hipEventSynchronize(e1);
+        if (e == hipSuccess && rc == HLM_SUCCESS) e = hipEventElapsedTime(&ms[i], e0, e1);
     }
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    if (e0) (void)hipEventDestroy(e0);  // on every exit path
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(HLM_ERR_HIP, "rk45_time_device: %s", hipGetErrorString(e));
     return rc;
 }
 
@@ -827,10 +851,29 @@ int hlm_setup_gpu_buffers(const double* h_y0, int ns, const double* h_q, int nq,
 int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double tf, const void* d_sp)
 {
     if (!b) return fail(HLM_ERR_INVALID_ARGUMENT, "buffers are NULL");
+    ForcingSlot* slot = forc_slot();
+    if (!slot) return HLM_ERR_HIP;
     hlm_device_job j;
     std::memset(&j, 0, sizeof(j));
-    int rc = fill_job_from_registry(&j, uid);
-    if (rc != HLM_SUCCESS) return rc;
+    const float* host_tables[HLM_MAX_FORCINGS];
+    double chunk_minutes = 0.0;
+    int radau = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (slot->in_flight)
+            return fail(HLM_ERR_STATE, "another hlm_launch_rk45_kernel / hlm_run_rk45 is running on this device "
+                                       "with the same forcing registration (one host-API integration per device)");
+        const int rc0 = fill_job_from_registry(&j, uid, slot->f);
+        if (rc0 != HLM_SUCCESS) return rc0;
+        chunk_minutes = slot->f.chunk_minutes;
+        std::memcpy(host_tables, slot->f.h_tables, sizeof(host_tables));
+        radau = g_radau;
+        slot->in_flight = 1;
+    }
+    struct Release {  // every exit path frees the slot again
+        ForcingSlot* s;
+        ~Release() { std::lock_guard<std::mutex> lk(g_mu); s->in_flight = 0; }
+    } release{slot};
     j.num_systems = b->num_systems;
     j.num_queries = b->num_queries;
     j.t0 = t0;
@@ -843,20 +886,11 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     j.d_stiff = b->d_stiff;
     j.d_n_attempt = b->d_n_attempt;
     j.d_n_accept = b->d_n_accept;
-    const float* host_tables[HLM_MAX_FORCINGS];
-    double chunk_minutes = 0.0;
-    int radau = 0;
-    {
-        std::lock_guard<std::mutex> lk(g_mu);
-        const ForcingState& F = g_forc;
-        chunk_minutes = F.chunk_minutes;
-        std::memcpy(host_tables, F.h_tables, sizeof(host_tables));
-        radau = g_radau;
-    }
     const bool streamed = chunk_minutes > 0.0 && uid != HLM_UID_DUMMY;
     if (streamed && radau)
         return fail(HLM_ERR_INVALID_ARGUMENT, "the Radau fallback needs the forcing series resident in HBM "
                                               "(hlm_set_forcings), not streamed in time chunks");
+    int rc;
     if (streamed)
         rc = hlm_rk45_integrate_forcing_streamed(&j, host_tables, chunk_minutes, nullptr, nullptr);
     else

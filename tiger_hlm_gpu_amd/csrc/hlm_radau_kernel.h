@@ -378,8 +378,10 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
         }
     }
 
+    // both counters ACCUMULATE: after the fallback they hold the RK45 work spent on the system up to
+    // its flag plus the implicit attempts / accepted steps of this pass
     if (A.n_attempt) A.n_attempt[sys] += n_attempt;
-    if (A.n_accept) A.n_accept[sys] = n_accept;
+    if (A.n_accept) A.n_accept[sys] += n_accept;
     const bool failed = capped && t < tf;
     if (failed) A.stiff[sys] = HLM_SYS_CAPPED;  // success leaves the RK45 flag in place (rk45_api.hpp:189-247 does)
 #pragma unroll

@@ -366,12 +366,17 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     if (resume_i && A.resume_in) {
         const int st = resume_i[(size_t)4 * A.ns + sys];
         if (st != SYS_PAUSED) {
-            // finished or flagged in an earlier launch: outputs were written then; the dense
-            // slots it never reaches are 0
+            // Finished or flagged in an earlier launch: its outputs were written then.  With a
+            // per-window dense buffer (query windows) the slots of THIS window were never reached
+            // and are 0.  With the whole query range in one buffer (time chunks / checkpoints)
+            // the launch that finished the lane already zero-filled [next_q, nq) and the rows
+            // before that hold its results: nothing may be touched.
             if constexpr (DENSE) {
-                for (int q = qb; q < qe; ++q) {
+                if (qb != 0 || qe != A.nq) {
+                    for (int q = qb; q < qe; ++q) {
 #pragma unroll
-                    for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * q_stride + c] = 0.0;
+                        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * q_stride + c] = 0.0;
+                    }
                 }
             }
             return;

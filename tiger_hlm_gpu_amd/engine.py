@@ -14,7 +14,7 @@ from .models import Parameters, SP_DTYPE
 
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
-                 math_mode=_lib.MATH_STRICT, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
+                 math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
                  dense_tiled=False):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():

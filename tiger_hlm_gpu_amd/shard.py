@@ -43,3 +43,35 @@ def gather_to_root(local, total, group=None, root=0):
         return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
     dist.gather(pad, gather_list=None, dst=root, group=group)
     return None
+
+
+def result_blob_bytes(count, n_eq=5):
+    """Size of a ShardEngine.result_blob of ``count`` hillslopes (y_final | stiff | n_attempt |
+    n_accept, the int32 sections padded to an even count)."""
+    c8 = -(-int(count) // 2) * 2
+    return int(count) * 8 * n_eq + 3 * c8 * 4
+
+
+def gather_blobs(blob, total, group=None, root=0, n_eq=5):
+    """The end-of-run gather as ONE collective: every rank's result blob (uint8, 52 B per
+    hillslope) to ``root``.  Returns the list of per-rank blobs (each cut to its own length) on
+    root, None elsewhere.  Shards of unequal size (``total`` not divisible by the world size) are
+    padded to the longest blob for the collective."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return [blob]
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if blob.is_cuda and dist.get_backend(group) == "gloo":
+        blob = blob.cpu()
+    sizes = [result_blob_bytes(shard_bounds(total, world, r)[1], n_eq) for r in range(world)]
+    assert blob.numel() == sizes[rank], (blob.numel(), sizes[rank])
+    smax = max(sizes)
+    pad = blob
+    if blob.numel() != smax:
+        pad = torch.zeros(smax, dtype=blob.dtype, device=blob.device)
+        pad[: blob.numel()] = blob
+    if rank == root:
+        bufs = [torch.empty_like(pad) for _ in range(world)]
+        dist.gather(pad, gather_list=bufs, dst=root, group=group)
+        return [b[:n] for b, n in zip(bufs, sizes)]
+    dist.gather(pad, gather_list=None, dst=root, group=group)
+    return None

@@ -19,6 +19,7 @@
 #include <fstream>
 #include <iostream>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -52,7 +53,7 @@ struct Options {
     std::string init_file;        // "hot" start: CSV, one row of N_EQ states per hillslope (parameter-file order)
     std::vector<int> states;      // subset of states written to the NetCDF outputs (empty = all)
     bool scipy_h0 = false;
-    std::string math = "strict";
+    std::string math;  // "fast" | "strict"; empty = the library default (FAST where its atol range allows)
     std::string out_final = "final.csv", out_dense = "dense.csv";
     // NetCDF forcings "file:var:dt_hours" in forcing order (main.cpp:513-514: pr 1 h, t2m 24 h)
     std::vector<std::string> forcing_nc;
@@ -98,13 +99,25 @@ void apply_config(Options& o, const std::string& path)
     if (c.auto_initial_step) o.scipy_h0 = true;  // "null -> auto-scaled": the driver's SciPy-style guess (main.cpp:615-631)
     else o.initial_step = c.initial_step;
     if (c.forcing_type == "folder_nc") {
-        // one file per variable, <path>/<variable>.nc; sample spacing by role as main.cpp:513-514 (pr 1 h, t2m 24 h)
+        // One file per variable, <path>/<variable>.nc.  A variable is placed by its ROLE, not by its
+        // position in the file: the model reads F[0] as rainfall and F[1] as temperature
+        // (model_204.hpp:82-83), sampled every 1 h and 24 h (main.cpp:513-514).  A model that reads
+        // forcings needs every role; nothing is shifted into a missing role's slot.
+        static const struct { const char* role; double dt_h; } kSlots[] = {{"precipitation", 1.0}, {"temperature", 24.0}};
+        constexpr size_t nslots = sizeof(kSlots) / sizeof(kSlots[0]);
+        std::string spec[nslots];
         for (const auto& rv : c.forcing_vars) {
-            double dt_h;
-            if (rv.first == "precipitation") dt_h = 1.0;
-            else if (rv.first == "temperature") dt_h = 24.0;
-            else throw std::runtime_error("config: forcings.vars." + rv.first + ": unknown role (precipitation, temperature)");
-            o.forcing_nc.push_back(c.forcing_path + "/" + rv.second + ".nc:" + rv.second + ":" + std::to_string(dt_h));
+            size_t k = 0;
+            while (k < nslots && rv.first != kSlots[k].role) ++k;
+            if (k == nslots) throw std::runtime_error("config: forcings.vars." + rv.first + ": unknown role (precipitation, temperature)");
+            if (!spec[k].empty()) throw std::runtime_error("config: forcings.vars." + rv.first + " is given twice");
+            spec[k] = c.forcing_path + "/" + rv.second + ".nc:" + rv.second + ":" + std::to_string(kSlots[k].dt_h);
+        }
+        for (size_t k = 0; k < nslots; ++k) {
+            if (spec[k].empty())
+                throw std::runtime_error(std::string("config: forcings.vars.") + kSlots[k].role + " is missing (Model 204 reads F[" +
+                                         std::to_string(k) + "] = " + kSlots[k].role + ")");
+            o.forcing_nc.push_back(spec[k]);
         }
         o.lookup = c.forcing_lookup;
     }
@@ -275,7 +288,10 @@ int run(const Options& o, hlm_io::CsvStyle style)
         hp.initialStep = scipy_initial_step<Model>(spatial.data(), f0.data(), (int)f0.size(), o.rtol, o.atol);
     }
     rk45_api::setModelParameters<Model>(hp);
-    rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
+    if (!o.math.empty()) {
+        if (o.math != "fast" && o.math != "strict") usage("--math must be fast or strict");
+        rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
+    }
     rk45_api::set_radau_fallback(o.radau);
 
     // ---- initial state and query grid --------------------------------------------------------------------
@@ -337,12 +353,18 @@ int run(const Options& o, hlm_io::CsvStyle style)
     std::vector<int32_t> stiff(ns, 0);
     std::vector<uint32_t> n_attempt(ns, 0);
     std::vector<std::string> errors(G);
+    // The host API keeps ONE forcing registration per device, like the reference's global symbols
+    // (forcing_data.cu:5-10): from set_forcings to clear_forcings a shard owns its device.  With
+    // --oversubscribe several shards share a device and take turns.
+    std::vector<std::mutex> device_turn((size_t)std::max(ndev, 1));
     auto run_shard = [&](int r) {
         try {
             const int base = ns / G, rem = ns % G;
             const int start = r * base + std::min(r, rem), count = base + (r < rem ? 1 : 0);
             if (count == 0) return;
-            rk45_api::detail::check(hlm_set_device(G > 1 ? (o.device + r) % std::max(ndev, 1) : o.device), "hlm_set_device");
+            const int dev = G > 1 ? (o.device + r) % std::max(ndev, 1) : o.device;
+            std::lock_guard<std::mutex> turn(device_turn[(size_t)std::min(std::max(dev, 0), std::max(ndev, 1) - 1)]);
+            rk45_api::detail::check(hlm_set_device(dev), "hlm_set_device");
             SpatialParams* d_sp = rk45_api::device_upload(spatial.data() + start, (size_t)count);
             float* d_forc = nullptr;
             int32_t* d_col = nullptr;
