@@ -60,3 +60,85 @@ def assert_parity(a, b, what=""):
 def fmt6(x):
     """Default std::ostream formatting of a double: 6 significant digits (%g)."""
     return "%g" % x
+
+
+# ---- the yardstick: is a hillslope well-conditioned at the level of the parity bound? ----------------
+# The GPU kernel contracts FMAs, hoists reciprocals and (FAST) uses its own roots; on a well-conditioned
+# hillslope that moves the result by ~1e-4 OF the parity bound (the 50 000-hillslope C3 test: max 5e-4).
+# A hillslope that sits on a discrete event (a reject that becomes an accept, a store reaching capacity,
+# the six rejects that flag a system) is different: ANY change of rounding can move its result by more
+# than the bound -- including the oracle's own text compiled with FMA contraction
+# (oracle/libhlm_oracle_fma.so), and either implementation run with rtol or the first step changed
+# by a relative 1e-12 .. 1e-10.  Those runs are the yardstick.  A hillslope is SHOWN ILL-CONDITIONED when
+# a yardstick run moves the oracle's (or the GPU's) own result by at least half the parity bound, or
+# at least as far as the GPU result is from the oracle, or flips its stiff flag: no two correct
+# implementations can be expected to agree on it within the bound.  Tests assert: every hillslope is within
+# the bound with the oracle's flag OR individually shown ill-conditioned, and the number of the latter
+# does not exceed a committed count.
+DEFAULT_PARAMS = (0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0)
+# (relative change of rtol, relative change of initialStep)
+YARDSTICK_PERTURBATIONS = ((1e-12, 0.0), (-1e-12, 0.0), (1e-11, 0.0), (-1e-11, 0.0), (1e-10, 0.0), (-1e-10, 0.0),
+                           (0.0, 1e-12), (0.0, -1e-12))
+
+
+def perturbed_params(params, e_rtol, e_h0):
+    p = list(params)
+    p[0] *= 1.0 + e_h0
+    p[1] *= 1.0 + e_rtol
+    return tuple(p)
+
+
+def yardstick_runs(oracle, uid, y0, t0, tf, params=DEFAULT_PARAMS, perturbations=YARDSTICK_PERTURBATIONS[:2], **kw):
+    """The oracle's FMA build + the plain oracle under each perturbation (default: rtol * (1 +- 1e-12))."""
+    alts = [oracle.run(uid, y0, t0, tf, params=params, fma=True, **kw)]
+    alts += [oracle.run(uid, y0, t0, tf, params=perturbed_params(params, er, eh), **kw) for er, eh in perturbations]
+    return alts
+
+
+def scaled_deviation(a, ref, names):
+    """Per hillslope: max over the values of `names` of |a - ref| / (1e-9 + 1e-6 |ref|)  (1.0 = the
+    stated parity bound).  Rows one side never wrote (zeros after a flag) count like any other value."""
+    ns = ref[names[0]].shape[0]
+    dev = np.zeros(ns)
+    for n in names:
+        if ref.get(n) is None:
+            continue
+        tol = PARITY_ATOL + PARITY_RTOL * np.abs(ref[n])
+        with np.errstate(invalid="ignore"):
+            d = (np.abs(a[n] - ref[n]) / tol).reshape(ns, -1)
+        dev = np.maximum(dev, np.where(np.isnan(d), np.inf, d).max(axis=1))
+    return dev
+
+
+def parity_or_shown_ill_conditioned(got, ref, alts, names=("y_final", "dense"), got_alts=()):
+    """Returns (within, exempt, dev, spread) per hillslope.
+    within = the oracle's stiff flag and every value inside the parity bound;
+    spread = how far the yardstick runs move a result: max over `alts` (oracle variants, against the
+             oracle) and `got_alts` (GPU runs with perturbed parameters, against the GPU run);
+    exempt = not within, and shown ill-conditioned: a yardstick run flips the flag, or spread >= 0.5
+             (half the parity bound), or spread >= the GPU's deviation from the oracle."""
+    dev = scaled_deviation(got, ref, names)
+    spread = np.max([scaled_deviation(a, ref, names) for a in alts], axis=0)
+    flips = np.any([a["stiff"] != ref["stiff"] for a in alts], axis=0)
+    for g in got_alts:
+        spread = np.maximum(spread, scaled_deviation(g, got, names))
+        flips |= g["stiff"] != got["stiff"]
+    within = (got["stiff"] == ref["stiff"]) & (dev <= 1.0)
+    shown = flips | (spread >= 0.5) | (spread >= dev)
+    return within, (~within) & shown, dev, spread
+
+
+def assert_parity_with_exemptions(got, ref, alts, max_exempt, names=("y_final", "dense"), what="", got_alts=()):
+    within, exempt, dev, spread = parity_or_shown_ill_conditioned(got, ref, alts, names, got_alts)
+    bad = ~(within | exempt)
+    if os.environ.get("HLM_PARITY_DIAG"):  # development aid: per-hillslope numbers of every call
+        os.makedirs(os.environ["HLM_PARITY_DIAG"], exist_ok=True)
+        tag = "".join(c if c.isalnum() else "_" for c in what)[:60]
+        np.savez(os.path.join(os.environ["HLM_PARITY_DIAG"], f"parity_{tag}.npz"), within=within, exempt=exempt, dev=dev,
+                 spread=spread, stiff_got=got["stiff"], stiff_ref=ref["stiff"], stiff_alts=np.array([a["stiff"] for a in alts]))
+    detail = [(int(i), float(dev[i]), float(spread[i]), int(got["stiff"][i]), int(ref["stiff"][i])) for i in np.flatnonzero(bad)[:10]]
+    assert not bad.any(), (f"{what}: {bad.sum()} hillslopes outside the parity bound and NOT shown ill-conditioned "
+                           f"(index, dev, yardstick spread, flag got/ref): {detail}")
+    n = int(exempt.sum())
+    assert n <= max_exempt, f"{what}: {n} hillslopes needed the ill-conditioning exemption (committed: {max_exempt})"
+    return n, float(dev[within].max()) if within.any() else 0.0

@@ -122,12 +122,25 @@ def test_per_cell_table_equals_per_stream_expansion_bitwise(gpu):
         assert np.array_equal(a[k], b[k]), k
 
 
+# committed exemption counts (hillslopes the yardstick shows ill-conditioned), per math mode
+EXEMPT_STIFF_FLAGS = {0: 3, 1: 4}          # of 512 (measured on MI355X, round 2)
+
+
 @pytest.mark.parametrize("math_mode", [0, 1])
 def test_stiff_flags_and_zero_rows_match_oracle(gpu, oracle, math_mode):
     """Cold cells (T<0) make the ET stub negative: the static store grows to Hu and the
     kink flags the system (rk45_kernel.cu:160-170).  Flags, zero final rows and zeroed
-    dense tails must match the oracle."""
+    dense tails must match the oracle.
+
+    This case is ill-conditioned by construction: with T < 0 the static store GROWS exponentially
+    (rate 0.1|T|/Hu per minute) and systems that reach Hu pass through the overflow kink, so last-bit
+    differences between two valid step sequences are amplified (the gcc oracle built with and without
+    FMA contraction differs from ITSELF by 5e-4 in one of these 512 systems, and the six rejects that
+    flag a system can come at a different event).  Every hillslope must be within 1e-9 + 1e-6|y| with
+    the oracle's flag, or be individually shown ill-conditioned by the yardstick (conftest.py); the
+    number of the latter is committed above."""
     H = gpu
+    from conftest import assert_parity_with_exemptions, yardstick_runs
     from tiger_hlm_gpu_amd import synth
     ns, days = 512, 8
     sp = synth.model204_params(0, ns)
@@ -137,37 +150,23 @@ def test_stiff_flags_and_zero_rows_match_oracle(gpu, oracle, math_mode):
     q = synth.minute_queries(0.0, days * 1440.0, 120.0)
     got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT),
                       math_mode=math_mode)
-    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp,
-                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    kw = dict(query=q, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, **kw)
     assert 0 < (ref["stiff"] == 1).sum() < ns  # the case exercises both outcomes
-    mism = got["stiff"] != ref["stiff"]
-    assert mism.mean() <= 0.01, f"{mism.sum()} stiff flags differ"  # marginal rejects only
-    ok = ~mism
-    fl = ok & (ref["stiff"] == 1)
+    assert np.all(np.isfinite(got["y_final"])) and np.all(np.isfinite(got["dense"]))
+    from conftest import DEFAULT_PARAMS, YARDSTICK_PERTURBATIONS, perturbed_params
+    got_alts = [_run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode,
+                            params=H.Parameters(*perturbed_params(DEFAULT_PARAMS, er, eh))) for er, eh in YARDSTICK_PERTURBATIONS]
+    alts = yardstick_runs(oracle, oracle.UID_204, y0, 0.0, days * 1440.0, perturbations=YARDSTICK_PERTURBATIONS, **kw)
+    n, worst = assert_parity_with_exemptions(got, ref, alts, EXEMPT_STIFF_FLAGS[math_mode], what=f"cold cells, math {math_mode}",
+                                             got_alts=got_alts)
+    print(f"cold cells math={math_mode}: {n} exempt, worst in-tolerance deviation {worst:.3g} of the bound")
+    # a flagged hillslope: zero final row, and its dense rows stop for good once they stop
+    fl = got["stiff"] == 1
     assert np.all(got["y_final"][fl] == 0.0)
-    # This case is ill-conditioned by construction: with T < 0 the static store GROWS
-    # exponentially (rate 0.1|T|/Hu per minute) and systems that reach Hu pass through the
-    # overflow kink, so last-bit differences between two valid step sequences are amplified
-    # (the gcc oracle built with and without FMA contraction differs from ITSELF by 5e-4 in
-    # one of these 512 systems).  So: >= 99 % of the systems within the solver tolerance
-    # 1e-9 + 1e-6|y| and every value finite.  Every well-posed case in this file uses the
-    # solver tolerance for all values.
-    for name in ("y_final", "dense"):
-        a, b = got[name][ok], ref[name][ok]
-        d = np.abs(a - b).reshape(a.shape[0], -1)
-        bound = (1e-9 + 1e-6 * np.abs(b)).reshape(a.shape[0], -1)
-        within = np.all(d <= bound, axis=1)
-        assert within.mean() >= 0.99, (name, float(within.mean()))
-        assert np.all(np.isfinite(a)), name
-    # zeroed dense tails: a flagged hillslope's rows stop at its flag time.  The six rejects that
-    # flag it can start one step earlier or later in a different rounding of the same sequence, so
-    # the number of rows written may differ by the queries of one step (here: at most one row)
-    rows_got = (np.abs(got["dense"][ok]).sum(axis=2) > 0).sum(axis=1)
-    rows_ref = (np.abs(ref["dense"][ok]).sum(axis=2) > 0).sum(axis=1)
-    assert np.abs(rows_got - rows_ref).max() <= 1, (rows_got - rows_ref)[rows_got != rows_ref]
-    assert (rows_got != rows_ref).sum() <= (0 if math_mode == 0 else 5), int((rows_got != rows_ref).sum())
-    q_idx = np.arange(len(q))[None, :]
-    assert np.all(got["dense"][ok][q_idx >= np.maximum(rows_got, 1)[:, None] + 1] == 0.0)
+    written = np.abs(got["dense"]).sum(axis=2) > 0
+    rows = written.sum(axis=1)
+    assert np.all(written[:, 1:] == (np.arange(1, len(q))[None, :] <= rows[:, None]))  # q = 0 is at t0: never written
 
 
 def test_attempt_cap_status_matches_oracle(gpu, oracle):
@@ -707,6 +706,9 @@ def test_cpp_driver_netcdf_forcings_and_netcdf_outputs(gpu, golden, tmp_path):
 
 
 # ---- broader randomized coverage ---------------------------------------------------------------------
+EXEMPT_WIDE_RANGES = {0: 121, 1: 125}   # of 2048: 6 % of these deliberately extreme hillslopes sit on an event
+
+
 @pytest.mark.parametrize("math_mode", [0, 1])
 def test_wide_parameter_ranges_vs_oracle(gpu, oracle, math_mode):
     """Random hillslopes far outside the benchmark's ranges: saturating static stores (small Hu),
@@ -714,10 +716,12 @@ def test_wide_parameter_ranges_vs_oracle(gpu, oracle, math_mode):
     Over half of these are flagged stiff and the rest run through min/max kinks all the time,
     where two valid step sequences differ at the tolerance level: the gcc oracle built with and
     without FMA contraction agrees with ITSELF on 92 % of the unflagged systems at the solver
-    tolerance.  So the assertion is statistical: flags agree for >= 98 % of the systems; of the
-    agreeing, unflagged systems >= 88 % meet 1e-9 + 1e-6|y| in every final and dense value,
-    >= 95 % meet 1e-8 + 1e-4|y|, and every value is finite."""
+    tolerance.  Assertion: EVERY hillslope has the oracle's flag and every final / dense value within
+    1e-9 + 1e-6|y|, or is individually shown ill-conditioned by the yardstick (conftest.py: the
+    oracle's own FMA build or rtol * (1 +- 1e-12) separates from the oracle at least as far, or flips
+    the flag); the number of such exemptions is committed above.  Every value is finite."""
     H = gpu
+    from conftest import assert_parity_with_exemptions, yardstick_runs
     from tiger_hlm_gpu_amd import synth
     ns, days = 2048, 4
     rng = np.random.default_rng(1234)
@@ -733,42 +737,22 @@ def test_wide_parameter_ranges_vs_oracle(gpu, oracle, math_mode):
     cells = synth.cell_of_system(0, ns, run_len=16)
     pr, t2m, dt, nT = synth.forcing_tables(days=days, seed=5, wet_prob=0.3, intensity=3e-4, tmin=-4.0, tmax=20.0)
     q = synth.minute_queries(0.0, days * 1440.0, 45.0)
-    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT),
+    tf = days * 1440.0
+    got = _run_engine(H, H.Model204, y0, 0.0, tf, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT),
                       math_mode=math_mode, attempt_cap=400000)
-    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, attempt_cap=400000,
-                     forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    kw = dict(query=q, sp=sp, attempt_cap=400000, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, tf, **kw)
     assert np.all(np.isfinite(got["y_final"])) and np.all(np.isfinite(got["dense"]))
-    agree = got["stiff"] == ref["stiff"]
-    assert agree.mean() >= 0.98, agree.mean()
     assert 0.02 < (ref["stiff"] != 0).mean() < 0.98  # the case really mixes flagged and clean systems
-    ok = agree & (ref["stiff"] == 0)
-    d = np.concatenate([np.abs(got["y_final"][ok] - ref["y_final"][ok]),
-                        np.abs(got["dense"][ok] - ref["dense"][ok]).reshape(ok.sum(), -1)], axis=1)
-    b = np.concatenate([np.abs(ref["y_final"][ok]), np.abs(ref["dense"][ok]).reshape(ok.sum(), -1)], axis=1)
-    within = np.all(d <= 1e-9 + 1e-6 * b, axis=1)
-    assert within.mean() >= 0.88, within.mean()
-    loose = np.all(d <= 1e-8 + 1e-4 * b, axis=1)
-    assert loose.mean() >= 0.95, loose.mean()
-    fl = agree & (ref["stiff"] != 0)
-    assert np.all(got["y_final"][fl] == 0.0)
-    # The sharp form of the same statement: per hillslope, the GPU result is no further from the oracle
-    # than the tolerance plus 5x the distance at which the oracle's own yardstick runs land (the same
-    # text compiled with FMA contraction; rtol * (1 +- 1e-12)).  A hillslope can sit on a discrete
-    # event that none of the three perturbations moves, so 1 % may exceed the bound.
-    block = synth.expand_per_stream(pr, t2m, cells)
-    yard = [oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, attempt_cap=400000, forc=block, forc_dt_h=dt,
-                       forc_nT=nT, fma=True)]
-    yard += [oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, attempt_cap=400000, forc=block, forc_dt_h=dt,
-                        forc_nT=nT, params=(0.01, 1e-6 * (1.0 + e), 1e-9, 0.9, 0.2, 10.0)) for e in (1e-12, -1e-12)]
-    use = ok & np.all([yr["stiff"] == 0 for yr in yard], axis=0)
-    assert use.sum() > 0.3 * ns
-    over = np.zeros(ns)
-    for name in ("y_final", "dense"):
-        tol = 1e-9 + 1e-6 * np.abs(ref[name])
-        dev = (np.abs(got[name] - ref[name]) / tol).reshape(ns, -1).max(axis=1)
-        spread = np.max([(np.abs(yr[name] - ref[name]) / tol).reshape(ns, -1).max(axis=1) for yr in yard], axis=0)
-        over = np.maximum(over, dev / (1.0 + 5.0 * spread))
-    assert (over[use] > 1.0).mean() <= 0.01, float((over[use] > 1.0).mean())
+    assert np.all(got["y_final"][got["stiff"] != 0] == 0.0)
+    from conftest import DEFAULT_PARAMS, YARDSTICK_PERTURBATIONS, perturbed_params
+    got_alts = [_run_engine(H, H.Model204, y0, 0.0, tf, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode,
+                            attempt_cap=400000, params=H.Parameters(*perturbed_params(DEFAULT_PARAMS, er, eh)))
+                for er, eh in YARDSTICK_PERTURBATIONS]
+    alts = yardstick_runs(oracle, oracle.UID_204, y0, 0.0, tf, perturbations=YARDSTICK_PERTURBATIONS, **kw)
+    n, worst = assert_parity_with_exemptions(got, ref, alts, EXEMPT_WIDE_RANGES[math_mode], what=f"wide ranges, math {math_mode}",
+                                             got_alts=got_alts)
+    print(f"wide ranges math={math_mode}: {n} of {ns} exempt, worst in-tolerance deviation {worst:.3g} of the bound")
 
 
 @pytest.mark.parametrize("math_mode", [0, 1])
@@ -841,6 +825,39 @@ def test_full_size_idempotence_and_properties(gpu):
     assert np.all(a["y_final"][ok, 4] < 0.2) and np.all(a["y_final"][ok, 4] > 0.19)
     assert np.all(a["y_final"][:, 2] == 0.0)  # dry surface store stays exactly 0
     assert a["n_attempt"][ok].min() > 500 and a["n_attempt"].max() < 2000
+
+
+def test_c4_four_million_hillslopes_whole_equals_its_eight_shards(gpu):
+    """BASELINE config 4 size: 4 000 000 hillslopes.  Without 8 GPUs at hand the eight contiguous
+    shards of the reference's split rule (main.cpp:275-307; 500 000 each) run one after the other on
+    this GPU and must reproduce, bit for bit, the rows of the 4 M run in one launch -- the property
+    that makes the multi-GPU result independent of the number of GPUs.  Plus the oracle-free
+    properties of the C3-size test on all 4 M."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    from tiger_hlm_gpu_amd.shard import shard_bounds
+    total, days, world = 4_000_000, 2, 8
+    pr, t2m, dt, nT = synth.forcing_tables(days=days)
+
+    def run(start, count):
+        eng = ShardEngine(H.Model204, synth.model204_y0(count), 0.0, days * 1440.0, sp=synth.model204_params(start, count))
+        eng.set_forcings_per_cell((pr, t2m), synth.cell_of_system(start, count), dt, nT)
+        eng.integrate()
+        return eng.results()
+
+    whole = run(0, total)
+    ok = whole["stiff"] == 0
+    assert ok.mean() > 0.999 and np.all(np.isfinite(whole["y_final"]))
+    assert np.all(whole["y_final"][ok, 4] < 0.2) and np.all(whole["y_final"][ok, 4] > 0.19)
+    assert np.all(whole["y_final"][:, 2] == 0.0)
+    assert whole["n_attempt"][ok].min() > 500 and whole["n_attempt"].max() < 2000
+    for r in range(world):
+        start, count = shard_bounds(total, world, r)
+        assert count == 500_000
+        part = run(start, count)
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(part[k], whole[k][start:start + count]), (r, k)
 
 
 def test_cpp_driver_multi_gpu_shards_equal_single(gpu, golden, tmp_path):
@@ -1060,13 +1077,19 @@ def test_cpp_template_api_three_phases_and_errors(gpu, golden, tmp_path):
     assert p.stdout.count("OK ") == 3 and "FAILED" not in p.stdout
 
 
+EXEMPT_C3_50K = {0: 0, 1: 0}   # of 50 000: every hillslope of the benchmark workload is within the bound
+
+
 @pytest.mark.parametrize("math_mode", [0, 1])
 def test_c3_thirty_days_50k_hillslopes_vs_oracle(gpu, oracle, math_mode):
     """The benchmark workload itself (BASELINE config 3: Model 204, 30-day window, hourly pr +
     daily t2m, per-stream forcing layout) on a 50 000-hillslope slice, every hillslope compared
-    with the CPU oracle after ~16 000 adaptive steps: finals within 1e-9 + 1e-6|y|, flags equal,
-    step counts within 1 %."""
+    with the CPU oracle after ~16 000 adaptive steps: EVERY hillslope has the oracle's flag and its
+    final state within 1e-9 + 1e-6|y|, or is individually shown ill-conditioned by the yardstick
+    (conftest.py; committed count above -- 5e-5 of these hillslopes are flagged at all, each by a
+    marginal sixth reject); step counts within 1 %."""
     H = gpu
+    from conftest import assert_parity_with_exemptions, yardstick_runs
     from tiger_hlm_gpu_amd import synth
     ns, days = 50_000, 30
     start = 123_456  # an interior slice of the 1 M-hillslope shard
@@ -1074,15 +1097,14 @@ def test_c3_thirty_days_50k_hillslopes_vs_oracle(gpu, oracle, math_mode):
     y0 = synth.model204_y0(ns)
     cells = synth.cell_of_system(start, ns)
     pr, t2m, dt, nT = synth.forcing_tables(days=days)
-    got = _run_engine(H, H.Model204, y0, 0.0, days * 1440.0, sp=sp, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
-    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells),
-                     forc_dt_h=dt, forc_nT=nT)
-    agree = got["stiff"] == ref["stiff"]
-    assert agree.mean() > 0.9995, (~agree).sum()   # a marginal reject can flip a flag (5e-5 of systems are flagged at all)
-    ok = agree & (ref["stiff"] == 0)
-    d = np.abs(got["y_final"][ok] - ref["y_final"][ok])
-    within = np.all(d <= 1e-9 + 1e-6 * np.abs(ref["y_final"][ok]), axis=1)
-    assert within.mean() > 0.9995, (within.mean(), float(d.max()))
+    tf = days * 1440.0
+    got = _run_engine(H, H.Model204, y0, 0.0, tf, sp=sp, forcing=(pr, t2m, cells, dt, nT), math_mode=math_mode)
+    kw = dict(sp=sp, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, tf, **kw)
+    n, worst = assert_parity_with_exemptions(got, ref, yardstick_runs(oracle, oracle.UID_204, y0, 0.0, tf, **kw),
+                                             EXEMPT_C3_50K[math_mode], names=("y_final",), what=f"C3 50k, math {math_mode}")
+    print(f"C3 50k math={math_mode}: {n} of {ns} exempt, worst in-tolerance deviation {worst:.3g} of the bound")
+    ok = (got["stiff"] == 0) & (ref["stiff"] == 0)
     rel = np.abs(got["n_attempt"][ok].astype(float) - ref["n_attempt"][ok]) / ref["n_attempt"][ok]
     assert rel.max() < 0.01 and 15000 < got["n_attempt"][ok].mean() < 17500
 
