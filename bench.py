@@ -81,8 +81,14 @@ def parse():
     ap.add_argument("--layout", choices=["per-stream", "per-cell"], default="per-stream")
     ap.add_argument("--dense-stride", type=float, default=0.0,
                     help="minutes between dense queries (0 = no dense output)")
-    ap.add_argument("--dense-tiled", action="store_true",
-                    help="with --dense-stride: tile-major device layout (kernel measurement only)")
+    ap.add_argument("--dense-tiled", type=int, nargs="?", const=1, default=0,
+                    help="with --dense-stride: device layout of the in-HBM dense buffer (0 host order, 1 tile-row, "
+                         "2 tile-comp wave-synchronous, 3 host order wave-synchronous)")
+    ap.add_argument("--wet-surface", action="store_true",
+                    help="headline pass on the wet-surface regime (y0[2] = 0.01: the Manning x^(2/3) term in all 7 stages)")
+    ap.add_argument("--tmin", type=float, default=0.5,
+                    help="lower end of the daily temperatures; -5 is SURVEY 8d's C3 generator (cold cells get flagged stiff)")
+    ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
     ap.add_argument("--no-variants", action="store_true", help="skip the wet-surface variant pass")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-output (config 5 style) section")
     ap.add_argument("--dense-ns", type=int, default=65536)
@@ -132,7 +138,8 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}"
+    extra = (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "")
+    return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
 def _coll_device(dev):
@@ -382,7 +389,10 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    eng, total = build_engine(args, rank, world, wet=False)
+    eng, total = build_engine(args, rank, world, wet=args.wet_surface, tmin=args.tmin)
+    if args.radau:
+        plain = eng.integrate
+        eng.integrate = lambda: plain(radau=True)
     wall, kernel_ms, gather_ms = timed_passes(eng, total, world, args.warmup, args.steps)
     cdev = _coll_device(eng.device) if world > 1 else eng.device
     attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=cdev)
@@ -428,7 +438,9 @@ def main():
                 "on a 32x32 grid (%s layout), rtol 1e-6 atol 1e-9 h0 0.01, %s, math=%s"
                 % ("C3" if args.scaling == "weak" else "C4 (strong scaling, reference split rule)",
                    eng.ns, total, args.days, args.layout,
-                   "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})", args.math))
+                   "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})", args.math)
+                + (", WET surface store" if args.wet_surface else "") + (f", T in [{args.tmin:g}, 15]" if args.tmin != 0.5 else "")
+                + (", + Radau-IIA fallback" if args.radau else ""))
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/); only quoted
     # when they were collected on this same per-GPU workload
     traffic, traffic_source = None, None

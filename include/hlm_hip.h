@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HLM_ABI_VERSION 1
+#define HLM_ABI_VERSION 2
 #define HLM_NEQ 5           /* Model204::N_EQ, models/model_204.hpp:19 */
 #define HLM_MAX_FORCINGS 16 /* I_O/forcing_data.h:5 */
 
@@ -125,12 +125,15 @@ typedef struct hlm_gpu_buffers {
     double* d_y0_all;      /* [ns][neq] */
     double* d_y_final_all; /* [ns][neq] */
     double* d_query_times; /* [nq] */
-    double* d_dense_all;   /* [ns][nq][neq] -- already in the host-facing order */
+    double* d_dense_all;   /* dense rows in the device layout named by dense_layout (below) */
     int32_t* d_stiff;      /* [ns] */
     uint32_t* d_n_attempt; /* [ns] attempted RK45 steps (build's step counter) */
     uint32_t* d_n_accept;  /* [ns] */
     int num_systems;
     int num_queries;
+    int dense_layout;      /* an hlm_device_job.dense_tiled value; hlm_setup_gpu_buffers chooses 2: tile-major
+                            * [ceil(ns/64)][nq][neq][64] (the reference's device layout is [ns][neq][nq],
+                            * rk45_kernel.cu:145, and is likewise re-ordered on the way to the host) */
 } hlm_gpu_buffers;
 
 /* setup_gpu_buffers<M>: allocate the device buffers, copy h_y0 and h_query_times. */
@@ -142,7 +145,9 @@ int hlm_setup_gpu_buffers(const double* h_y0, int num_systems, const double* h_q
 int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double tf,
                            const void* d_sp);
 /* retrieve_and_free<M>: D2H of final states (h_final [ns][neq]) and dense output
- * (h_dense [ns][nq][neq] = index (s*nq+q)*neq+c, rk45_api.hpp:255-267), then free.
+ * (h_dense [ns][nq][neq] = index (s*nq+q)*neq+c, rk45_api.hpp:255-267: the device layout is
+ * transposed on the way, by a kernel writing pinned host memory directly or through a device
+ * staging buffer), then free.
  * h_stiff / h_n_attempt / h_n_accept are optional (NULL to skip).  The Radau relaunch the
  * reference attempts in here (rk45_api.hpp:189-247, after its copies) runs in
  * hlm_launch_rk45_kernel instead, and only when hlm_set_radau_fallback(1) was called; by default
@@ -193,9 +198,14 @@ typedef struct hlm_device_job {
     int query_begin, query_end;
     void* d_resume;
     int resume_in;
-    /* 0: d_dense is [ns][W][5] (W = window length, nq when no window): the host-facing order.
-     * 1: tile-major [ceil(ns/64)][W][64][5]: what hlm_rk45_integrate_streamed uses internally
-     *    (fully coalesced row stores); a caller using it must transpose itself. */
+    /* Device layout of d_dense (W = window length, nq when no window):
+     * 0: [ns][W][5], the host-facing order (free-running kernel, hlm_rk45_kernel.h: every lane stores its
+     *    rows when it has them; 1.6x write amplification at 1-minute stride);
+     * 1: tile-major [ceil(ns/64)][W][64][5], same kernel;
+     * 2: tile-major [ceil(ns/64)][W][5][64], written by the kernel with wave-synchronous stores
+     *    (hlm_rk45_dense_kernel.h): every store instruction writes 512 contiguous bytes, HBM write traffic
+     *    equals the algorithmic 40 B per row.  What the host API and hlm_rk45_integrate_streamed's
+     *    transfer-kernel path use; a caller using 1 or 2 transposes itself. */
     int dense_tiled;
     /* Time chunks / checkpoints (build feature).  use_t_stop != 0: every hillslope pauses the
      * first time its t reaches t_stop (before its next attempt; needs d_resume) and continues in

@@ -24,13 +24,14 @@ def test_library_exports_every_declared_symbol(hlm):
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
     # and the python binding covers exactly the header
     assert sorted(hlm._lib.SIGNATURES) == names
-    assert hlm._lib.lib().hlm_abi_version() == 1
+    assert hlm._lib.lib().hlm_abi_version() == 2
 
 
 def test_struct_layouts_match_header(hlm):
     assert hlm.SP_DTYPE.itemsize == 136  # parameters_loader.hpp:19-37
     assert [n for n in hlm.SP_DTYPE.names][:4] == ["stream", "next_stream", "c1", "infil"]
-    assert C.sizeof(hlm._lib.GpuBuffers) == 7 * 8 + 2 * 4 and C.sizeof(hlm._lib.StreamStats) == 40
+    assert C.sizeof(hlm._lib.GpuBuffers) == 7 * 8 + 4 * 4  # 7 pointers, 3 ints + tail padding
+    assert C.sizeof(hlm._lib.StreamStats) == 40
     j = hlm._lib.DeviceJob
     assert j.forc_dt_hours.offset % 8 == 0 and j.params.size == 48
 

@@ -563,7 +563,7 @@ def test_cpp_driver_model204_g2(gpu, golden, tmp_path):
 
 
 # ---- dense output in query windows (BASELINE config 5) ------------------------------------------
-@pytest.mark.parametrize("path", ["transfer-kernel", "copy-engine", "pageable"])
+@pytest.mark.parametrize("path", ["transfer-kernel", "transfer-kernel-tile-row", "copy-engine", "pageable"])
 @pytest.mark.parametrize("window", [1, 7, 48, 1000])
 def test_streamed_dense_equals_one_shot_bitwise(gpu, window, path):
     """The windowed run pauses a lane before it commits a step whose queries cross the
@@ -579,7 +579,7 @@ def test_streamed_dense_equals_one_shot_bitwise(gpu, window, path):
     eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     eng.integrate()
     one = eng.results()
-    H._lib.lib().hlm_set_stream_path(1 if path == "transfer-kernel" else 0)
+    H._lib.lib().hlm_set_stream_path({"transfer-kernel": 2, "transfer-kernel-tile-row": 1}.get(path, 0))
     try:
         host_out = np.full((ns, len(q), 5), np.nan) if path == "pageable" else None
         host, stats = eng.integrate_streamed(window, host_out=host_out)
@@ -612,9 +612,11 @@ def test_streamed_dense_with_flagged_systems(gpu, oracle):
     assert np.array_equal(eng.results()["stiff"], one["stiff"])
 
 
-def test_manual_window_loop_through_device_job(gpu):
+@pytest.mark.parametrize("layout", [0, 2])
+def test_manual_window_loop_through_device_job(gpu, layout):
     """The same protocol driven by the caller: consecutive hlm_rk45_integrate_device calls
-    with query_begin/query_end/d_resume."""
+    with query_begin/query_end/d_resume, the window buffers in the host order (0, free-running
+    kernel) or tile-major [tile][W][5][64] (2, the kernel with wave-synchronous stores)."""
     H = gpu
     import torch
     from tiger_hlm_gpu_amd import synth
@@ -628,14 +630,17 @@ def test_manual_window_loop_through_device_job(gpu):
     resume = torch.zeros(H.api.resume_bytes(ns), dtype=torch.uint8, device="cuda:0")
     out = np.zeros_like(one["dense"])
     W = 40
+    tiles = -(-ns // 64)
     for k, qb in enumerate(range(0, len(q), W)):
         qe = min(qb + W, len(q))
-        win = torch.empty((ns, qe - qb, 5), dtype=torch.float64, device="cuda:0")
+        win = torch.empty((tiles * 64 if layout else ns, qe - qb, 5), dtype=torch.float64, device="cuda:0")
         job = eng.job()
-        job.d_dense, job.query_begin, job.query_end = win.data_ptr(), qb, qe
+        job.d_dense, job.dense_tiled, job.query_begin, job.query_end = win.data_ptr(), layout, qb, qe
         job.d_resume, job.resume_in = resume.data_ptr(), int(k > 0)
         H.api.integrate_device(job)
         torch.cuda.synchronize()
+        if layout:
+            win = win.view(tiles, qe - qb, 5, 64).permute(0, 3, 1, 2).reshape(tiles * 64, qe - qb, 5)[:ns]
         out[:, qb:qe] = win.cpu().numpy()
     assert np.array_equal(out, one["dense"])
     assert np.array_equal(eng.results()["y_final"], one["y_final"])
@@ -958,8 +963,9 @@ def test_streamed_forcings_equal_resident_bitwise(gpu, layout, chunk):
             assert np.array_equal(got[k], ref[k]), (method.__name__, k)
 
 
+@pytest.mark.parametrize("layout", [0, 2])
 @pytest.mark.parametrize("case", ["tiny-last-chunk", "flagged-cold-cells"])
-def test_streamed_forcings_keep_the_rows_of_lanes_that_finished_early(gpu, case):
+def test_streamed_forcings_keep_the_rows_of_lanes_that_finished_early(gpu, case, layout):
     """Time-chunk launches share ONE dense buffer over the whole query range.  A hillslope that
     reaches tf (a step crossing the last chunk edge) or is flagged in an earlier chunk must keep the
     rows it wrote: later launches may not touch them.  (a) tf = 2880 in chunks of 1439 minutes leaves
@@ -984,7 +990,7 @@ def test_streamed_forcings_keep_the_rows_of_lanes_that_finished_early(gpu, case)
         fl = ref["stiff"] == 1
         assert 10 < fl.sum() < ns
         assert np.abs(ref["dense"][fl]).sum(axis=(1, 2)).min() > 0  # flagged lanes have pre-flag rows
-    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, math_mode=H.MATH_FAST)
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, math_mode=H.MATH_FAST, dense_tiled=layout)
     for method in (eng.integrate_forcing_streamed, eng.integrate_forcing_streamed_abi):
         eng.y_final.zero_()
         eng.dense.fill_(-7.0)
@@ -1213,9 +1219,11 @@ def test_device_rhs_single_evaluations_vs_oracle(gpu, oracle, math_mode):
     assert np.allclose(outd.cpu().numpy()[::20], refd, rtol=1e-14, atol=2e-15)  # FMA-contracted products
 
 
-def test_dense_tile_layout_holds_the_same_rows(gpu, layout=1):
-    """dense_tiled 1 ([tile][q][lane][c]) is a re-ordering of the host layout: same bits for
-    every (hillslope, query, state), flagged rows and tails zero alike, also after the Radau
+@pytest.mark.parametrize("layout", [1, 2])
+def test_dense_tile_layout_holds_the_same_rows(gpu, layout):
+    """dense_tiled 1 ([tile][q][lane][c], free-running kernel) and 2 ([tile][q][c][lane], the kernel
+    with wave-synchronous stores) hold the same bits as the host layout of the free-running kernel
+    for every (hillslope, query, state), flagged rows and tails zero alike, also after the Radau
     pass and for a ragged last tile."""
     H = gpu
     from tiger_hlm_gpu_amd.engine import ShardEngine

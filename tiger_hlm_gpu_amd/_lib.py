@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libhlm_hip.so")
+# HLM_HIP_LIB: another build of the same library (kernel experiments: tools/dense_probe.sh)
+LIB_PATH = os.environ.get("HLM_HIP_LIB") or os.path.join(_HERE, "lib", "libhlm_hip.so")
 
 HLM_NEQ = 5
 HLM_MAX_FORCINGS = 16
@@ -34,7 +35,7 @@ class GpuBuffers(C.Structure):
     _fields_ = [
         ("d_y0_all", C.c_void_p), ("d_y_final_all", C.c_void_p), ("d_query_times", C.c_void_p),
         ("d_dense_all", C.c_void_p), ("d_stiff", C.c_void_p), ("d_n_attempt", C.c_void_p),
-        ("d_n_accept", C.c_void_p), ("num_systems", C.c_int), ("num_queries", C.c_int),
+        ("d_n_accept", C.c_void_p), ("num_systems", C.c_int), ("num_queries", C.c_int), ("dense_layout", C.c_int),
     ]
 
 

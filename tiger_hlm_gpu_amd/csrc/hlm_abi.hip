@@ -14,6 +14,7 @@
 
 #include "hlm_hip.h"
 #include "hlm_radau_kernel.h"
+#include "hlm_rk45_dense_kernel.h"
 #include "hlm_rk45_kernel.h"
 
 namespace {
@@ -49,7 +50,8 @@ ModelState g_models[2] = {
     {HLM_UID_204, {0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0}, 0.0},
 };
 uint32_t g_cap = 1u << 24;
-int g_stream_path = 0;  // hlm_set_stream_path(): 0 copy engine (default), 1 transposing transfer kernel
+int g_stream_path = 0;  // hlm_set_stream_path(): 0 copy engine (default), 1 / 2 transposing transfer kernel
+int g_stream_layout = hlm::DENSE_TILE_COMP;  // device layout of the tiled stream path (1 tile-row, 2 tile-comp)
 // Default arithmetic of the host API: FAST (the measured-more-accurate and 2.4x faster of the two,
 // DESIGN.md "Math modes").  Until hlm_set_math_mode() is called the choice is automatic: FAST wherever
 // its one precondition holds (1e-60 <= atol <= 1e50), STRICT otherwise -- a reference-style caller
@@ -121,6 +123,27 @@ KernelFn pick_kernel(int math, bool dense, bool fixed, bool resumable)
     return resumable ? pick_kernel2<Model, MATH_STRICT, true>(dense, fixed) : pick_kernel2<Model, MATH_STRICT, false>(dense, fixed);
 }
 
+// the dense kernels with wave-synchronous stores (hlm_rk45_dense_kernel.h), layout [tile][q][comp][lane]
+template <class Model>
+KernelFn pick_dense_ring(int math, bool fixed, bool res)
+{
+    using namespace hlm;
+    constexpr int R = HLM_DENSE_RING_ROWS;
+    if (math == HLM_MATH_FAST) {
+        if (res) return fixed ? rk45_dense_ring_kernel<Model, MATH_FAST, true, true, R> : rk45_dense_ring_kernel<Model, MATH_FAST, false, true, R>;
+        return fixed ? rk45_dense_ring_kernel<Model, MATH_FAST, true, false, R> : rk45_dense_ring_kernel<Model, MATH_FAST, false, false, R>;
+    }
+    if (res) return fixed ? rk45_dense_ring_kernel<Model, MATH_STRICT, true, true, R> : rk45_dense_ring_kernel<Model, MATH_STRICT, false, true, R>;
+    return fixed ? rk45_dense_ring_kernel<Model, MATH_STRICT, true, false, R> : rk45_dense_ring_kernel<Model, MATH_STRICT, false, false, R>;
+}
+
+KernelFn pick_dense_ring(int uid, int math, bool fixed, bool res)
+{
+    if (uid == HLM_UID_204) return pick_dense_ring<hlm::Model204Dev>(math, fixed, res);
+    if (uid == HLM_UID_DUMMY) return pick_dense_ring<hlm::DummyDev>(math, fixed, res);
+    return nullptr;
+}
+
 KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
 {
     if (uid == HLM_UID_204) return pick_kernel<hlm::Model204Dev>(math, dense, fixed, resumable);
@@ -184,7 +207,7 @@ int validate_job(const hlm_device_job* j)
             return fail(HLM_ERR_INVALID_ARGUMENT, "a partial query window needs d_resume");
     }
     if (j->resume_in && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "resume_in without d_resume");
-    if (j->dense_tiled != 0 && j->dense_tiled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0 or 1");
+    if (j->dense_tiled < 0 || j->dense_tiled > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0, 1 or 2");
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
@@ -249,7 +272,9 @@ int launch(const hlm_device_job* j, hipStream_t stream)
 {
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
-    KernelFn fn = pick(j->uid, j->math_mode, dense, fixed, job_is_resumable(j));
+    KernelFn fn = dense && j->dense_tiled == hlm::DENSE_TILE_COMP
+                      ? pick_dense_ring(j->uid, j->math_mode, fixed, job_is_resumable(j))
+                      : pick(j->uid, j->math_mode, dense, fixed, job_is_resumable(j));
     if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
     const hlm::Rk45Args a = make_args(j);
     const unsigned blocks = (unsigned)((j->num_systems + hlm::WAVE - 1) / hlm::WAVE);
@@ -431,9 +456,10 @@ int hlm_set_attempt_cap(uint32_t cap)
 
 int hlm_set_stream_path(int path)
 {
-    if (path != 0 && path != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "stream path %d", path);
+    if (path < 0 || path > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "stream path %d", path);
     std::lock_guard<std::mutex> lk(g_mu);
-    g_stream_path = path;
+    g_stream_path = path ? 1 : 0;
+    if (path) g_stream_layout = path == 2 ? hlm::DENSE_TILE_COMP : hlm::DENSE_TILE_ROW;
     return HLM_SUCCESS;
 }
 
@@ -601,7 +627,7 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
         const int b = k & 1, qb = k * W, qe = (qb + W < nq) ? qb + W : nq;
         hlm_device_job j = *job;
         j.d_dense = buf[b];
-        j.dense_tiled = tiled ? 1 : 0;
+        j.dense_tiled = tiled ? g_stream_layout : 0;
         j.query_begin = qb;
         j.query_end = qe;
         j.d_resume = resume;
@@ -616,7 +642,10 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
         if (tiled) {
             const int Wk = qe - qb;
             const dim3 grid((unsigned)nblk, (unsigned)((Wk + hlm::TILE_TQ - 1) / hlm::TILE_TQ));
-            hipLaunchKernelGGL(hlm::dense_tile_to_host, grid, dim3(256), 0, copy, buf[b], h_dense_dev, ns, nq, qb, Wk);
+            if (g_stream_layout == hlm::DENSE_TILE_COMP)
+                hipLaunchKernelGGL(hlm::dense_tile_to_host<true>, grid, dim3(256), 0, copy, buf[b], h_dense_dev, ns, nq, qb, Wk);
+            else
+                hipLaunchKernelGGL(hlm::dense_tile_to_host<false>, grid, dim3(256), 0, copy, buf[b], h_dense_dev, ns, nq, qb, Wk);
             ok(hipGetLastError());
         } else {
             // device [ns][qe-qb][5] -> host rows of nq*40 B, columns qb..qe
@@ -824,7 +853,10 @@ int hlm_setup_gpu_buffers(const double* h_y0, int ns, const double* h_q, int nq,
     out->num_queries = nq;
     const size_t b_state = sizeof(double) * (size_t)ns * HLM_NEQ;
     const size_t b_q = sizeof(double) * (size_t)nq;
-    const size_t b_dense = b_state * (size_t)nq;
+    // dense rows live tile-major in HBM ([ceil(ns/64)][nq][5][64], whole cache lines per store:
+    // hlm_rk45_dense_kernel.h); hlm_retrieve_and_free delivers the host order
+    out->dense_layout = hlm::DENSE_TILE_COMP;
+    const size_t b_dense = sizeof(double) * (size_t)((ns + hlm::WAVE - 1) / hlm::WAVE) * hlm::WAVE * HLM_NEQ * (size_t)nq;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMalloc(p, bytes);
@@ -883,6 +915,7 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     j.d_sp = d_sp;
     j.d_y_final = b->d_y_final_all;
     j.d_dense = b->d_dense_all;
+    j.dense_tiled = b->dense_layout;
     j.d_stiff = b->d_stiff;
     j.d_n_attempt = b->d_n_attempt;
     j.d_n_accept = b->d_n_accept;
@@ -901,6 +934,49 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     return HLM_SUCCESS;
 }
 
+// dense rows of a tile-major device buffer -> h_dense in the host order (s*nq + q)*5 + c
+// (rk45_api.hpp:255-267).  Pinned, device-mapped host memory is written by the transposing kernel
+// directly; any other destination goes through a device staging buffer of whole tiles.
+static hipError_t dense_to_host_order(const double* d_dense, int layout, size_t ns, size_t nq, double* h_dense)
+{
+    if (!h_dense || !d_dense || ns == 0 || nq == 0) return hipSuccess;
+    const size_t row = sizeof(double) * HLM_NEQ;
+    if (layout == hlm::DENSE_LINEAR) return hipMemcpy(h_dense, d_dense, ns * nq * row, hipMemcpyDeviceToHost);
+    const int nblk = (int)((ns + hlm::WAVE - 1) / hlm::WAVE);
+    auto launch_tiles = [&](int blk0, int nb, double* dst_for_sys0) {  // dst_for_sys0: where system 0's rows would start
+        const dim3 grid((unsigned)nb, (unsigned)((nq + hlm::TILE_TQ - 1) / hlm::TILE_TQ));
+        const double* src = d_dense + (size_t)blk0 * nq * hlm::WAVE * HLM_NEQ;
+        double* dst = dst_for_sys0 + (size_t)blk0 * hlm::WAVE * nq * HLM_NEQ;
+        const int ns_left = (int)(ns - (size_t)blk0 * hlm::WAVE);
+        if (layout == hlm::DENSE_TILE_COMP)
+            hipLaunchKernelGGL(hlm::dense_tile_to_host<true>, grid, dim3(256), 0, nullptr, src, dst, ns_left, (int)nq, 0, (int)nq);
+        else
+            hipLaunchKernelGGL(hlm::dense_tile_to_host<false>, grid, dim3(256), 0, nullptr, src, dst, ns_left, (int)nq, 0, (int)nq);
+        return hipGetLastError();
+    };
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, h_dense) == hipSuccess && at.type == hipMemoryTypeHost && at.devicePointer) {
+        hipError_t e = launch_tiles(0, nblk, static_cast<double*>(at.devicePointer));
+        return e != hipSuccess ? e : hipDeviceSynchronize();
+    }
+    (void)hipGetLastError();  // pageable memory: not an error
+    const size_t tile_bytes = (size_t)hlm::WAVE * nq * row;
+    size_t tiles_per_pass = ((size_t)256 << 20) / tile_bytes;
+    if (tiles_per_pass == 0) tiles_per_pass = 1;
+    if (tiles_per_pass > (size_t)nblk) tiles_per_pass = (size_t)nblk;
+    double* stage = nullptr;
+    hipError_t e = hipMalloc((void**)&stage, tiles_per_pass * tile_bytes);
+    for (int b0 = 0; e == hipSuccess && b0 < nblk; b0 += (int)tiles_per_pass) {
+        const int nb = (int)((size_t)(nblk - b0) < tiles_per_pass ? (size_t)(nblk - b0) : tiles_per_pass);
+        const size_t sys0 = (size_t)b0 * hlm::WAVE, nsys = (size_t)nb * hlm::WAVE < ns - sys0 ? (size_t)nb * hlm::WAVE : ns - sys0;
+        // the kernel addresses dst by the system index within the launch: shift so that tile b0 lands at stage[0]
+        e = launch_tiles(b0, nb, stage - (size_t)b0 * hlm::WAVE * nq * HLM_NEQ);
+        if (e == hipSuccess) e = hipMemcpy(h_dense + sys0 * nq * HLM_NEQ, stage, nsys * nq * row, hipMemcpyDeviceToHost);
+    }
+    if (stage) (void)hipFree(stage);
+    return e;
+}
+
 int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense, int32_t* h_stiff,
                           uint32_t* h_n_attempt, uint32_t* h_n_accept)
 {
@@ -911,7 +987,7 @@ int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense, 
         if (e == hipSuccess && dst && src && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
     };
     d2h(h_final, b->d_y_final_all, sizeof(double) * ns * HLM_NEQ);
-    d2h(h_dense, b->d_dense_all, sizeof(double) * ns * nq * HLM_NEQ);
+    if (e == hipSuccess) e = dense_to_host_order(b->d_dense_all, b->dense_layout, ns, nq, h_dense);
     d2h(h_stiff, b->d_stiff, sizeof(int32_t) * ns);
     d2h(h_n_attempt, b->d_n_attempt, sizeof(uint32_t) * ns);
     d2h(h_n_accept, b->d_n_accept, sizeof(uint32_t) * ns);

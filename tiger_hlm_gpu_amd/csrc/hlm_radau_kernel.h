@@ -214,11 +214,15 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
     double tb0 = -__builtin_inf(), tb1 = -__builtin_inf(), F0 = 0.0, F1 = 0.0;
     typename Model::Forc FV = Model::prep_forcing(P, F0, F1);
 
-    const size_t q_stride = A.dense_tiled ? (size_t)WAVE * NEQ : (size_t)NEQ;
+    // dense layouts as in hlm_rk45_dense_kernel.h: 0 / 3 [sys][q][c], 1 [tile][q][lane][c], 2 [tile][q][c][lane]
+    const bool tiled = A.dense_tiled == 1 || A.dense_tiled == 2;
+    const size_t q_stride = tiled ? (size_t)WAVE * NEQ : (size_t)NEQ;
+    const size_t c_stride = A.dense_tiled == 2 ? (size_t)WAVE : (size_t)1;
     double* dense_row = nullptr;
     if (A.nq > 0)
-        dense_row = A.dense_tiled ? A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride + (size_t)(sys % WAVE) * NEQ
-                                  : A.dense + (size_t)sys * (size_t)A.nq * NEQ;
+        dense_row = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * NEQ
+                           : A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride +
+                                 (size_t)(sys % WAVE) * (A.dense_tiled == 2 ? (size_t)1 : (size_t)NEQ);
 
     double t = A.t0, h = A.h0;
     const double tf = A.tf;
@@ -227,7 +231,7 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
     // queries at or before t0 are never produced: zero rows
     while (next_q < A.nq && A.query[next_q] <= t) {
 #pragma unroll
-        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
+        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
         ++next_q;
     }
 
@@ -363,7 +367,7 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
                         acc += (PD[0][m] * Z[0][c] + PD[1][m] * Z[1][c] + PD[2][m] * Z[2][c]) * thp;
                         thp *= th;
                     }
-                    o[c] = acc;
+                    o[(size_t)c * c_stride] = acc;
                 }
                 ++next_q;
             }
@@ -388,7 +392,7 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
     for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = failed ? 0.0 : y[i];
     for (; next_q < A.nq; ++next_q) {  // rows never reached (later than tf, or after the cap): zero
 #pragma unroll
-        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
+        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
     }
 }
 

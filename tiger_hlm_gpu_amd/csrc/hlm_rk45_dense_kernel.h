@@ -1,0 +1,299 @@
+// Dense output with wave-synchronous stores: the RK45 loop of hlm_rk45_kernel.h with the query rows of
+// a wave written to HBM by all its 64 lanes TOGETHER, so that every store instruction of the dense
+// output writes whole cache lines.
+//
+// Restates reference src/solver/rk45_kernel.cu:139-148 (the query loop inside an accepted step) and
+// rk45_step_dense.cuh:171-244 (the interpolant); the host-order copy of rk45_api.hpp:255-267 is
+// dense_tile_to_host() at the end of hlm_rk45_kernel.h.
+//
+// Why.  The dense output is the one HBM-bound part of the path: 40 bytes per (hillslope, query),
+// 57.6 GB for 1 M hillslopes x 1 day at 1-minute stride.  With each lane storing its rows whenever it
+// has them (hlm_rk45_kernel.h) a row store of a wave touches up to 64 different places: measured on
+// MI355X (profiles/r02_dense_pmc.json) 133 write requests per 2560-byte row block where 40 would do,
+// the texture cache's pending-request stall dominating: 18.3 ms = 3.2 TB/s.  Making the lanes emit each
+// row in lockstep (one query cursor per wave, a lane holding its accepted step until all 64 have
+// reached the query) brought the requests down to exactly 40 -- and cost 31 % more VALU work: the
+// lanes of a wave take the same NUMBER of attempts (they share a forcing cell) but reject at slightly
+// different attempts, and in lockstep every reject of any lane stalls the other 63 (measured lane
+// utilisation 72 %; 19.5 ms).  So the lanes run free, as in hlm_rk45_kernel.h, and the ROWS are what
+// waits: a lane puts each row it produces into an LDS ring of R rows ([row % R][comp][lane]: its own
+// 8-byte column, no transposition, no bank conflict) and the wave flushes row q to HBM -- in the tile
+// layout [tile][q][comp][lane], five stores of 512 contiguous bytes -- once every lane has produced
+// it.  A lane only waits when it is R rows ahead of the slowest lane of its wave.  The committed step
+// sequence of every lane, and therefore every output bit, is that of the free-running kernel.
+#pragma once
+
+#include "hlm_rk45_kernel.h"
+
+namespace hlm {
+
+// device layouts of the dense buffer (hlm_device_job.dense_tiled)
+constexpr int DENSE_LINEAR = 0;     // [sys][q][comp]: the host-facing order
+constexpr int DENSE_TILE_ROW = 1;   // [sys/64][q][sys%64][comp]            (free-running kernel only)
+constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte run per store instruction (this file)
+
+// rows of slack between the lanes of a wave (LDS: R x 2560 bytes per wave)
+#ifndef HLM_DENSE_RING_ROWS
+#define HLM_DENSE_RING_ROWS 4
+#endif
+
+template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R>
+__global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
+{
+    using namespace dp;
+    // XCD-aware block -> hillslope-chunk map (see rk45_multi_kernel)
+    const unsigned nblk = gridDim.x, orig = blockIdx.x;
+    const unsigned xcd = orig & 7u, qd = nblk >> 3, rm = nblk & 7u;
+    const unsigned blk = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + (orig >> 3);
+    const int lane = (int)threadIdx.x;
+    const int sys = (int)(blk * WAVE) + lane;
+    if (sys >= A.ns) return;
+
+    using lds_double_ptr = __attribute__((address_space(3))) double*;
+    __shared__ double ring_mem[R * NEQ * WAVE];  // [row % R][comp][lane]
+    __shared__ double lds_query[DENSE_QWIN];     // sliding window of query times (see rk45_multi_kernel)
+    const lds_double_ptr ring = (lds_double_ptr)ring_mem + lane;
+
+    const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
+    double y[NEQ];
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
+    HeldForcing<Model, RESUMABLE> held;
+    held.init(A, sys);
+
+    double t = A.t0;
+    double h = FIXED ? A.fixed_step : A.h0;
+    const double tf = A.tf;
+    int reject_count = 0;
+    int status = HLM_SYS_OK;
+    uint32_t n_attempt = 0, n_accept = 0;
+
+    // Query window [qb, qe) of this launch (the whole range unless the host streams the dense output
+    // in windows, hlm_rk45_integrate_streamed); the buffer holds exactly these rows, tile-major:
+    // element (q, c) of this lane = row0[(q - qb) * 320 + c * 64].
+    const int qb = A.q_begin, qe = A.q_end;
+    const int q_hi = A.nq < qe ? A.nq : qe;
+    constexpr size_t Q_STRIDE = (size_t)WAVE * NEQ;
+    double* const row0 = A.dense + (size_t)blk * (size_t)(qe - qb) * Q_STRIDE + (size_t)lane;
+
+    // live: still integrating in this launch.  Not live = reached tf, flagged, capped, paused at
+    // t_stop ("stuck": it continues in the next launch), or finished in an earlier launch.
+    bool live = true, finished_before = false;
+    int next_q = qb;  // this lane's query cursor: it has produced (or owes nothing for) the rows below it
+    int* const resume_i =
+        RESUMABLE && A.resume ? reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns) : nullptr;
+    if (resume_i && A.resume_in) {
+        const int st = resume_i[(size_t)4 * A.ns + sys];
+        next_q = resume_i[(size_t)3 * A.ns + sys];
+        if (next_q < qb) next_q = qb;  // (windows are visited in order; never index before the buffer)
+        if (st != SYS_PAUSED) {
+            live = false;
+            finished_before = true;
+            status = st;
+            t = tf;  // whatever stopped it, it takes no part in the integration any more
+        } else {
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
+            t = A.resume[(size_t)5 * A.ns + sys];
+            h = A.resume[(size_t)6 * A.ns + sys];
+            reject_count = resume_i[(size_t)0 * A.ns + sys];
+            n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
+            n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
+        }
+    }
+    const int my_start_q = next_q;  // rows below it were written by earlier launches: never touched here
+    // the wave's flush cursor: rows below it are in HBM for every lane that owes them in this launch
+    int q_flush = 0x7fffffff;
+    for (unsigned long long m = __builtin_amdgcn_ballot_w64(true); m != 0ull; m &= m - 1ull) {
+        const int v = __builtin_amdgcn_readlane(next_q, (int)__builtin_ctzll(m));
+        q_flush = v < q_flush ? v : q_flush;
+    }
+
+    const double inf = __builtin_inf();
+    int qwin_base = -(1 << 30);  // wave-uniform: first query index held in lds_query
+    using lds_cdouble_ptr = const __attribute__((address_space(3))) double*;
+    auto query_at = [&](int q) -> double {  // q < nq
+        const unsigned idx = (unsigned)(q - qwin_base);
+        double v;
+        if (idx < (unsigned)DENSE_QWIN) v = ((lds_cdouble_ptr)lds_query)[idx];
+        else v = A.query[q];
+        return v;
+    };
+    double tq_next = next_q < A.nq ? A.query[next_q] : inf;
+
+    bool have_k0 = false;  // see rk45_multi_kernel: k6 of an accepted step is the next k0
+    double k0[NEQ], k6[NEQ], yt[NEQ], Q1[NEQ], Q2[NEQ], Q3[NEQ];
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) k0[i] = k6[i] = yt[i] = Q1[i] = Q2[i] = Q3[i] = 0.0;
+    typename Model::Forc FV = Model::prep_forcing(P, held.F0, held.F1);
+    // A PENDING step: accepted, not yet committed because rows of it are still to be produced (the
+    // ring is full, or the launch's query window ends inside it).  While a lane waits its registers
+    // are not written (it is masked off in the attempt code), so the step lives where the attempt
+    // left it: y (old state), yt (new state), k0, k6 (the next k0), Q1..Q3 (rk45_step_dense.cuh:222-231).
+    bool pending = false;
+    double t1 = t, h_next = h;
+    const double t_end = RESUMABLE ? fmin(tf, A.t_stop) : tf;
+
+    // One loop, one back-edge, one exit.  Every iteration: (A) the lanes that can integrate do one
+    // attempt, (B) lanes with rows to produce put them into the ring while it has room, committing
+    // their step after its last row, (C) the wave flushes the rows every lane is through with.
+    bool wave_on = true;  // wave-uniform
+    while (wave_on) {
+        bool progress = false;
+        // ---- (A) one attempt ------------------------------------------------------------------
+        const bool can_step = live && !pending && t < t_end && n_attempt < A.cap;
+        if (live && !pending && !can_step) {
+            live = false;
+            if (t < t_end) status = HLM_SYS_CAPPED;  // attempt cap (the build's guard, see hlm_hip.h)
+        }
+        if (can_step) {
+            progress = true;
+            if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
+            if (held.refresh(A, P, t, FV)) have_k0 = false;
+            ++n_attempt;
+            double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ];
+            [[maybe_unused]] double err = 0.0, jump = 0.0;
+            attempt_on_cheapest_path<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+            bool accepted = true;
+            [[maybe_unused]] double fac = 1.0;
+            if constexpr (!FIXED) {
+                fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);  // rk45_kernel.cu:151,156
+                if (err <= 1.0) {
+                    reject_count = 0;
+                    if (jump > SLOPE_JUMP_THRESH) {  // rk45_kernel.cu:132-136
+                        h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
+                        accepted = false;
+                    }
+                } else {  // rk45_kernel.cu:153-163
+                    ++reject_count;
+                    double f = fmin(fac, 1.0);
+                    f = fmin(fmax(f, A.min_scale), A.max_scale);
+                    h *= f;
+                    if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) {
+                        status = HLM_SYS_STIFF;
+                        live = false;
+                    }
+                    accepted = false;
+                }
+            }
+            if (accepted) {
+                // committed in (B), after the step's last row
+                t1 = t + h;
+                h_next = FIXED ? A.fixed_step : h * fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+                pending = true;
+                if (tq_next <= t1) {
+                    // Q_m = sum_j P[j][m] k_j once per step; Q_0 = k0 (rk45_step_dense.cuh:222-231)
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) {
+                        Q1[i] = lc(P01 * k0[i], P21, k2[i], P31, k3[i], P41, k4[i], P51, k5[i], P61, k6[i]);
+                        Q2[i] = lc(P02 * k0[i], P22, k2[i], P32, k3[i], P42, k4[i], P52, k5[i], P62, k6[i]);
+                        Q3[i] = lc(P03 * k0[i], P23, k2[i], P33, k3[i], P43, k4[i], P53, k5[i], P63, k6[i]);
+                    }
+                }
+            }
+        }
+        // stopped for good (tf reached, flagged, capped -- not: paused at t_stop): rows from next_q on are 0
+        const bool stuck = !live && !pending && status == HLM_SYS_OK && t < tf;
+        const bool owes_zeros = !live && !pending && !stuck;
+
+        // ---- (B) rows -------------------------------------------------------------------------
+        // slide the query-time window (the lanes' cursors are within R rows of the flush cursor)
+        if (q_flush < A.nq && (unsigned)(q_flush - qwin_base) >= (unsigned)(DENSE_QWIN - R - 2)) {
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+            const int nact = __builtin_popcountll(act);
+            const int rank = __builtin_popcountll(act & ((1ull << lane) - 1ull));
+            for (int i = rank; i < DENSE_QWIN; i += nact) lds_query[i] = (q_flush + i) < A.nq ? A.query[q_flush + i] : inf;
+            qwin_base = q_flush;
+        }
+        // A lane has a row to produce when its pending step contains the next query (rk45_kernel.cu:139-146),
+        // or when that query is not later than its current time: such a row is never produced by the
+        // reference (rk45_kernel.cu:141: "if (tq > t)") and stays 0.
+        bool want = !owes_zeros && ((pending && tq_next <= t1) || tq_next <= t);
+        [[maybe_unused]] const double inv_h = MATH == MATH_FAST ? fast_rcp(h) : 0.0;
+        while (want && next_q < q_flush + R && next_q < q_hi) {
+            const double tq_after = next_q + 1 < A.nq ? query_at(next_q + 1) : inf;  // fetched while the row is computed
+            double row[NEQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (tq_next > t) {  // then the step is pending: rk45_step_dense.cuh:235-243
+                double th;
+                if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
+                const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) {
+                    const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
+                    row[i] = __builtin_fma(h, poly, y[i]);
+                }
+            }
+            const lds_double_ptr slot = ring + (next_q % R) * (NEQ * WAVE);
+#pragma unroll
+            for (int c = 0; c < NEQ; ++c) slot[c * WAVE] = row[c];
+            ++next_q;
+            tq_next = tq_after;
+            want = (pending && tq_next <= t1) || tq_next <= t;
+            progress = true;
+        }
+        if (pending && !(tq_next <= t1)) {
+            // the step's last row is out: commit it (the only place a step is committed)
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) { y[i] = yt[i]; k0[i] = k6[i]; }
+            t = t1;
+            h = h_next;
+            ++n_accept;
+            pending = false;
+            progress = true;
+        }
+
+        // ---- (C) flush: row q_flush goes to HBM once every lane is through with it ----------------
+        // (Reading all ready rows from the ring before the first store -- one LDS latency per batch --
+        // was measured: no gain, 40 more live registers, spills.)
+        bool flushed = false;
+        while (q_flush < q_hi) {
+            const bool has_row = next_q > q_flush;
+            if (__builtin_amdgcn_ballot_w64(!(has_row || owes_zeros || stuck)) != 0ull) break;  // somebody is still on its way
+            // nobody has produced it: only a wave whose lanes have ALL stopped for good fills in zeros here
+            if (__builtin_amdgcn_ballot_w64(has_row) == 0ull && __builtin_amdgcn_ballot_w64(!owes_zeros) != 0ull) break;
+            if (q_flush >= my_start_q && (has_row || owes_zeros)) {
+                const lds_double_ptr slot = ring + (q_flush % R) * (NEQ * WAVE);
+                double* o = row0 + (size_t)(q_flush - qb) * Q_STRIDE;
+#pragma unroll
+                for (int c = 0; c < NEQ; ++c) o[c * WAVE] = has_row ? slot[c * WAVE] : 0.0;  // 64 lanes x 8 B: 512 contiguous bytes
+            }
+            ++q_flush;
+            flushed = true;
+        }
+        wave_on = flushed || __builtin_amdgcn_ballot_w64(progress) != 0ull;
+    }
+
+    if (pending) {
+        // the launch's query window ends inside this step: it is given back -- (y, t, h) are still the
+        // step's start and the attempt is redone in the next launch, which then produces the rest of its rows
+        --n_attempt;
+        status = SYS_PAUSED;
+    }
+    if (RESUMABLE && !live && status == HLM_SYS_OK && t < tf) status = SYS_PAUSED;  // stopped at t_stop
+    if (resume_i) {
+        // a lane that has stopped for good has (zero-)written every row the wave flushed
+        resume_i[(size_t)3 * A.ns + sys] = (status != SYS_PAUSED && q_flush > next_q) ? q_flush : next_q;
+        if (!finished_before) {
+            resume_i[(size_t)4 * A.ns + sys] = status;
+            if (status == SYS_PAUSED) {
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
+                A.resume[(size_t)5 * A.ns + sys] = t;
+                A.resume[(size_t)6 * A.ns + sys] = h;
+                resume_i[(size_t)0 * A.ns + sys] = reject_count;
+                resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
+                resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
+            }
+        }
+    }
+    if (status != SYS_PAUSED && !finished_before) {
+        if (A.n_attempt) A.n_attempt[sys] = n_attempt;
+        if (A.n_accept) A.n_accept[sys] = n_accept;
+        const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170
+        A.stiff[sys] = flagged ? status : HLM_SYS_OK;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
+    }
+}
+
+}  // namespace hlm

@@ -261,6 +261,90 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
     return broke;
 }
 
+// ---- held forcing samples -----------------------------------------------------------------------
+// Zero-order hold sampled at the START time of a step and held for all its stages
+// (rk45_kernel.cu:85-106).  Each lane keeps the held samples F0/F1 and the time at which its sample
+// index next changes; the index (an f64 divide) and the 4-byte load are redone only when an accepted
+// step carries t past that time -- about once per forcing interval instead of twice per attempt.
+// (floor(t/dt) == idx for t < tb up to a final-ulp tie of the quotient, a measure-zero difference
+// from the reference.)
+template <class Model, bool RESUMABLE>
+struct HeldForcing {
+    size_t fcol = 0;
+    double tb0 = -__builtin_inf(), tb1 = -__builtin_inf();
+    double tb_next = -__builtin_inf();  // min(tb0, tb1): when the held samples expire
+    double F0 = 0.0, F1 = 0.0;
+
+    __device__ __forceinline__ void init(const Rk45Args& A, int sys)
+    {
+        if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
+    }
+    // One rarely-taken branch per attempt: has t (which only moves on an accepted step) reached the
+    // end of a held sample?  Returns true when a sample changed (FV was rebuilt; k0 is stale).
+    __device__ __forceinline__ bool refresh(const Rk45Args& A, const typename Model::Local& P, double t,
+                                            typename Model::Forc& FV)
+    {
+        if constexpr (Model::NF > 0) {
+            if (!(t < tb_next)) {
+                const bool use_f0 = Model::NF > 0 && A.nforc > 0;
+                const bool use_f1 = Model::NF > 1 && A.nforc > 1;
+                if (use_f0 && !(t < tb0)) {
+                    const unsigned long long i0 = forcing_index(t, A.forc_dtmin[0], A.forc_nT[0]);
+                    tb0 = (i0 + 1ull < A.forc_nT[0]) ? (double)(i0 + 1ull) * A.forc_dtmin[0] : __builtin_inf();
+                    F0 = (double)A.forc[A.forc_base[0] + (RESUMABLE ? forcing_row(i0, A.forc_first[0], A.forc_rows[0]) : (size_t)i0) * (size_t)A.forc_ld + fcol];
+                }
+                if (use_f1 && !(t < tb1)) {
+                    const unsigned long long i1 = forcing_index(t, A.forc_dtmin[1], A.forc_nT[1]);
+                    tb1 = (i1 + 1ull < A.forc_nT[1]) ? (double)(i1 + 1ull) * A.forc_dtmin[1] : __builtin_inf();
+                    F1 = (double)A.forc[A.forc_base[1] + (RESUMABLE ? forcing_row(i1, A.forc_first[1], A.forc_rows[1]) : (size_t)i1) * (size_t)A.forc_ld + fcol];
+                }
+                tb_next = fmin(use_f0 ? tb0 : __builtin_inf(), use_f1 ? tb1 : __builtin_inf());
+                FV = Model::prep_forcing(P, F0, F1);
+                return true;
+            }
+        }
+        return false;
+    }
+};
+
+// ---- one attempt on the cheapest RHS path the whole wave qualifies for ----------------------------
+// A model may offer a cheaper RHS that is exact while its per-lane precondition holds (Model 204:
+// surface store == 0, the Manning term vanishes; and no rain on top of that).  The wave takes it only
+// when ALL its active lanes qualify, and every stage reports whether the precondition broke during the
+// step (inflow reached the surface store); if it did for any lane the attempt is simply recomputed
+// with the general RHS -- same bits either way.  On return have_k0 is true (k0 stays valid through a
+// reject / slope-jump retry) and yt is the 5th-order solution.
+template <class Model, int MATH, bool FIXED>
+__device__ __forceinline__ void attempt_on_cheapest_path(const typename Model::Local& P, const typename Model::Forc& FV,
+                                                         const Rk45Args& A, const double (&y)[NEQ], double h, bool& have_k0,
+                                                         double (&k0)[NEQ], double (&k1)[NEQ], double (&k2)[NEQ],
+                                                         double (&k3)[NEQ], double (&k4)[NEQ], double (&k5)[NEQ],
+                                                         double (&k6)[NEQ], double (&yt)[NEQ], double& err, double& jump)
+{
+    bool general = true;
+    if constexpr (Model::HAS_NORAINPATH) {
+        // between storms (no rain in the held sample, dry surface): the cascade below the static store is idle
+        if (__builtin_amdgcn_ballot_w64(!Model::norainpath_ok(P, FV, y)) == 0ull) {
+            const bool had_k0 = have_k0;
+            const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+            general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+            // Unlike the dry path's, this path's precondition is not decided by y alone: "static
+            // store below capacity" is only discovered by the RHS evaluations themselves, the one
+            // for k0 included.  A k0 evaluated in an attempt that falls back is therefore not kept.
+            have_k0 = general ? had_k0 : true;
+        }
+    }
+    if constexpr (Model::HAS_FASTPATH) {
+        if (general && __builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
+            const bool broke = rk_attempt<Model, MATH, PATH_DRY, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+            have_k0 = true;  // k0 of a qualifying state is exact
+            general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+        }
+    }
+    if (general) rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+    have_k0 = true;
+}
+
 // ---- dense output ---------------------------------------------------------------------------
 // The host-facing dense layout is [sys][query][comp]: a lane's rows are contiguous in memory
 // (40 B per query) but the 64 lanes of a wave are nq*40 B apart, so a row store touches 64
@@ -301,19 +385,8 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
 
-    // Forcing: zero-order hold sampled at the START time of a step and held for all its
-    // stages (rk45_kernel.cu:85-106).  Each lane keeps the held samples F0/F1 and the time
-    // tb at which its sample index next changes; the index (an f64 divide) and the 4-byte
-    // load are redone only when an accepted step carries t past tb -- about once per
-    // forcing interval instead of twice per attempt.  (floor(t/dt) == idx for t < tb up to
-    // a final-ulp tie of the quotient, a measure-zero difference from the reference.)
-    [[maybe_unused]] size_t fcol = 0;
-    [[maybe_unused]] double tb0 = -__builtin_inf(), tb1 = -__builtin_inf();
-    [[maybe_unused]] double tb_next = -__builtin_inf();  // min(tb0, tb1): when the held samples expire
-    double F0 = 0.0, F1 = 0.0;
-    const bool use_f0 = Model::NF > 0 && A.nforc > 0;
-    const bool use_f1 = Model::NF > 1 && A.nforc > 1;
-    if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
+    HeldForcing<Model, RESUMABLE> held;  // zero-order-hold samples of this lane (rk45_kernel.cu:85-106)
+    held.init(A, sys);
 
     double t = A.t0;
     double h = FIXED ? A.fixed_step : A.h0;
@@ -409,7 +482,7 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     // the previous value IS the reference's k0, bit for bit.  have_k0 tracks that.
     bool have_k0 = false;
     double k0[NEQ];
-    typename Model::Forc FV = Model::prep_forcing(P, F0, F1);
+    typename Model::Forc FV = Model::prep_forcing(P, held.F0, held.F1);
 
     // t_stop (time chunks / checkpoints): a lane whose t has reached it pauses BEFORE its next
     // attempt, so the continuation in the next launch repeats nothing and changes nothing.
@@ -430,57 +503,13 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         }
         if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
 
-        if constexpr (Model::NF > 0) {
-            // one rarely-taken branch per attempt: has t (which only moves on an accepted step)
-            // reached the end of a held forcing sample?
-            if (!(t < tb_next)) {
-                if (use_f0 && !(t < tb0)) {
-                    const unsigned long long i0 = forcing_index(t, A.forc_dtmin[0], A.forc_nT[0]);
-                    tb0 = (i0 + 1ull < A.forc_nT[0]) ? (double)(i0 + 1ull) * A.forc_dtmin[0] : __builtin_inf();
-                    F0 = (double)A.forc[A.forc_base[0] + (RESUMABLE ? forcing_row(i0, A.forc_first[0], A.forc_rows[0]) : (size_t)i0) * (size_t)A.forc_ld + fcol];
-                }
-                if (use_f1 && !(t < tb1)) {
-                    const unsigned long long i1 = forcing_index(t, A.forc_dtmin[1], A.forc_nT[1]);
-                    tb1 = (i1 + 1ull < A.forc_nT[1]) ? (double)(i1 + 1ull) * A.forc_dtmin[1] : __builtin_inf();
-                    F1 = (double)A.forc[A.forc_base[1] + (RESUMABLE ? forcing_row(i1, A.forc_first[1], A.forc_rows[1]) : (size_t)i1) * (size_t)A.forc_ld + fcol];
-                }
-                tb_next = fmin(use_f0 ? tb0 : __builtin_inf(), use_f1 ? tb1 : __builtin_inf());
-                FV = Model::prep_forcing(P, F0, F1);
-                have_k0 = false;
-            }
-        }
+        if (held.refresh(A, P, t, FV)) have_k0 = false;
 
         ++n_attempt;
-        // ---- 7 stages (rk_stages below) ---------------------------------------------------
-        // A model may offer a cheaper RHS that is exact while its per-lane precondition holds
-        // (Model 204: surface store == 0, the Manning term vanishes).  The wave takes it only
-        // when ALL its lanes qualify, and every stage reports whether the precondition broke
-        // during the step (inflow reached the surface store); if it did for any lane the
-        // attempt is simply recomputed with the general RHS -- same bits either way.
+        // ---- 7 stages + the two norms, on the cheapest RHS path the wave qualifies for -------------
         double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
         [[maybe_unused]] double err = 0.0, jump = 0.0;
-        bool general = true;
-        if constexpr (Model::HAS_NORAINPATH) {
-            // between storms (no rain in the held sample, dry surface): the cascade below the static store is idle
-            if (__builtin_amdgcn_ballot_w64(!Model::norainpath_ok(P, FV, y)) == 0ull) {
-                const bool had_k0 = have_k0;
-                const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
-                general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
-                // Unlike the dry path's, this path's precondition is not decided by y alone: "static
-                // store below capacity" is only discovered by the RHS evaluations themselves, the one
-                // for k0 included.  A k0 evaluated in an attempt that falls back is therefore not kept.
-                have_k0 = general ? had_k0 : true;
-            }
-        }
-        if constexpr (Model::HAS_FASTPATH) {
-            if (general && __builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
-                const bool broke = rk_attempt<Model, MATH, PATH_DRY, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
-                have_k0 = true;  // k0 of a qualifying state is exact
-                general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
-            }
-        }
-        if (general) rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
-        have_k0 = true;  // stays valid through a reject / slope-jump retry
+        attempt_on_cheapest_path<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
         // 5th-order solution (rk45_step_dense.cuh:111-117).  b[6] = 0, so it is the same
         // chain of operations as the stage-6 state: identical bits, reuse it.
 #pragma unroll
@@ -643,22 +672,27 @@ __global__ void selftest_rhs_kernel(const double* __restrict__ y, const void* sp
 }
 
 // ---- tile-major window -> host order -------------------------------------------------------
-// Transposes one query window from the kernel's tile-major layout [blk][W][64][5] to the
-// host-facing order dst[(sys*nq + q)*5 + c] (rk45_api.hpp:255-267).  dst is normally PINNED
-// HOST memory mapped into the device: the kernel IS the device-to-host transfer (PCIe
-// writes in 640-byte contiguous runs), running on its own stream beside the integration of
-// the next window.  One workgroup = 64 systems x TQ queries staged through LDS.
+// Transposes one query window from a tile-major device layout to the host-facing order
+// dst[(sys*nq + q)*5 + c] (rk45_api.hpp:255-267).  dst is normally PINNED HOST memory mapped into the
+// device: the kernel IS the device-to-host transfer (PCIe writes in 640-byte contiguous runs), running
+// on its own stream beside the integration of the next window -- or a device staging buffer
+// (hlm_retrieve_and_free).  One workgroup = 64 systems x TQ queries staged through LDS.
+// COMP_MAJOR: src is [blk][W][5][64] (the wave-synchronous kernel's layout), else [blk][W][64][5].
 constexpr int TILE_TQ = 16;
 
+template <bool COMP_MAJOR>
 __global__ void __launch_bounds__(256) dense_tile_to_host(const double* __restrict__ src, double* __restrict__ dst,
                                                           int ns, int nq, int q_begin, int W)
 {
-    __shared__ double tile[TILE_TQ * WAVE * NEQ];  // 40 KB: [ql][lane][c]
+    // [ql][lane][c], or [ql][c][lane] with each 64-lane run padded to 65 so that the transposed reads
+    // below (consecutive threads = consecutive components of one lane) do not all hit one LDS bank
+    constexpr int RUN = COMP_MAJOR ? WAVE + 1 : WAVE;
+    __shared__ double tile[TILE_TQ * NEQ * RUN];  // ~41 KB
     const int blk = blockIdx.x, q0 = blockIdx.y * TILE_TQ;
     const int nql = (W - q0) < TILE_TQ ? (W - q0) : TILE_TQ;
     const int n_in = nql * WAVE * NEQ;
     const double* s = src + ((size_t)blk * (size_t)W + (size_t)q0) * (WAVE * NEQ);
-    for (int i = threadIdx.x; i < n_in; i += 256) tile[i] = s[i];  // contiguous, coalesced
+    for (int i = threadIdx.x; i < n_in; i += 256) tile[COMP_MAJOR ? (i / WAVE) * RUN + (i % WAVE) : i] = s[i];  // contiguous, coalesced
     __syncthreads();
     const int row_len = nql * NEQ;  // doubles each system contributes: contiguous in dst
     const int n_out = WAVE * row_len;
@@ -667,7 +701,8 @@ __global__ void __launch_bounds__(256) dense_tile_to_host(const double* __restri
         const int sys = blk * WAVE + l;
         if (sys < ns) {
             const int ql = r / NEQ, c = r - ql * NEQ;
-            dst[((size_t)sys * (size_t)nq + (size_t)(q_begin + q0)) * NEQ + r] = tile[(ql * WAVE + l) * NEQ + c];
+            dst[((size_t)sys * (size_t)nq + (size_t)(q_begin + q0)) * NEQ + r] =
+                tile[COMP_MAJOR ? (ql * NEQ + c) * RUN + l : (ql * WAVE + l) * NEQ + c];
         }
     }
 }

@@ -15,7 +15,7 @@ from .models import Parameters, SP_DTYPE
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
                  math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
-                 dense_tiled=False):
+                 dense_tiled=2):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -45,9 +45,10 @@ class ShardEngine:
         self.result_blob = torch.empty(self.ns * 40 + 3 * ns8 * 4, dtype=torch.uint8, device=dev)
         o = self.ns * 40
         self.y_final = self.result_blob[:o].view(torch.float64).view(self.ns, model.N_EQ)
-        # dense_tiled: tile-major [ceil(ns/64)][nq][64][5] device layout (what the streamed path
-        # uses internally); only for measuring the kernel -- results() then returns that layout
-        self.dense_tiled = int(bool(dense_tiled))  # 0 host order, 1 [tile][q][lane][c]
+        # device layout of the dense buffer (hlm_device_job.dense_tiled): 2 (default) tile-major
+        # [tile][q][c][lane], the kernel with wave-synchronous stores; 0 host order and 1 [tile][q][lane][c],
+        # the free-running kernel.  results() / dense_host_order() deliver [ns][nq][5] whatever the layout.
+        self.dense_tiled = int(dense_tiled)
         rows = -(-self.ns // 64) * 64 if self.dense_tiled else self.ns
         self.dense = (torch.empty((rows, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
                       if self.nq and alloc_dense else None)
@@ -239,7 +240,10 @@ class ShardEngine:
             return self.dense
         tiles = self.dense.shape[0] // 64
         n_eq = self.model.N_EQ
-        d = self.dense.view(tiles, self.nq, 64, n_eq).permute(0, 2, 1, 3)  # [tile][q][lane][c]
+        if self.dense_tiled == 1:
+            d = self.dense.view(tiles, self.nq, 64, n_eq).permute(0, 2, 1, 3)  # [tile][q][lane][c]
+        else:
+            d = self.dense.view(tiles, self.nq, n_eq, 64).permute(0, 3, 1, 2)  # [tile][q][c][lane]
         return d.reshape(tiles * 64, self.nq, n_eq)[:self.ns]
 
     def results(self):
