@@ -94,6 +94,8 @@ def parse():
     ap.add_argument("--dense-ns", type=int, default=65536)
     ap.add_argument("--dense-days", type=int, default=2)
     ap.add_argument("--dense-window", type=int, default=720, help="queries per streamed window")
+    ap.add_argument("--dense-hbm-ns", type=int, default=1_000_000,
+                    help="hillslopes of the in-HBM dense kernel measurement (1 day at 1-minute stride; 0 skips it)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo only to rehearse N > 1 ranks on a one-GPU box (ranks share the card)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -214,14 +216,53 @@ def dense_section(args):
     attempts = eng.total_attempts()
     algo_bytes = st["dense_bytes"] + ns * B_SYS + 4.0 * sum(eng.forc_nT) * ns
     hbm = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9
-    return {"workload": f"Model 204, {ns} hillslopes, {days} days, query every 1 min (nq={len(q)}), "
-                        f"{st['windows']} windows of {args.dense_window} queries, math={args.math}",
-            "dense_output_MBps": st["dense_bytes"] / (st["wall_ms"] * 1e-3) / 1e6,
-            "dense_bytes": st["dense_bytes"], "wall_ms": st["wall_ms"], "kernel_ms_sum": st["kernel_ms"],
-            "d2h_ms_sum": st["copy_ms"], "steps_per_s_kernel_only": attempts / (st["kernel_ms"] * 1e-3),
-            "roofline_hbm_kernel": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                    "frac": hbm / PEAK_HBM_GBS, "algorithmic_bytes": algo_bytes},
-            "pcie_GBps": st["dense_bytes"] / (st["copy_ms"] * 1e-3) / 1e9}
+    out = {"workload": f"Model 204, {ns} hillslopes, {days} days, query every 1 min (nq={len(q)}), "
+                       f"{st['windows']} windows of {args.dense_window} queries, math={args.math}",
+           "dense_output_MBps": st["dense_bytes"] / (st["wall_ms"] * 1e-3) / 1e6,
+           "dense_bytes": st["dense_bytes"], "wall_ms": st["wall_ms"], "kernel_ms_sum": st["kernel_ms"],
+           "d2h_ms_sum": st["copy_ms"], "steps_per_s_kernel_only": attempts / (st["kernel_ms"] * 1e-3),
+           "roofline_hbm_kernel": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                   "frac": hbm / PEAK_HBM_GBS, "algorithmic_bytes": algo_bytes},
+           "pcie_GBps": st["dense_bytes"] / (st["copy_ms"] * 1e-3) / 1e9}
+    del eng, host
+    torch.cuda.empty_cache()
+    # The dense kernel by itself, output kept in HBM: 1 M hillslopes x 1 day at 1-minute stride (57.6 GB of
+    # rows) in the tile layout [tile][q][comp][lane] with wave-synchronous stores (hlm_rk45_dense_kernel.h).
+    # This is the HBM-bound kernel of the path: its roofline is the 8 TB/s spec peak; a pure fill of the
+    # same 57.6 GB reaches 4.8 TB/s on this GPU (tools/hbm_write_probe.py).
+    ns2, days2 = args.dense_hbm_ns, 1
+    if ns2 > 0:
+        tf2 = days2 * 1440.0
+        q2 = synth.minute_queries(0.0, tf2, 1.0)
+        pr2, t2, dt2, nT2 = synth.forcing_tables(days=days2)
+        e2 = ShardEngine(H.Model204, synth.model204_y0(ns2), 0.0, tf2, sp=synth.model204_params(0, ns2), query=q2,
+                         math_mode=H.MATH_FAST if args.math == "fast" else H.MATH_STRICT,
+                         device=f"cuda:{torch.cuda.current_device()}", dense_tiled=2)
+        e2.expand_forcings_on_device((pr2, t2), synth.cell_of_system(0, ns2), dt2, nT2)
+        e2.integrate()
+        torch.cuda.synchronize()
+        ms = []
+        for _ in range(3):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            e2.integrate()
+            b.record()
+            torch.cuda.synchronize()
+            ms.append(a.elapsed_time(b))
+        k = float(np.mean(ms))
+        ab = 40.0 * ns2 * len(q2) + ns2 * B_SYS + 4.0 * sum(e2.forc_nT) * ns2
+        out["in_hbm_kernel"] = {
+            "workload": f"Model 204, {ns2} hillslopes, {days2} day, query every 1 min (nq={len(q2)}): {40.0 * ns2 * len(q2) / 1e9:.1f} GB "
+                        "of rows kept in HBM, tile layout, wave-synchronous stores",
+            "kernel_ms": k, "kernel_ms_each": ms, "attempts_per_hillslope": e2.total_attempts() / ns2,
+            "roofline": {"bound": "hbm", "achieved": ab / (k * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": ab / (k * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": ab,
+                         "kernel": "hlm::rk45_dense_ring_kernel<Model204Dev>",
+                         "measured_fill_GBps": 4800.0,
+                         "note": "write-only traffic; a pure fill of the same bytes reaches 4.8 TB/s on MI355X (tools/hbm_write_probe.py)"}}
+        del e2
+        torch.cuda.empty_cache()
+    return out
 
 
 def c2_dummy_section(args):

@@ -112,13 +112,8 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     const double inf = __builtin_inf();
     int qwin_base = -(1 << 30);  // wave-uniform: first query index held in lds_query
     using lds_cdouble_ptr = const __attribute__((address_space(3))) double*;
-    auto query_at = [&](int q) -> double {  // q < nq
-        const unsigned idx = (unsigned)(q - qwin_base);
-        double v;
-        if (idx < (unsigned)DENSE_QWIN) v = ((lds_cdouble_ptr)lds_query)[idx];
-        else v = A.query[q];
-        return v;
-    };
+    // query time q from the LDS window: valid for q in [q_flush, q_flush + R + 1] after the slide in (B)
+    auto query_at = [&](int q) -> double { return ((lds_cdouble_ptr)lds_query)[q - qwin_base]; };
     double tq_next = next_q < A.nq ? A.query[next_q] : inf;
 
     bool have_k0 = false;  // see rk45_multi_kernel: k6 of an accepted step is the next k0
@@ -198,7 +193,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
 
         // ---- (B) rows -------------------------------------------------------------------------
         // slide the query-time window (the lanes' cursors are within R rows of the flush cursor)
-        if (q_flush < A.nq && (unsigned)(q_flush - qwin_base) >= (unsigned)(DENSE_QWIN - R - 2)) {
+        if ((unsigned)(q_flush - qwin_base) >= (unsigned)(DENSE_QWIN - R - 2)) {
             const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
             const int nact = __builtin_popcountll(act);
             const int rank = __builtin_popcountll(act & ((1ull << lane) - 1ull));
@@ -251,11 +246,16 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             if (__builtin_amdgcn_ballot_w64(!(has_row || owes_zeros || stuck)) != 0ull) break;  // somebody is still on its way
             // nobody has produced it: only a wave whose lanes have ALL stopped for good fills in zeros here
             if (__builtin_amdgcn_ballot_w64(has_row) == 0ull && __builtin_amdgcn_ballot_w64(!owes_zeros) != 0ull) break;
+            // every lane reads its column of the slot (five reads in flight, one wait); what it has not
+            // produced is replaced by the zeros it owes
+            const lds_double_ptr slot = ring + (q_flush % R) * (NEQ * WAVE);
+            double v[NEQ];
+#pragma unroll
+            for (int c = 0; c < NEQ; ++c) v[c] = slot[c * WAVE];
             if (q_flush >= my_start_q && (has_row || owes_zeros)) {
-                const lds_double_ptr slot = ring + (q_flush % R) * (NEQ * WAVE);
                 double* o = row0 + (size_t)(q_flush - qb) * Q_STRIDE;
 #pragma unroll
-                for (int c = 0; c < NEQ; ++c) o[c * WAVE] = has_row ? slot[c * WAVE] : 0.0;  // 64 lanes x 8 B: 512 contiguous bytes
+                for (int c = 0; c < NEQ; ++c) o[c * WAVE] = has_row ? v[c] : 0.0;  // 64 lanes x 8 B: 512 contiguous bytes
             }
             ++q_flush;
             flushed = true;
