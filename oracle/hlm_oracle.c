@@ -114,6 +114,59 @@ void hlm_oracle_rhs(int uid, double t, const double* y, double* dydt,
         rhs_dummy(y, dydt);
 }
 
+/* d(rhs)/dy of the two models above, for the Radau-IIA pass (the reference differentiates
+ * numerically, radau_step_dense.cuh:13-31: 5 more RHS calls per attempt; the models' RHS are piecewise
+ * linear apart from the Manning term, so the exact one-sided derivative is a handful of comparisons).
+ * Every min / max contributes the derivative of the operand it returns (a < b picks a), exactly the
+ * choice the RHS itself makes; w = min(1, c h^(2/3)) gives d(h w)/dh = 5/3 c h^(2/3) below the cap and
+ * 1 at it (also for h < 0, where the RHS drains at rate 1: SURVEY A.1 note 6). */
+void hlm_oracle_jacobian(int uid, const double* y, double Jm[NEQ][NEQ],
+                         const hlm_oracle_spatial_params* P, const double* F, int nforc)
+{
+    for (int i = 0; i < NEQ; ++i)
+        for (int j = 0; j < NEQ; ++j) Jm[i][j] = 0.0;
+    if (uid != HLM_ORACLE_UID_204) {  /* DummyModel: constant */
+        Jm[0][0] = -0.5;
+        Jm[1][0] = 0.5; Jm[1][1] = -0.9;
+        Jm[2][1] = 0.3;
+        Jm[3][1] = 0.6; Jm[3][3] = -0.4;
+        Jm[4][3] = 0.4;
+        return;
+    }
+    const double h_snow = y[0], h_stat = y[1], h_surf = y[2];
+    const double rainfall = nforc > 0 ? F[0] : 0.0;
+    const double temperature = nforc > 1 ? F[1] : 0.0;
+    const double melt_pot = temperature * P->melt_f;
+    const int warm = temperature >= P->temp_thr;
+    const double snowmelt = warm ? fmin(h_snow, melt_pot) : 0.0;
+    const double m = (warm && h_snow < melt_pot) ? 1.0 : 0.0;       /* d snowmelt / d h_snow */
+    const double x1 = rainfall + snowmelt;
+    const double over = x1 + h_stat - P->Hu;
+    const double x2 = fmax(0.0, over);
+    const double a = over > 0.0 ? 1.0 : 0.0;                        /* d x2 / d (x1 + h_stat) */
+    const double e_pot = 0.1 * temperature;
+    const double Emax = fmin(e_pot, h_stat);
+    const double e = h_stat < e_pot ? 1.0 : 0.0;                    /* d Emax / d h_stat */
+    const double s = h_stat / P->Hu;
+    const double x3 = fmin(x2, P->infil);
+    const double b = x2 < P->infil ? 1.0 : 0.0;                     /* d x3 / d x2 */
+    const double c = x3 < P->perco ? 1.0 : 0.0;                     /* d x4 / d x3 */
+    const double alfa2 = (1.0 / P->n_mann) * pow(h_surf, 2.0 / 3.0) * sqrt(P->slope);
+    const double w_lin = alfa2 * P->L / P->A_h * 60.0;              /* NaN for h_surf < 0: the cap applies */
+    Jm[0][0] = -m;
+    Jm[1][0] = m - a * m;
+    Jm[1][1] = -a - (Emax / P->Hu + s * e);
+    Jm[2][0] = (1.0 - b) * a * m;
+    Jm[2][1] = (1.0 - b) * a;
+    Jm[2][2] = -(w_lin < 1.0 ? (5.0 / 3.0) * w_lin : 1.0);
+    Jm[3][0] = (1.0 - c) * b * a * m;
+    Jm[3][1] = (1.0 - c) * b * a;
+    Jm[3][3] = -(P->alpha3 >= 1.0 ? 1.0 / P->alpha3 : 0.0);
+    Jm[4][0] = c * b * a * m;
+    Jm[4][1] = c * b * a;
+    Jm[4][4] = -(P->alpha4 >= 1.0 ? 1.0 / P->alpha4 : 0.0);
+}
+
 /* rk45_step_dense.cuh:94-142 */
 void hlm_oracle_rk45_step(int uid, double t, const double* y, double h, double rtol,
                           double atol, const hlm_oracle_spatial_params* sp,

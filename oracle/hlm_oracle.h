@@ -105,6 +105,9 @@ void hlm_oracle_reorder_dense(const double* raw, double* out, int ns, int nq);
 /* Single evaluations for known-answer tests. */
 void hlm_oracle_rhs(int uid, double t, const double* y, double* dydt,
                     const hlm_oracle_spatial_params* sp, const double* F, int nforc);
+/* exact one-sided d(rhs)/dy (row-major J[i][j] = d dydt_i / d y_j) used by the Radau-IIA pass */
+void hlm_oracle_jacobian(int uid, const double* y, double Jm[HLM_ORACLE_NEQ][HLM_ORACLE_NEQ],
+                         const hlm_oracle_spatial_params* sp, const double* F, int nforc);
 /* rk45_step_dense.cuh:33-145.  k[0] must hold rhs(t,y).  F are the (double-converted)
  * forcing values held for all stages. */
 void hlm_oracle_rk45_step(int uid, double t, const double* y, double h, double rtol,

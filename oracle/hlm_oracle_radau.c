@@ -39,7 +39,6 @@ static const double RP[NS][3] = {
 
 #define NEWTON_MAXITER 10   /* radau_step_dense.cuh:87 */
 #define NEWTON_TOL 1e-3     /* in units of the error tolerance (RADAU5: min(0.03, sqrt(rtol))) */
-#define FD_EPS 1e-8         /* radau_step_dense.cuh:20: sqrt(1e-16) */
 
 /* real 5x5 LU with partial pivoting; the reciprocal pivots are kept for the solves.
  * Returns 0 if a pivot is (numerically) zero. */
@@ -177,17 +176,12 @@ static void radau_one(const hlm_oracle_job* J, int sys)
         if (clipped) h = t_end - t;
         ++n_attempt;
 
-        /* f0 and the finite-difference Jacobian at (t, y) (radau_step_dense.cuh:13-31) */
+        /* f0 and the Jacobian at (t, y).  The reference differentiates numerically
+         * (approx_jacobian, radau_step_dense.cuh:13-31: delta_j = 1e-8 max(1, |y_j|), 5 more RHS
+         * calls); the models here supply the exact one-sided derivative (hlm_oracle_jacobian). */
         double f0[NEQ], Jm[NEQ][NEQ];
         hlm_oracle_rhs(J->uid, t, y, f0, sp, F, J->nforc);
-        for (int j = 0; j < NEQ; ++j) {
-            double yp[NEQ], f1[NEQ];
-            const double d = FD_EPS * fmax(1.0, fabs(y[j]));
-            for (int i = 0; i < NEQ; ++i) yp[i] = y[i];
-            yp[j] += d;
-            hlm_oracle_rhs(J->uid, t, yp, f1, sp, F, J->nforc);
-            for (int i = 0; i < NEQ; ++i) Jm[i][j] = (f1[i] - f0[i]) / d;
-        }
+        hlm_oracle_jacobian(J->uid, y, Jm, sp, F, J->nforc);
 
         /* LU of (g/h) I - J (Newton's real block AND the error estimator) and of ((a - ib)/h) I - J */
         double Mr[NEQ][NEQ], Cr[NEQ][NEQ], Ci[NEQ][NEQ], inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];

@@ -67,6 +67,8 @@ def _declare(_lib):
         _lib.hlm_oracle_reorder_dense.restype = None
         _lib.hlm_oracle_rhs.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.hlm_oracle_rhs.restype = None
+        _lib.hlm_oracle_jacobian.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        _lib.hlm_oracle_jacobian.restype = None
         _lib.hlm_oracle_rk45_step.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_double,
                                              C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib.hlm_oracle_rk45_step.restype = None
@@ -105,6 +107,16 @@ def rhs(uid, y, sp=None, F=(), t=0.0):
     Fd = np.ascontiguousarray(np.asarray(F, dtype=np.float32).astype(np.float64))
     spa = None if sp is None else np.ascontiguousarray(sp, dtype=SP_DTYPE)
     lib().hlm_oracle_rhs(uid, t, _p(y), _p(out), _p(spa), _p(Fd) if len(Fd) else None, len(Fd))
+    return out
+
+
+def jacobian(uid, y, sp=None, F=()):
+    """d(rhs)/dy, J[i][j] = d dydt_i / d y_j: the exact one-sided derivative the Radau pass uses."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    out = np.zeros((NEQ, NEQ))
+    Fd = np.ascontiguousarray(np.asarray(F, dtype=np.float32).astype(np.float64))
+    spa = None if sp is None else np.ascontiguousarray(sp, dtype=SP_DTYPE)
+    lib().hlm_oracle_jacobian(uid, _p(y), _p(out), _p(spa), _p(Fd) if len(Fd) else None, len(Fd))
     return out
 
 

@@ -94,3 +94,42 @@ def test_radau_attempt_cap_flags_and_zeroes(oracle):
     r = oracle.run(oracle.UID_DUMMY, y0, 0.0, 5.0, query=synth.dummy_query_times(5.0, 20), radau_only=True, attempt_cap=4)
     assert (r["stiff"] == 2).all() and np.all(r["y_final"] == 0.0) and (r["n_attempt"] == 4).all()
     assert np.all(r["dense"][:, -1] == 0.0)  # rows past the cap stay zero
+
+
+def test_analytic_jacobian_equals_finite_differences(oracle):
+    """The Radau pass takes d(rhs)/dy from the model instead of the reference's finite differences
+    (approx_jacobian, radau_step_dense.cuh:13-31).  Away from the kinks of the min / max terms the two
+    must agree: random Model 204 states in every regime (cold / warm, saturated / not, wet / dry /
+    negative surface store, infiltration and percolation limited or not) and the DummyModel."""
+    from tiger_hlm_gpu_amd import synth
+    rng = np.random.default_rng(5)
+    n = 400
+    sp = synth.model204_params(0, n, seed=11)
+    sp["Hu"] = np.where(rng.random(n) < 0.5, sp["Hu"], 10.0 ** rng.uniform(-3, 0, n))
+    worst = 0.0
+    checked = 0
+    for i in range(n):
+        y = np.array([rng.uniform(0, 0.05), rng.uniform(0, 3.0), rng.choice([0.0, rng.uniform(1e-6, 0.02), -1e-4]),
+                      rng.uniform(0, 5), rng.uniform(0, 1)])
+        F = (rng.choice([0.0, rng.uniform(1e-6, 1e-3)]), rng.uniform(-5, 15))
+        Ja = oracle.jacobian(oracle.UID_204, y, sp[i:i + 1], F)
+        f0 = oracle.rhs(oracle.UID_204, y, sp[i:i + 1], F)
+        Jf = np.zeros((5, 5))
+        kink = False
+        for j in range(5):
+            d = 1e-7 * max(1.0, abs(y[j]))
+            yp, ym = y.copy(), y.copy()
+            yp[j] += d
+            ym[j] -= d
+            fp, fm = oracle.rhs(oracle.UID_204, yp, sp[i:i + 1], F), oracle.rhs(oracle.UID_204, ym, sp[i:i + 1], F)
+            Jf[:, j] = (fp - fm) / (2 * d)
+            # a kink inside [y - d, y + d]: the one-sided slopes differ, the state is skipped
+            kink |= bool(np.any(np.abs((fp - f0) - (f0 - fm)) > 1e-6 * d + 1e-18)) and y[2] <= 0.0 or \
+                bool(np.any(np.abs((fp - f0) / d - (f0 - fm) / d) > 1e-3 * (np.abs(Jf[:, j]) + 1e-12)))
+        if kink:
+            continue
+        checked += 1
+        worst = max(worst, float(np.abs(Ja - Jf).max() / (np.abs(Jf).max() + 1e-12)))
+    assert checked > n // 2 and worst < 1e-5, (checked, worst)
+    M = np.array([[-0.5, 0, 0, 0, 0], [0.5, -0.9, 0, 0, 0], [0, 0.3, 0, 0, 0], [0, 0.6, 0, -0.4, 0], [0, 0, 0, 0.4, 0]])
+    assert np.array_equal(oracle.jacobian(oracle.UID_DUMMY, np.ones(5)), M)

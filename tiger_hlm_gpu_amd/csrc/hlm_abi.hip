@@ -305,12 +305,12 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     // system (half a minute), not the RK45 loop's 2^24, so a hopeless system cannot hold a wave for long
     if (!j->attempt_cap) a.cap = 1u << 20;
     const unsigned blocks = (unsigned)((ns + hlm::WAVE - 1) / hlm::WAVE);  // blocks past the count exit at once
-    if (j->uid == HLM_UID_204)
-        hipLaunchKernelGGL(hlm::radau_fallback_kernel<hlm::Model204Dev>, dim3(blocks), dim3(hlm::WAVE), 0, stream, a,
-                           scratch + 1, scratch);
-    else
-        hipLaunchKernelGGL(hlm::radau_fallback_kernel<hlm::DummyDev>, dim3(blocks), dim3(hlm::WAVE), 0, stream, a,
-                           scratch + 1, scratch);
+    using RadauFn = void (*)(const hlm::Rk45Args, const int*, const int*);
+    const bool fast = j->math_mode == HLM_MATH_FAST;
+    RadauFn rf = j->uid == HLM_UID_204
+                     ? (fast ? hlm::radau_fallback_kernel<hlm::Model204Dev, hlm::MATH_FAST> : hlm::radau_fallback_kernel<hlm::Model204Dev, hlm::MATH_STRICT>)
+                     : (fast ? hlm::radau_fallback_kernel<hlm::DummyDev, hlm::MATH_FAST> : hlm::radau_fallback_kernel<hlm::DummyDev, hlm::MATH_STRICT>);
+    hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, scratch + 1, scratch);
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(scratch, stream));  // stream-ordered: after the kernels above
     HLM_HIP_TRY(launched);

@@ -257,6 +257,59 @@ struct Model204Dev {
         return rhs_impl<MATH, true>(P, F, y, dydt);
     }
 
+    // d(rhs)/dy for the Radau-IIA pass: the exact one-sided derivative (every min / max contributes the
+    // derivative of the operand it returns; w = min(1, c h^(2/3)) gives d(h w)/dh = 5/3 c h^(2/3) below
+    // the cap and 1 at it, also for h < 0).  Same text as oracle/hlm_oracle.c:hlm_oracle_jacobian.
+    static constexpr bool HAS_JACOBIAN = true;
+    static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;  // a cascade: store i only feels stores j <= i
+    template <int MATH>
+    static __device__ __forceinline__ void jacobian(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
+                                                    double (&J)[HLM_NEQ][HLM_NEQ])
+    {
+#pragma unroll
+        for (int i = 0; i < HLM_NEQ; ++i)
+#pragma unroll
+            for (int j = 0; j < HLM_NEQ; ++j) J[i][j] = 0.0;
+        const double h_snow = y[0], h_stat = y[1], h_surf = y[2];
+        const bool warm = F.warm_mask != 0ull;
+        const double snowmelt = warm ? fmin(h_snow, F.melt_pot) : 0.0;
+        const double m = (warm && h_snow < F.melt_pot) ? 1.0 : 0.0;
+        const double x1 = F.rain + snowmelt;
+        const double over = x1 + h_stat - P.Hu;
+        const double x2 = fmax(0.0, over);
+        const double a = over > 0.0 ? 1.0 : 0.0;
+        const double Emax = fmin(F.e_pot, h_stat);
+        const double e = h_stat < F.e_pot ? 1.0 : 0.0;
+        const double x3 = fmin(x2, P.infil);
+        const double b = x2 < P.infil ? 1.0 : 0.0;
+        const double c = x3 < P.perco ? 1.0 : 0.0;
+        double w_lin, s, dEmax;
+        if constexpr (MATH == MATH_FAST) {
+            w_lin = P.manning * pow_two_thirds<MATH>(h_surf);
+            s = h_stat * P.inv_Hu;
+            dEmax = Emax * P.inv_Hu;
+            J[3][3] = -P.inv_alpha3;
+            J[4][4] = -P.inv_alpha4;
+        } else {
+            const double alfa2 = P.inv_n * pow_two_thirds<MATH>(h_surf) * P.sqrt_slope;
+            w_lin = alfa2 * P.L / P.A_h * 60.0;
+            s = h_stat / P.Hu;
+            dEmax = Emax / P.Hu;
+            J[3][3] = -(P.alpha3 >= 1.0 ? 1.0 / P.alpha3 : 0.0);
+            J[4][4] = -(P.alpha4 >= 1.0 ? 1.0 / P.alpha4 : 0.0);
+        }
+        J[0][0] = -m;
+        J[1][0] = m - a * m;
+        J[1][1] = -a - (dEmax + s * e);
+        J[2][0] = (1.0 - b) * a * m;
+        J[2][1] = (1.0 - b) * a;
+        J[2][2] = -(w_lin < 1.0 ? (5.0 / 3.0) * w_lin : 1.0);
+        J[3][0] = (1.0 - c) * b * a * m;
+        J[3][1] = (1.0 - c) * b * a;
+        J[4][0] = c * b * a * m;
+        J[4][1] = c * b * a;
+    }
+
     template <int MATH, bool DRY>
     static __device__ __forceinline__ bool rhs_impl(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
                                                     double (&dydt)[HLM_NEQ])
@@ -335,6 +388,19 @@ struct DummyDev {
     template <int MATH>
     static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[HLM_NEQ],
                                                     double (&)[HLM_NEQ]) { return true; }
+    static constexpr bool HAS_JACOBIAN = true;  // constant: the system is linear
+    static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;
+    template <int MATH>
+    static __device__ __forceinline__ void jacobian(const Local&, const Forc&, const double (&)[HLM_NEQ],
+                                                    double (&J)[HLM_NEQ][HLM_NEQ])
+    {
+        const double M[HLM_NEQ][HLM_NEQ] = {{-0.5, 0, 0, 0, 0}, {0.5, -0.9, 0, 0, 0}, {0, 0.3, 0, 0, 0},
+                                            {0, 0.6, 0, -0.4, 0}, {0, 0, 0, 0.4, 0}};
+#pragma unroll
+        for (int i = 0; i < HLM_NEQ; ++i)
+#pragma unroll
+            for (int j = 0; j < HLM_NEQ; ++j) J[i][j] = M[i][j];
+    }
 
     template <int MATH>
     static __device__ __forceinline__ Local load(const void*, int) { return Local{}; }

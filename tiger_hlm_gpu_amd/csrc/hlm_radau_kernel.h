@@ -181,6 +181,37 @@ __device__ __forceinline__ void solve_cplx(const double (&ar)[NEQ][NEQ], const d
     }
 }
 
+// ---- models whose Jacobian is LOWER TRIANGULAR (a cascade of stores: each one only feels the stores
+// upstream of it -- Model 204 and the DummyModel are such).  Then mu/h I - J is triangular as well: no
+// factorisation, no pivoting (LU with partial pivoting would not pivot either: |mu/h - J_ii| exceeds the
+// entries below it), the solves are forward substitutions.  Entries a model's jacobian() leaves at the
+// literal 0.0 drop out at compile time.
+__device__ __forceinline__ void solve_real_tri(const double (&Jm)[NEQ][NEQ], const double (&inv)[NEQ], double (&b)[NEQ])
+{
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) {
+        double s = b[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s += Jm[i][j] * b[j];  // the matrix entry is -J_ij
+        b[i] = s * inv[i];
+    }
+}
+__device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], const double (&ir)[NEQ], const double (&ii)[NEQ],
+                                               double (&br)[NEQ], double (&bi)[NEQ])
+{
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) {
+        double sr = br[i], si = bi[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) {
+            sr += Jm[i][j] * br[j];
+            si += Jm[i][j] * bi[j];
+        }
+        br[i] = sr * ir[i] - si * ii[i];
+        bi[i] = sr * ii[i] + si * ir[i];
+    }
+}
+
 }  // namespace radau
 
 // compacts the indices of the systems flagged HLM_SYS_STIFF into list[0 .. *count)
@@ -191,12 +222,19 @@ __global__ void radau_collect_kernel(const int32_t* __restrict__ stiff, int ns, 
     if (i < ns && stiff[i] == HLM_SYS_STIFF) list[atomicAdd(count, 1)] = i;
 }
 
-template <class Model>
-__global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args A, const int* __restrict__ list,
+// MATH: the arithmetic of the model's RHS (hlm_set_math_mode / hlm_device_job.math_mode), as in the RK45
+// kernel.  It matters here more than there: an attempt evaluates the RHS 6 + 3 per Newton iteration
+// = ~14 times, and STRICT's OCML pow costs ~200 instructions each.
+// Occupancy: the general path keeps two 5x5 LU factorisations (75 doubles) in registers: one wave per
+// SIMD.  With a triangular Jacobian they are gone and two waves fit.
+#ifndef HLM_RADAU_TRI_WAVES
+#define HLM_RADAU_TRI_WAVES 2
+#endif
+template <class Model, int MATH>
+__global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR) ? HLM_RADAU_TRI_WAVES : 1) radau_fallback_kernel(const Rk45Args A, const int* __restrict__ list,
                                                                  const int* __restrict__ count)
 {
     using namespace radau;
-    constexpr int MATH = MATH_STRICT;
     const int lane = (int)threadIdx.x;
     const int slot = (int)(blockIdx.x * WAVE) + lane;
     if (slot >= *count) return;
@@ -263,34 +301,61 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
         if (clipped) h = t_end - t;
         ++n_attempt;
 
-        // f0 and the finite-difference Jacobian
+        // f0 and the Jacobian: the model's exact one-sided derivative where it supplies one, else the
+        // reference's finite differences (approx_jacobian, radau_step_dense.cuh:13-31: 5 more RHS calls)
         double f0[NEQ], Jm[NEQ][NEQ];
         Model::template rhs<MATH>(P, FV, y, f0);
-#pragma unroll
-        for (int j = 0; j < NEQ; ++j) {
-            double yp[NEQ], f1[NEQ];
-            const double d = FD_EPS * fmax(1.0, fabs(y[j]));
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) yp[i] = y[i];
-            yp[j] += d;
-            Model::template rhs<MATH>(P, FV, yp, f1);
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) Jm[i][j] = (f1[i] - f0[i]) / d;
-        }
-        // LU of (g/h) I - J (Newton's real block and the error estimator) and of ((a - ib)/h) I - J
-        double Mr[NEQ][NEQ], Cr[NEQ][NEQ], Ci[NEQ][NEQ], inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
-        int piv_r[NEQ], piv_c[NEQ];
-        const double g_h = MU_REAL / h, a_h = MU_CRE / h, b_h = MU_CIM / h;
-#pragma unroll
-        for (int i = 0; i < NEQ; ++i)
+        if constexpr (Model::HAS_JACOBIAN) {
+            Model::template jacobian<MATH>(P, FV, y, Jm);
+        } else {
 #pragma unroll
             for (int j = 0; j < NEQ; ++j) {
-                Mr[i][j] = ((i == j) ? g_h : 0.0) - Jm[i][j];
-                Cr[i][j] = ((i == j) ? a_h : 0.0) - Jm[i][j];
-                Ci[i][j] = (i == j) ? -b_h : 0.0;
+                double yp[NEQ], f1[NEQ];
+                const double d = FD_EPS * fmax(1.0, fabs(y[j]));
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) yp[i] = y[i];
+                yp[j] += d;
+                Model::template rhs<MATH>(P, FV, yp, f1);
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) Jm[i][j] = (f1[i] - f0[i]) / d;
             }
-        bool ok = lu_real(Mr, piv_r, inv_r);
-        ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci) && ok;
+        }
+        // (g/h) I - J (Newton's real block and the error estimator) and ((a - ib)/h) I - J: LU with partial
+        // pivoting in general; for a lower-triangular J just the reciprocals of the diagonals
+        constexpr bool TRI = Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR;
+        [[maybe_unused]] double Mr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Cr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Ci[TRI ? 1 : NEQ][TRI ? 1 : NEQ];
+        double inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
+        [[maybe_unused]] int piv_r[NEQ], piv_c[NEQ];
+        const double g_h = MU_REAL / h, a_h = MU_CRE / h, b_h = MU_CIM / h;
+        bool ok = true;
+        if constexpr (TRI) {
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) {
+                const double dr = g_h - Jm[i][i], cr = a_h - Jm[i][i];
+                inv_r[i] = 1.0 / dr;
+                const double d = 1.0 / (cr * cr + b_h * b_h);  // 1 / ((a/h - J_ii) - i b/h)
+                inv_cr[i] = cr * d;
+                inv_ci[i] = b_h * d;
+                ok = ok && fabs(dr) > 1e-300;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i)
+#pragma unroll
+                for (int j = 0; j < NEQ; ++j) {
+                    Mr[i][j] = ((i == j) ? g_h : 0.0) - Jm[i][j];
+                    Cr[i][j] = ((i == j) ? a_h : 0.0) - Jm[i][j];
+                    Ci[i][j] = (i == j) ? -b_h : 0.0;
+                }
+            ok = lu_real(Mr, piv_r, inv_r);
+            ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci) && ok;
+        }
+        auto solve_r = [&](double (&b)[NEQ]) {
+            if constexpr (TRI) solve_real_tri(Jm, inv_r, b); else solve_real(Mr, piv_r, inv_r, b);
+        };
+        auto solve_c = [&](double (&br)[NEQ], double (&bi)[NEQ]) {
+            if constexpr (TRI) solve_cplx_tri(Jm, inv_cr, inv_ci, br, bi); else solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, br, bi);
+        };
 
         // simplified Newton on W = (TI (x) I) Z,  Z_i = Y_i - y
         double Z[NS][NEQ], W[NS][NEQ];
@@ -316,8 +381,8 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
                 d1[i] = (TI[1][0] * Fs[0][i] + TI[1][1] * Fs[1][i] + TI[1][2] * Fs[2][i]) - (a_h * W[1][i] + b_h * W[2][i]);
                 d2[i] = (TI[2][0] * Fs[0][i] + TI[2][1] * Fs[1][i] + TI[2][2] * Fs[2][i]) - (a_h * W[2][i] - b_h * W[1][i]);
             }
-            solve_real(Mr, piv_r, inv_r, d0);
-            solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, d1, d2);
+            solve_r(d0);
+            solve_c(d1, d2);
             double nrm = 0.0, chk = 0.0;
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) {
@@ -344,7 +409,7 @@ __global__ void __launch_bounds__(WAVE, 1) radau_fallback_kernel(const Rk45Args 
             y_new[i] = y[i] + Z[2][i];
             ev[i] = f0[i] + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) / h;
         }
-        solve_real(Mr, piv_r, inv_r, ev);
+        solve_r(ev);
         double err = 0.0;
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) {
