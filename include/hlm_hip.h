@@ -98,6 +98,8 @@ int hlm_get_model_parameters(int uid, double p[6]);
 int hlm_set_fixed_step(int uid, double h);
 int hlm_set_attempt_cap(uint32_t cap);
 int hlm_set_math_mode(int mode);
+/* 1: the host API's launches without dense output use lane refill (hlm_device_job.lane_refill). */
+int hlm_set_lane_refill(int enabled);
 /* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
  * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free); 0 (default): flagged systems
  * keep stiff = 1 and zero rows, the reference's observable behaviour. */
@@ -219,6 +221,13 @@ typedef struct hlm_device_job {
     double t_stop;
     uint64_t forc_first_index[HLM_MAX_FORCINGS];
     uint64_t forc_rows[HLM_MAX_FORCINGS];
+    /* 1: lane refill (build feature; hlm_rk45_refill_kernel.h).  A persistent grid in which a lane whose
+     * hillslope is finished or flagged takes the next one from a device queue instead of idling until the
+     * slowest hillslope of its wave is through (the reference's one-system-per-thread map,
+     * rk45_kernel.cu:33).  Bit-identical results; pays when trip counts within a wave differ (cold cells
+     * flagged early next to hillslopes that run 30 days).  Used for launches without dense output and
+     * without resume state; ignored otherwise. */
+    int lane_refill;
 } hlm_device_job;
 
 size_t hlm_resume_bytes(int num_systems);

@@ -832,6 +832,46 @@ def test_full_size_idempotence_and_properties(gpu):
     assert a["n_attempt"][ok].min() > 500 and a["n_attempt"].max() < 2000
 
 
+@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step"])
+def test_lane_refill_is_bit_identical_to_the_fixed_map(gpu, case):
+    """hlm_device_job.lane_refill: a persistent grid whose lanes take the next hillslope from a queue
+    when theirs is finished or flagged.  Which lane integrates which hillslope changes, nothing else:
+    finals, flags and both counters of every hillslope equal the one-system-per-thread launch
+    (rk45_kernel.cu:33) bit for bit -- with early-flagged cold cells (lanes refill at different times),
+    on the benchmark workload (whole waves refill at once; 300 000 hillslopes = more than the 196 608 the
+    persistent grid starts with), on fewer hillslopes than one wave, with the attempt cap, in fixed-step mode."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    kw = {}
+    if case == "cold-cells":
+        ns, days = 250_037, 6
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
+    elif case == "benchmark":
+        ns, days = 300_000, 2
+        pr, t2m, dt, nT = synth.forcing_tables(days=days)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
+    elif case == "ragged-small":
+        ns, days = 37, 3
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=True), synth.model204_params(0, ns), days * 1440.0
+    elif case == "dummy-capped":
+        ns = 1000
+        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 500.0, dict(attempt_cap=100)
+    else:
+        ns = 777
+        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 50.0, dict(fixed_step=0.05)
+    forcing = None if sp is None else (pr, t2m, synth.cell_of_system(0, ns, run_len=64), dt, nT)
+    a = _run_engine(H, model, y0, 0.0, tf, sp=sp, forcing=forcing, per_cell=True, **kw)
+    b = _run_engine(H, model, y0, 0.0, tf, sp=sp, forcing=forcing, per_cell=True, lane_refill=True, **kw)
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(a[k], b[k]), (case, k)
+    if case == "cold-cells":
+        assert 0.05 < (a["stiff"] == 1).mean() < 0.95
+    if case == "dummy-capped":
+        assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()
+
+
 def test_c4_four_million_hillslopes_whole_equals_its_eight_shards(gpu):
     """BASELINE config 4 size: 4 000 000 hillslopes.  Without 8 GPUs at hand the eight contiguous
     shards of the reference's split rule (main.cpp:275-307; 500 000 each) run one after the other on

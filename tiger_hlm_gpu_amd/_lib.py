@@ -55,6 +55,7 @@ class DeviceJob(C.Structure):
         ("query_begin", C.c_int), ("query_end", C.c_int), ("d_resume", C.c_void_p), ("resume_in", C.c_int),
         ("dense_tiled", C.c_int), ("use_t_stop", C.c_int), ("t_stop", C.c_double),
         ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
+        ("lane_refill", C.c_int),
     ]
 
 
@@ -81,6 +82,7 @@ SIGNATURES = {
     "hlm_set_attempt_cap": (C.c_int, [C.c_uint32]),
     "hlm_set_math_mode": (C.c_int, [C.c_int]),
     "hlm_set_radau_fallback": (C.c_int, [C.c_int]),
+    "hlm_set_lane_refill": (C.c_int, [C.c_int]),
     "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
                                    C.c_int64, C.c_void_p]),
     "hlm_set_forcings_host": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,

@@ -16,6 +16,7 @@
 #include "hlm_radau_kernel.h"
 #include "hlm_rk45_dense_kernel.h"
 #include "hlm_rk45_kernel.h"
+#include "hlm_rk45_refill_kernel.h"
 
 namespace {
 
@@ -58,6 +59,7 @@ int g_stream_layout = hlm::DENSE_TILE_COMP;  // device layout of the tiled strea
 // with any tolerances the reference accepts gets a result, and with the usual ones the fast kernel.
 int g_math = HLM_MATH_FAST;
 bool g_math_explicit = false;
+int g_refill = 0;  // hlm_set_lane_refill(): host-API launches without dense output use the refill kernel
 int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
 
 struct ForcingState {
@@ -144,6 +146,22 @@ KernelFn pick_dense_ring(int uid, int math, bool fixed, bool res)
     return nullptr;
 }
 
+// the kernels with lane refill (hlm_rk45_refill_kernel.h): no dense output, no resume state
+using RefillFn = void (*)(const hlm::Rk45Args, unsigned int*);
+template <class Model>
+RefillFn pick_refill(int math, bool fixed)
+{
+    using namespace hlm;
+    if (math == HLM_MATH_FAST) return fixed ? rk45_refill_kernel<Model, MATH_FAST, true> : rk45_refill_kernel<Model, MATH_FAST, false>;
+    return fixed ? rk45_refill_kernel<Model, MATH_STRICT, true> : rk45_refill_kernel<Model, MATH_STRICT, false>;
+}
+RefillFn pick_refill(int uid, int math, bool fixed)
+{
+    if (uid == HLM_UID_204) return pick_refill<hlm::Model204Dev>(math, fixed);
+    if (uid == HLM_UID_DUMMY) return pick_refill<hlm::DummyDev>(math, fixed);
+    return nullptr;
+}
+
 KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
 {
     if (uid == HLM_UID_204) return pick_kernel<hlm::Model204Dev>(math, dense, fixed, resumable);
@@ -208,6 +226,7 @@ int validate_job(const hlm_device_job* j)
     }
     if (j->resume_in && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "resume_in without d_resume");
     if (j->dense_tiled < 0 || j->dense_tiled > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0, 1 or 2");
+    if (j->lane_refill != 0 && j->lane_refill != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane_refill must be 0 or 1");
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
@@ -268,10 +287,39 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     return a;
 }
 
+// Persistent launch with lane refill: as many one-wave workgroups as the device holds at once, the
+// rest of the hillslopes handed out through a device counter (hlm_rk45_refill_kernel.h).
+int launch_refill(const hlm_device_job* j, hipStream_t stream)
+{
+    const bool fixed = j->fixed_step > 0.0;
+    RefillFn fn = pick_refill(j->uid, j->math_mode, fixed);
+    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
+    int dev = 0, cus = 0, per_cu = 0;
+    HLM_HIP_TRY(hipGetDevice(&dev));
+    HLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HLM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), hlm::WAVE, 0));
+    const long long resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
+    const long long waves = ((long long)j->num_systems + hlm::WAVE - 1) / hlm::WAVE;
+    const unsigned blocks = (unsigned)(waves < resident ? waves : resident);
+    unsigned int* queue = nullptr;
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&queue), sizeof(unsigned int), stream));
+    if (hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(queue), (int)(blocks * (unsigned)hlm::WAVE), 1, stream); e != hipSuccess) {
+        (void)hipFreeAsync(queue, stream);
+        return fail(HLM_ERR_HIP, "hipMemsetD32Async failed: %s", hipGetErrorString(e));
+    }
+    const hlm::Rk45Args a = make_args(j);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue);
+    const hipError_t launched = hipGetLastError();
+    HLM_HIP_TRY(hipFreeAsync(queue, stream));  // stream-ordered: after the kernel
+    HLM_HIP_TRY(launched);
+    return HLM_SUCCESS;
+}
+
 int launch(const hlm_device_job* j, hipStream_t stream)
 {
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
+    if (!dense && j->lane_refill && !job_is_resumable(j)) return launch_refill(j, stream);
     KernelFn fn = dense && j->dense_tiled == hlm::DENSE_TILE_COMP
                       ? pick_dense_ring(j->uid, j->math_mode, fixed, job_is_resumable(j))
                       : pick(j->uid, j->math_mode, dense, fixed, job_is_resumable(j));
@@ -325,6 +373,7 @@ int fill_job_from_registry(hlm_device_job* j, int uid, const ForcingState& F)
     std::memcpy(j->params, m->p, sizeof(m->p));
     j->fixed_step = m->fixed_step;
     j->attempt_cap = g_cap;
+    j->lane_refill = g_refill;
     j->math_mode = g_math;
     if (!g_math_explicit && !(m->p[2] >= 1e-60 && m->p[2] <= 1e50)) j->math_mode = HLM_MATH_STRICT;
     j->d_forc = F.d_forc;
@@ -528,6 +577,14 @@ int hlm_radau_fallback_device(const hlm_device_job* job, void* hip_stream)
     if (rc != HLM_SUCCESS) return rc;
     if (job->num_systems == 0) return HLM_SUCCESS;
     return launch_radau(job, static_cast<hipStream_t>(hip_stream));
+}
+
+int hlm_set_lane_refill(int enabled)
+{
+    if (enabled != 0 && enabled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane refill flag %d (want 0 or 1)", enabled);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_refill = enabled;
+    return HLM_SUCCESS;
 }
 
 int hlm_set_radau_fallback(int enabled)

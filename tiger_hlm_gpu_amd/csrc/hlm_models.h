@@ -259,7 +259,7 @@ struct Model204Dev {
 
     // d(rhs)/dy for the Radau-IIA pass: the exact one-sided derivative (every min / max contributes the
     // derivative of the operand it returns; w = min(1, c h^(2/3)) gives d(h w)/dh = 5/3 c h^(2/3) below
-    // the cap and 1 at it, also for h < 0).  Same text as oracle/hlm_oracle.c:hlm_oracle_jacobian.
+    // the cap and 1 at it, also for h < 0).  Reference: model_204.hpp:86-113 differentiated term by term.
     static constexpr bool HAS_JACOBIAN = true;
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;  // a cascade: store i only feels stores j <= i
     template <int MATH>

@@ -15,7 +15,7 @@ from .models import Parameters, SP_DTYPE
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
                  math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
-                 dense_tiled=2):
+                 dense_tiled=2, lane_refill=False):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -24,6 +24,7 @@ class ShardEngine:
         self.t0, self.tf = float(t0), float(tf)
         self.params = params if params is not None else Parameters()
         self.math_mode, self.fixed_step, self.attempt_cap = math_mode, fixed_step, attempt_cap
+        self.lane_refill = int(bool(lane_refill))  # hlm_device_job.lane_refill (launches without dense output)
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
         self.ns = y0.shape[0]
         dev = self.device
@@ -91,6 +92,7 @@ class ShardEngine:
             attempt_cap=self.attempt_cap, math_mode=self.math_mode, y_final=self.y_final,
             dense=self.dense, stiff=self.stiff, n_attempt=self.n_attempt, n_accept=self.n_accept)
         j.dense_tiled = self.dense_tiled if self.dense is not None else 0
+        j.lane_refill = self.lane_refill
         return j
 
     def integrate(self, stream=None, t_stop=None, resume_in=False, radau=False):
