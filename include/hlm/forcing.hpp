@@ -6,6 +6,7 @@
 // in-memory per-cell tables or constant values.
 #pragma once
 
+#include <cstdint>
 #include <fstream>
 #include <stdexcept>
 #include <string>
@@ -45,6 +46,38 @@ private:
     std::string path_;
     std::unordered_map<long long, std::pair<int, int>> map_;
 };
+
+// One forcing column per DISTINCT grid cell instead of one per stream (main.cpp:527-549 expands every
+// forcing to [time][stream]; the sample lookup maps 41 274 streams to 88 cells).  For each stream id, in
+// order: the column of its cell (lat * lon_size + lon, main.cpp:503-504), columns numbered in order of
+// first appearance; cell_of_col[c] is the flat grid index column c holds.  A stream without a valid cell
+// (the reference would index out of bounds with the {-1,-1} it gets back, main.cpp:503-504) is an error.
+struct CellColumns {
+    std::vector<int32_t> col_of_stream;
+    std::vector<size_t> cell_of_col;
+};
+template <class IdAt>
+inline CellColumns build_cell_columns(const LookupMapper& lm, size_t n_streams, IdAt id_at, size_t lat_size, size_t lon_size,
+                                      const std::string& lookup_name = "the lookup table")
+{
+    CellColumns cc;
+    cc.col_of_stream.resize(n_streams);
+    std::unordered_map<size_t, int32_t> col_of_cell;
+    for (size_t s = 0; s < n_streams; ++s) {
+        const long long id = id_at(s);
+        const auto [lat, lon] = lm.getLatLon(id);
+        if (lat < 0 || lon < 0 || (size_t)lat >= lat_size || (size_t)lon >= lon_size)
+            throw std::runtime_error("stream " + std::to_string(id) + " has no valid grid cell in " + lookup_name);
+        const size_t cell = (size_t)lat * lon_size + (size_t)lon;
+        auto it = col_of_cell.find(cell);
+        if (it == col_of_cell.end()) {
+            it = col_of_cell.emplace(cell, (int32_t)cc.cell_of_col.size()).first;
+            cc.cell_of_col.push_back(cell);
+        }
+        cc.col_of_stream[s] = it->second;
+    }
+    return cc;
+}
 
 struct ForcingBlock {
     std::vector<float> data;       // [sum nT][ld]

@@ -10,7 +10,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libhlm_oracle.so")
+# HLM_ORACLE_SO: another build of the same text (make -C oracle asan: AddressSanitizer + UBSan)
+_SO = os.environ.get("HLM_ORACLE_SO") or os.path.join(_HERE, "libhlm_oracle.so")
 _SO_FMA = os.path.join(_HERE, "libhlm_oracle_fma.so")  # conditioning yardstick, see the Makefile
 
 UID_DUMMY = 0

@@ -9,6 +9,8 @@ parameter table); no reference source text is copied.
   G1  src/final.csv, src/dense.csv            DummyModel, 4 identical systems, nq=10000
   G2  src/final_example.nc, dense_example.nc  Model 204, 10 systems, nq=2881 (1-min grid)
   IN  data/small_test.csv                      the parameter rows that reproduce G2
+  IN  data/small_example_pr_lookup.csv         the sample stream -> grid-cell lookup (41 274 streams, 88 cells;
+                                               the t2m lookup is byte-identical)
 """
 import json
 import os
@@ -63,6 +65,9 @@ def main():
     else:
         np.save(f"{HERE}/g2_m204_dense.npy", den)
     shutil.copyfile(f"{REF}/data/small_test.csv", f"{HERE}/small_test.csv")
+    # the sample lookup table (reference-held DATA): fixture for LookupMapper and the per-cell column index
+    shutil.copyfile(f"{REF}/data/small_example_pr_lookup.csv", f"{HERE}/lookup_small_example.csv")
+    assert open(f"{REF}/data/small_example_pr_lookup.csv", "rb").read() == open(f"{REF}/data/small_example_t2m_lookup.csv", "rb").read()
     # the two NetCDF-4 result files themselves (data, written by netcdf 4.9.2 / hdf5 1.14.4):
     # fixtures for the HDF5-based NetCDF reader, include/hlm/netcdf4_io.hpp
     shutil.copyfile(f"{REF}/src/final_example.nc", f"{HERE}/final_example.nc")

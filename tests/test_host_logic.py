@@ -250,3 +250,40 @@ def test_forcing_registration_needs_a_device(hlm):
         pytest.skip("a GPU is present")
     with pytest.raises(hlm.HlmError):
         hlm.api.clear_forcings()
+
+
+def test_lookup_mapper_and_cell_columns_on_the_reference_sample_lookup(hlm, tmp_path):
+    """The reference's own sample lookup (data/small_example_pr_lookup.csv, committed as a fixture:
+    41 274 streams on 88 grid cells) through both LookupMapper implementations
+    (forcing_loader.cpp:14-64) and through the per-cell column index the driver builds instead of the
+    reference's per-stream expansion (main.cpp:503-549), checked against an independent numpy reading."""
+    import subprocess
+    path = os.path.join(ROOT, "tests", "golden", "lookup_small_example.csv")
+    raw = np.loadtxt(path, delimiter=",", skiprows=1, dtype=np.int64)
+    assert raw.shape == (41274, 3) and len(np.unique(raw[:, 0])) == 41274
+    lat_size, lon_size = int(raw[:, 1].max()) + 1, int(raw[:, 2].max()) + 1
+    cell = raw[:, 1] * lon_size + raw[:, 2]
+    cells_in_order = list(dict.fromkeys(cell.tolist()))          # order of first appearance
+    assert len(cells_in_order) == 88
+    col = np.array([cells_in_order.index(c) for c in cell.tolist()])
+    # python mirror
+    lm = hlm.LookupMapper(path)
+    assert lm.load() and len(lm.map) == 41274
+    for i in (0, 1, 777, 41273):
+        assert lm.get_lat_lon(raw[i, 0]) == (raw[i, 1], raw[i, 2])
+    assert lm.get_lat_lon(-12345) == (-1, -1)
+    # C++ header
+    exe = str(tmp_path / "test_lookup")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cpp", "test_lookup.cpp"),
+                    "-o", exe], check=True)
+    out = subprocess.run([exe, path, str(lat_size), str(lon_size)], check=True, capture_output=True, text=True).stdout.splitlines()
+    assert out[0] == f"41274 88 {raw[0, 1]},{raw[0, 2]} -1,-1"
+    cols = [ln.split() for ln in out if ln.startswith("col ")]
+    assert [int(c[2]) for c in cols] == cells_in_order
+    assert [int(c[3]) for c in cols] == [int((col == k).sum()) for k in range(88)]
+    for ln in (ln.split() for ln in out if ln.startswith("stream ")):
+        i = int(np.flatnonzero(raw[:, 0] == int(ln[1]))[0])
+        assert int(ln[2]) == col[i]
+    # a grid smaller than the table's indices: the stream has no valid cell -> an error, not a wild index
+    bad = subprocess.run([exe, path, str(lat_size), str(lon_size - 1)], capture_output=True, text=True)
+    assert bad.returncode == 3 and "has no valid grid cell" in bad.stdout

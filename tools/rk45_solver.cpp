@@ -223,7 +223,6 @@ int run(const Options& o, hlm_io::CsvStyle style)
         LookupMapper lm(o.lookup);
         if (!lm.load()) throw std::runtime_error("Lookup load failed: " + o.lookup);
         std::vector<size_t> cell_of_col;
-        std::unordered_map<size_t, int32_t> col_of_cell;
         size_t lon_size = 0;
         const double days = std::ceil((tf - t0) / 1440.0);
         for (size_t fi = 0; fi < o.forcing_nc.size(); ++fi) {
@@ -236,18 +235,10 @@ int run(const Options& o, hlm_io::CsvStyle style)
             NetCDFLoader loader(path, var);
             if (fi == 0) {
                 lon_size = loader.getLonSize();
-                for (int s = 0; s < ns; ++s) {
-                    const auto [lat, lon] = lm.getLatLon(streams[s].id);
-                    if (lat < 0 || lon < 0 || (size_t)lat >= loader.getLatSize() || (size_t)lon >= lon_size)
-                        throw std::runtime_error("stream " + std::to_string(streams[s].id) + " has no valid grid cell in " + o.lookup);
-                    const size_t cell = (size_t)lat * lon_size + (size_t)lon;  // main.cpp:503-504
-                    auto it = col_of_cell.find(cell);
-                    if (it == col_of_cell.end()) {
-                        it = col_of_cell.emplace(cell, (int32_t)cell_of_col.size()).first;
-                        cell_of_col.push_back(cell);
-                    }
-                    col_of_stream[s] = it->second;
-                }
+                CellColumns cc = build_cell_columns(lm, (size_t)ns, [&](size_t s) { return (long long)streams[s].id; },
+                                                    loader.getLatSize(), lon_size, o.lookup);
+                col_of_stream = std::move(cc.col_of_stream);
+                cell_of_col = std::move(cc.cell_of_col);
                 fb.ld = (long long)cell_of_col.size();
             } else if (loader.getLonSize() != lon_size) {
                 throw std::runtime_error("forcing grids differ: " + path);
