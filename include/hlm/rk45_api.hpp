@@ -126,11 +126,11 @@ inline void set_radau_fallback(bool on) { detail::check(hlm_set_radau_fallback(o
 template <class Model>
 auto setup_gpu_buffers(const std::vector<double>& h_y0, const std::vector<double>& h_query_times)
 {
-    constexpr int N_EQ = Model::N_EQ;
-    static_assert(N_EQ == HLM_NEQ, "the gfx950 kernels are built for N_EQ = 5");
+    constexpr int N_EQ = Model::N_EQ;  // the kernels are templates over it (solver/rk45.h:51-66), one per registered model
+    static_assert(N_EQ >= 1 && N_EQ <= HLM_MAX_NEQ, "Model::N_EQ outside what the device kernels support");
     hlm_gpu_buffers b{};
-    detail::check(hlm_setup_gpu_buffers(h_y0.data(), int(h_y0.size() / N_EQ), h_query_times.data(),
-                                        int(h_query_times.size()), &b),
+    detail::check(hlm_setup_gpu_buffers_model(Model::UID, h_y0.data(), int(h_y0.size() / N_EQ), h_query_times.data(),
+                                              int(h_query_times.size()), &b),
                   "setup_gpu_buffers");
     {
         detail::Live& L = detail::live();
@@ -147,8 +147,9 @@ void launch_rk45_kernel(double* d_y0_all, double* d_y_final_all, double* d_query
                         int* d_stiff, int num_systems, int num_queries, double t0, double tf,
                         const typename Model::SP_TYPE* d_sp)
 {
-    const hlm_gpu_buffers b =
+    hlm_gpu_buffers b =
         detail::adopt(d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, num_systems, num_queries, false);
+    if (!b.neq) b.neq = Model::N_EQ;  // buffers the caller allocated itself
     detail::check(hlm_launch_rk45_kernel(Model::UID, &b, t0, tf, d_sp), "launch_rk45_kernel");
 }
 
@@ -162,6 +163,7 @@ std::pair<FinalType, DenseType> retrieve_and_free(double* d_y0_all, double* d_y_
     constexpr int N_EQ = Model::N_EQ;
     hlm_gpu_buffers b =
         detail::adopt(d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, num_systems, num_queries, true);
+    if (!b.neq) b.neq = N_EQ;
     FinalType h_final((size_t)num_systems * N_EQ);
     DenseType h_dense((size_t)num_systems * N_EQ * (size_t)num_queries);
     RunInfo info;

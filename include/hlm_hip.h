@@ -28,11 +28,14 @@ extern "C" {
 #endif
 
 #define HLM_ABI_VERSION 2
-#define HLM_NEQ 5           /* Model204::N_EQ, models/model_204.hpp:19 */
+#define HLM_NEQ 5           /* Model204::N_EQ, models/model_204.hpp:19 (and the DummyModel's) */
+#define HLM_MAX_NEQ 8       /* largest N_EQ a registered model may have (kernels are templates over it) */
 #define HLM_MAX_FORCINGS 16 /* I_O/forcing_data.h:5 */
 
 #define HLM_UID_DUMMY 0 /* DummyModel (README.md:41-42, rhs: model_dummy_python.ipynb:65-89) */
 #define HLM_UID_204 204 /* Model204::UID, models/model_204.hpp:18 */
+#define HLM_UID_TOY3 3  /* ToyModel3: N_EQ = 3, one forcing -- the build's "Add a New Model" example
+                         * (README.md plug-in section; include/hlm/models/model_toy3.hpp) */
 
 typedef enum {
     HLM_SUCCESS = 0,
@@ -133,12 +136,16 @@ typedef struct hlm_gpu_buffers {
     uint32_t* d_n_accept;  /* [ns] */
     int num_systems;
     int num_queries;
+    int neq;               /* N_EQ of the model the buffers were sized for (0 in a caller-filled struct = 5) */
     int dense_layout;      /* an hlm_device_job.dense_tiled value; hlm_setup_gpu_buffers chooses 2: tile-major
                             * [ceil(ns/64)][nq][neq][64] (the reference's device layout is [ns][neq][nq],
                             * rk45_kernel.cu:145, and is likewise re-ordered on the way to the host) */
 } hlm_gpu_buffers;
 
-/* setup_gpu_buffers<M>: allocate the device buffers, copy h_y0 and h_query_times. */
+/* setup_gpu_buffers<M>: allocate the device buffers, copy h_y0 ([ns][M::N_EQ]) and h_query_times.
+ * The template parameter of the reference is the uid here; hlm_setup_gpu_buffers is the N_EQ = 5 form. */
+int hlm_setup_gpu_buffers_model(int uid, const double* h_y0, int num_systems, const double* h_query_times,
+                                int num_queries, hlm_gpu_buffers* out);
 int hlm_setup_gpu_buffers(const double* h_y0, int num_systems, const double* h_query_times,
                           int num_queries, hlm_gpu_buffers* out);
 /* launch_rk45_kernel<M>: integrate all systems on the current device and synchronise.
@@ -230,7 +237,12 @@ typedef struct hlm_device_job {
     int lane_refill;
 } hlm_device_job;
 
-size_t hlm_resume_bytes(int num_systems);
+size_t hlm_resume_bytes_model(int uid, int num_systems); /* (N_EQ + 2) doubles + 5 int32 per system */
+size_t hlm_resume_bytes(int num_systems);                /* the N_EQ = 5 models: 76 bytes per system */
+/* Model::N_EQ and the number of forcings Model::rhs reads, for a registered uid (solver/rk45.h:51-66:
+ * the reference's kernels are templates over Model::N_EQ; so are these).  State arrays of the C ABI
+ * (y0, y_final, dense rows) have N_EQ doubles per system / row. */
+int hlm_model_info(int uid, int* n_eq, int* n_forcings);
 
 /* Enqueue the integration on `hip_stream` (a hipStream_t, NULL = default stream) of the
  * current device.  Asynchronous: returns after the launch. */

@@ -90,6 +90,25 @@ static void rhs_204(const double* y, double* dydt, const hlm_oracle_spatial_para
     dydt[4] = x4 - (P->alpha4 >= 1.0 ? h_aq / P->alpha4 : 0.0);
 }
 
+/* ToyModel3 (the build's "Add a New Model" example, csrc/hlm_models.h: ToyDev): 3 stores, 1 forcing,
+ * a feedback from store 2 to store 0.  Not a reference model: the oracle states it so that the generic
+ * kernels (N_EQ = 3, NF = 1, finite-difference Jacobian + pivoted LU in the Radau pass) have a checker. */
+static void rhs_toy3(const double* y, double* dydt, const hlm_oracle_spatial_params* P, const double* F, int nforc)
+{
+    const double k1 = P && P->alpha3 > 0.0 ? 1.0 / P->alpha3 : 0.05, k3 = P && P->alpha4 > 0.0 ? 1.0 / P->alpha4 : 0.01;
+    const double inflow = nforc > 0 ? F[0] : 0.0;
+    const double out0 = k1 * y[0], up = 0.3 * y[0] * y[2], out1 = 0.02 * y[1] * y[1];
+    dydt[0] = inflow - out0 - up;
+    dydt[1] = out0 - out1;
+    dydt[2] = out1 - k3 * y[2] + up;
+}
+
+/* Model::N_EQ of a uid (solver/rk45.h:51-66: the reference's kernels are templates over it); 0 = unknown */
+int hlm_oracle_neq(int uid)
+{
+    return uid == HLM_ORACLE_UID_204 || uid == HLM_ORACLE_UID_DUMMY ? 5 : (uid == HLM_ORACLE_UID_TOY3 ? 3 : 0);
+}
+
 /* model_dummy_python.ipynb:65-89 (the code cell, I2 = 0.6*H1). */
 static void rhs_dummy(const double* y, double* dydt)
 {
@@ -110,6 +129,8 @@ void hlm_oracle_rhs(int uid, double t, const double* y, double* dydt,
     (void)t; /* model_204.hpp:78 computes doy from t and never uses it */
     if (uid == HLM_ORACLE_UID_204)
         rhs_204(y, dydt, sp, F, nforc);
+    else if (uid == HLM_ORACLE_UID_TOY3)
+        rhs_toy3(y, dydt, sp, F, nforc);
     else
         rhs_dummy(y, dydt);
 }
@@ -120,6 +141,8 @@ void hlm_oracle_rhs(int uid, double t, const double* y, double* dydt,
  * Every min / max contributes the derivative of the operand it returns (a < b picks a), exactly the
  * choice the RHS itself makes; w = min(1, c h^(2/3)) gives d(h w)/dh = 5/3 c h^(2/3) below the cap and
  * 1 at it (also for h < 0, where the RHS drains at rate 1: SURVEY A.1 note 6). */
+int hlm_oracle_has_jacobian(int uid) { return uid == HLM_ORACLE_UID_204 || uid == HLM_ORACLE_UID_DUMMY; }
+
 void hlm_oracle_jacobian(int uid, const double* y, double Jm[NEQ][NEQ],
                          const hlm_oracle_spatial_params* P, const double* F, int nforc)
 {
@@ -173,22 +196,23 @@ void hlm_oracle_rk45_step(int uid, double t, const double* y, double h, double r
                           const double* F, int nforc, double k[7][NEQ], double* y_out,
                           double* err_norm)
 {
+    const int n = hlm_oracle_neq(uid);
     double y_temp[NEQ];
     for (int s = 1; s < 7; ++s) { /* :94-107 */
-        for (int i = 0; i < NEQ; ++i) {
+        for (int i = 0; i < n; ++i) {
             double acc = y[i];
             for (int j = 0; j < s; ++j) acc += h * TAB_A[s][j] * k[j][i];
             y_temp[i] = acc;
         }
         hlm_oracle_rhs(uid, t + TAB_C[s] * h, y_temp, k[s], sp, F, nforc);
     }
-    for (int i = 0; i < NEQ; ++i) { /* :111-117 */
+    for (int i = 0; i < n; ++i) { /* :111-117 */
         double acc = y[i];
         for (int s = 0; s < 7; ++s) acc += h * TAB_B[s] * k[s][i];
         y_out[i] = acc;
     }
     double max_ratio = 0.0; /* :123-142; "if (ratio > max)" ignores NaN ratios */
-    for (int i = 0; i < NEQ; ++i) {
+    for (int i = 0; i < n; ++i) {
         double y_err = 0.0;
         for (int s = 0; s < 7; ++s) y_err += h * (TAB_B[s] - TAB_BALT[s]) * k[s][i];
         const double ymax = fmax(fabs(y[i]), fabs(y_out[i]));
@@ -200,17 +224,22 @@ void hlm_oracle_rk45_step(int uid, double t, const double* y, double h, double r
 }
 
 /* rk45_step_dense.cuh:222-243 */
+static void rk45_dense_n(const double* y_n, double k[7][NEQ], double h, double theta, double* y_dense, int n);
 void hlm_oracle_rk45_dense(const double* y_n, double k[7][NEQ], double h, double theta,
                            double* y_dense)
 {
+    rk45_dense_n(y_n, k, h, theta, y_dense, NEQ);
+}
+static void rk45_dense_n(const double* y_n, double k[7][NEQ], double h, double theta, double* y_dense, int n)
+{
     double Q[4][NEQ];
     for (int m = 0; m < 4; ++m)
-        for (int i = 0; i < NEQ; ++i) {
+        for (int i = 0; i < n; ++i) {
             double sum = 0.0;
             for (int j = 0; j < 7; ++j) sum += TAB_P[j][m] * k[j][i];
             Q[m][i] = sum;
         }
-    for (int i = 0; i < NEQ; ++i) {
+    for (int i = 0; i < n; ++i) {
         double poly = 0.0, thp = theta;
         for (int m = 0; m < 4; ++m) {
             poly += Q[m][i] * thp;
@@ -221,10 +250,10 @@ void hlm_oracle_rk45_dense(const double* y_n, double k[7][NEQ], double h, double
 }
 
 /* event_detector.cuh:46-53 */
-static double norm_inf_diff(const double* a, const double* b)
+static double norm_inf_diff(const double* a, const double* b, int n)
 {
     double m = 0.0;
-    for (int i = 0; i < NEQ; ++i) {
+    for (int i = 0; i < n; ++i) {
         const double f = fabs(a[i] - b[i]);
         if (f > m) m = f;
     }
@@ -237,8 +266,9 @@ static void integrate_one(const hlm_oracle_job* J, int sys)
     const hlm_oracle_solver_params* P = &J->p;
     const uint32_t cap = J->attempt_cap ? J->attempt_cap : 0xFFFFFFFFu;
     const int fixed = J->fixed_step > 0.0;
+    const int n = hlm_oracle_neq(J->uid);
     double y[NEQ], y_next[NEQ], k[7][NEQ], err;
-    for (int i = 0; i < NEQ; ++i) y[i] = J->y0[(size_t)sys * NEQ + i];
+    for (int i = 0; i < n; ++i) y[i] = J->y0[(size_t)sys * n + i];
 
     int next_q = 0, reject_count = 0, stiff = 0, capped = 0;
     uint32_t n_attempt = 0, n_accept = 0;
@@ -270,7 +300,7 @@ static void integrate_one(const hlm_oracle_job* J, int sys)
         if (fixed || err <= 1.0) { /* :129 */
             reject_count = 0;
             if (!fixed) {
-                const double jump = norm_inf_diff(k[0], k[1]); /* :132-136 */
+                const double jump = norm_inf_diff(k[0], k[1], n); /* :132-136 */
                 if (jump > SLOPE_JUMP_THRESH) {
                     h = fmax(h * 0.5, P->initialStep * MIN_STEP_FRACTION);
                     continue;
@@ -282,13 +312,13 @@ static void integrate_one(const hlm_oracle_job* J, int sys)
                 if (tq > t) {
                     const double th = (tq - t) / h;
                     double yd[NEQ];
-                    hlm_oracle_rk45_dense(y, k, h, th, yd);
-                    for (int c = 0; c < NEQ; ++c)
-                        J->dense_raw[(size_t)sys * NEQ * (size_t)J->nq + (size_t)c * (size_t)J->nq + (size_t)next_q] = yd[c];
+                    rk45_dense_n(y, k, h, th, yd, n);
+                    for (int c = 0; c < n; ++c)
+                        J->dense_raw[(size_t)sys * n * (size_t)J->nq + (size_t)c * (size_t)J->nq + (size_t)next_q] = yd[c];
                 }
                 ++next_q;
             }
-            for (int i = 0; i < NEQ; ++i) y[i] = y_next[i];
+            for (int i = 0; i < n; ++i) y[i] = y_next[i];
             t = t1;
             ++n_accept;
             if (!fixed) { /* :151-152 */
@@ -312,7 +342,7 @@ static void integrate_one(const hlm_oracle_job* J, int sys)
     if (J->t_reached) J->t_reached[sys] = t;
     if (capped && t < J->tf) { J->stiff[sys] = HLM_ORACLE_CAPPED; return; }
     if (stiff && t < J->tf) { J->stiff[sys] = HLM_ORACLE_STIFF; return; } /* :167-170 */
-    for (int i = 0; i < NEQ; ++i) J->y_final[(size_t)sys * NEQ + i] = y[i]; /* :173-175 */
+    for (int i = 0; i < n; ++i) J->y_final[(size_t)sys * n + i] = y[i]; /* :173-175 */
 }
 
 int hlm_oracle_rk45_run(const hlm_oracle_job* J)
@@ -320,14 +350,15 @@ int hlm_oracle_rk45_run(const hlm_oracle_job* J)
     if (!J || J->ns < 0 || J->nq < 0 || J->nforc < 0 || J->nforc > HLM_ORACLE_MAX_FORCINGS) return -1;
     if (J->ns > 0 && (!J->y0 || !J->y_final || !J->stiff)) return -1;
     if (J->nq > 0 && (!J->query || !J->dense_raw)) return -1;
-    if (J->uid != HLM_ORACLE_UID_204 && J->uid != HLM_ORACLE_UID_DUMMY) return -1;
+    const int n = hlm_oracle_neq(J->uid);
+    if (n == 0) return -1;
     if (J->uid == HLM_ORACLE_UID_204 && J->ns > 0 && !J->sp) return -1;
     if (J->nforc > 0 && !J->forc_stub_f64 && (!J->forc || !J->forc_dt_h || !J->forc_nT)) return -1;
 
     /* SURVEY A.1 note 11: never-written slots read as 0 in every committed artifact. */
-    memset(J->y_final, 0, sizeof(double) * (size_t)J->ns * NEQ);
+    memset(J->y_final, 0, sizeof(double) * (size_t)J->ns * n);
     memset(J->stiff, 0, sizeof(int32_t) * (size_t)J->ns);
-    if (J->nq > 0) memset(J->dense_raw, 0, sizeof(double) * (size_t)J->ns * NEQ * (size_t)J->nq);
+    if (J->nq > 0) memset(J->dense_raw, 0, sizeof(double) * (size_t)J->ns * n * (size_t)J->nq);
 
     int sys;
 #ifdef _OPENMP
@@ -338,10 +369,11 @@ int hlm_oracle_rk45_run(const hlm_oracle_job* J)
     return 0;
 }
 
-void hlm_oracle_reorder_dense(const double* raw, double* out, int ns, int nq)
+void hlm_oracle_reorder_dense_n(const double* raw, double* out, int ns, int nq, int n)
 {
     for (size_t s = 0; s < (size_t)ns; ++s)
         for (size_t q = 0; q < (size_t)nq; ++q)
-            for (size_t c = 0; c < NEQ; ++c)
-                out[(s * (size_t)nq + q) * NEQ + c] = raw[s * NEQ * (size_t)nq + c * (size_t)nq + q];
+            for (size_t c = 0; c < (size_t)n; ++c)
+                out[(s * (size_t)nq + q) * (size_t)n + c] = raw[s * (size_t)n * (size_t)nq + c * (size_t)nq + q];
 }
+void hlm_oracle_reorder_dense(const double* raw, double* out, int ns, int nq) { hlm_oracle_reorder_dense_n(raw, out, ns, nq, NEQ); }

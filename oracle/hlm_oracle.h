@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HLM_ORACLE_NEQ 5
+#define HLM_ORACLE_NEQ 5   /* the largest N_EQ (array bound); a model's own N_EQ: hlm_oracle_neq(uid) */
 #define HLM_ORACLE_MAX_FORCINGS 16 /* I_O/forcing_data.h:5 */
 
 /* Model UIDs.  204 is models/model_204.hpp:18.  The DummyModel source is absent from
@@ -34,6 +34,7 @@ extern "C" {
  * model_dummy_python.ipynb:65-89); the build assigns it UID 0. */
 #define HLM_ORACLE_UID_DUMMY 0
 #define HLM_ORACLE_UID_204 204
+#define HLM_ORACLE_UID_TOY3 3   /* the build's 3-state example model (not a reference model) */
 
 /* Per-system status written to stiff[] (rk45_kernel.cu:160-170 uses 0/1 only;
  * 2 is the build's attempt-cap guard against the slope-jump livelock). */
@@ -105,6 +106,9 @@ void hlm_oracle_reorder_dense(const double* raw, double* out, int ns, int nq);
 /* Single evaluations for known-answer tests. */
 void hlm_oracle_rhs(int uid, double t, const double* y, double* dydt,
                     const hlm_oracle_spatial_params* sp, const double* F, int nforc);
+int hlm_oracle_neq(int uid);          /* Model::N_EQ (5, or 3 for the toy model); 0 = unknown uid */
+int hlm_oracle_has_jacobian(int uid); /* 0: the Radau pass differentiates numerically (radau_step_dense.cuh:13-31) */
+void hlm_oracle_reorder_dense_n(const double* raw, double* out, int ns, int nq, int neq);
 /* exact one-sided d(rhs)/dy (row-major J[i][j] = d dydt_i / d y_j) used by the Radau-IIA pass */
 void hlm_oracle_jacobian(int uid, const double* y, double Jm[HLM_ORACLE_NEQ][HLM_ORACLE_NEQ],
                          const hlm_oracle_spatial_params* sp, const double* F, int nforc);

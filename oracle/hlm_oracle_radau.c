@@ -39,69 +39,70 @@ static const double RP[NS][3] = {
 
 #define NEWTON_MAXITER 10   /* radau_step_dense.cuh:87 */
 #define NEWTON_TOL 1e-3     /* in units of the error tolerance (RADAU5: min(0.03, sqrt(rtol))) */
+#define FD_EPS 1e-8         /* radau_step_dense.cuh:20: sqrt(1e-16) */
 
 /* real 5x5 LU with partial pivoting; the reciprocal pivots are kept for the solves.
  * Returns 0 if a pivot is (numerically) zero. */
-static int lu_real(double a[NEQ][NEQ], int piv[NEQ], double inv[NEQ])
+static int lu_real(double a[NEQ][NEQ], int piv[NEQ], double inv[NEQ], int n)
 {
     int ok = 1;
-    for (int k = 0; k < NEQ; ++k) {
+    for (int k = 0; k < n; ++k) {
         int p = k;
         double best = fabs(a[k][k]);
-        for (int i = k + 1; i < NEQ; ++i)
+        for (int i = k + 1; i < n; ++i)
             if (fabs(a[i][k]) > best) { best = fabs(a[i][k]); p = i; }
         piv[k] = p;
         if (!(best > 1e-300)) ok = 0;
-        for (int j = 0; j < NEQ; ++j) { const double tmp = a[k][j]; a[k][j] = a[p][j]; a[p][j] = tmp; }
+        for (int j = 0; j < n; ++j) { const double tmp = a[k][j]; a[k][j] = a[p][j]; a[p][j] = tmp; }
         inv[k] = 1.0 / a[k][k];
-        for (int i = k + 1; i < NEQ; ++i) {
+        for (int i = k + 1; i < n; ++i) {
             const double m = a[i][k] * inv[k];
             a[i][k] = m;
-            for (int j = k + 1; j < NEQ; ++j) a[i][j] -= m * a[k][j];
+            for (int j = k + 1; j < n; ++j) a[i][j] -= m * a[k][j];
         }
     }
     return ok;
 }
 
-static void solve_real(double a[NEQ][NEQ], const int piv[NEQ], const double inv[NEQ], double b[NEQ])
+static void solve_real(double a[NEQ][NEQ], const int piv[NEQ], const double inv[NEQ], double b[NEQ], int n)
 {
-    for (int k = 0; k < NEQ; ++k) {
+    for (int k = 0; k < n; ++k) {
         const double tmp = b[k]; b[k] = b[piv[k]]; b[piv[k]] = tmp;
-        for (int i = k + 1; i < NEQ; ++i) b[i] -= a[i][k] * b[k];
+        for (int i = k + 1; i < n; ++i) b[i] -= a[i][k] * b[k];
     }
-    for (int i = NEQ - 1; i >= 0; --i) {
+    for (int i = n - 1; i >= 0; --i) {
         double s = b[i];
-        for (int j = i + 1; j < NEQ; ++j) s -= a[i][j] * b[j];
+        for (int j = i + 1; j < n; ++j) s -= a[i][j] * b[j];
         b[i] = s * inv[i];
     }
 }
 
 /* the same for a complex matrix held as (re, im); pivot on |re| + |im| */
-static int lu_cplx(double ar[NEQ][NEQ], double ai[NEQ][NEQ], int piv[NEQ], double ir[NEQ], double ii[NEQ])
+static int lu_cplx(double ar[NEQ][NEQ], double ai[NEQ][NEQ], int piv[NEQ], double ir[NEQ], double ii[NEQ], int n)
 {
     int ok = 1;
-    for (int k = 0; k < NEQ; ++k) {
+    for (int k = 0; k < n; ++k) {
         int p = k;
         double best = fabs(ar[k][k]) + fabs(ai[k][k]);
-        for (int i = k + 1; i < NEQ; ++i) {
+        for (int i = k + 1; i < n; ++i) {
             const double v = fabs(ar[i][k]) + fabs(ai[i][k]);
             if (v > best) { best = v; p = i; }
         }
         piv[k] = p;
         if (!(best > 1e-300)) ok = 0;
-        for (int j = 0; j < NEQ; ++j) {
+        for (int j = 0; j < n; ++j) {
             double tmp = ar[k][j]; ar[k][j] = ar[p][j]; ar[p][j] = tmp;
             tmp = ai[k][j]; ai[k][j] = ai[p][j]; ai[p][j] = tmp;
         }
         const double d = 1.0 / (ar[k][k] * ar[k][k] + ai[k][k] * ai[k][k]);
         ir[k] = ar[k][k] * d;
         ii[k] = -ai[k][k] * d;
-        for (int i = k + 1; i < NEQ; ++i) {
+        for (int i = k + 1; i < n; ++i) {
             const double mr = ar[i][k] * ir[k] - ai[i][k] * ii[k];
             const double mi = ar[i][k] * ii[k] + ai[i][k] * ir[k];
             ar[i][k] = mr;
             ai[i][k] = mi;
-            for (int j = k + 1; j < NEQ; ++j) {
+            for (int j = k + 1; j < n; ++j) {
                 ar[i][j] -= mr * ar[k][j] - mi * ai[k][j];
                 ai[i][j] -= mr * ai[k][j] + mi * ar[k][j];
             }
@@ -111,19 +112,19 @@ static int lu_cplx(double ar[NEQ][NEQ], double ai[NEQ][NEQ], int piv[NEQ], doubl
 }
 
 static void solve_cplx(double ar[NEQ][NEQ], double ai[NEQ][NEQ], const int piv[NEQ], const double ir[NEQ],
-                       const double ii[NEQ], double br[NEQ], double bi[NEQ])
+                       const double ii[NEQ], double br[NEQ], double bi[NEQ], int n)
 {
-    for (int k = 0; k < NEQ; ++k) {
+    for (int k = 0; k < n; ++k) {
         double tmp = br[k]; br[k] = br[piv[k]]; br[piv[k]] = tmp;
         tmp = bi[k]; bi[k] = bi[piv[k]]; bi[piv[k]] = tmp;
-        for (int i = k + 1; i < NEQ; ++i) {
+        for (int i = k + 1; i < n; ++i) {
             br[i] -= ar[i][k] * br[k] - ai[i][k] * bi[k];
             bi[i] -= ar[i][k] * bi[k] + ai[i][k] * br[k];
         }
     }
-    for (int i = NEQ - 1; i >= 0; --i) {
+    for (int i = n - 1; i >= 0; --i) {
         double sr = br[i], si = bi[i];
-        for (int j = i + 1; j < NEQ; ++j) {
+        for (int j = i + 1; j < n; ++j) {
             sr -= ar[i][j] * br[j] - ai[i][j] * bi[j];
             si -= ar[i][j] * bi[j] + ai[i][j] * br[j];
         }
@@ -138,10 +139,11 @@ static void radau_one(const hlm_oracle_job* J, int sys)
     const uint32_t cap = J->attempt_cap ? J->attempt_cap : 0xFFFFFFFFu;
     const hlm_oracle_spatial_params* sp = J->sp ? &J->sp[sys] : NULL;
     const size_t nq = (size_t)J->nq;
-    double* dense = J->nq ? J->dense_raw + (size_t)sys * NEQ * nq : NULL;
+    double* dense = J->nq ? J->dense_raw + (size_t)sys * hlm_oracle_neq(J->uid) * nq : NULL;
+    const int n = hlm_oracle_neq(J->uid);
     double y[NEQ];
-    for (int i = 0; i < NEQ; ++i) y[i] = J->y0[(size_t)sys * NEQ + i];
-    if (dense) memset(dense, 0, sizeof(double) * NEQ * nq);
+    for (int i = 0; i < n; ++i) y[i] = J->y0[(size_t)sys * n + i];
+    if (dense) memset(dense, 0, sizeof(double) * n * nq);
 
     double t = J->t0, h = P->initialStep;
     int next_q = 0, capped = 0;
@@ -181,20 +183,31 @@ static void radau_one(const hlm_oracle_job* J, int sys)
          * calls); the models here supply the exact one-sided derivative (hlm_oracle_jacobian). */
         double f0[NEQ], Jm[NEQ][NEQ];
         hlm_oracle_rhs(J->uid, t, y, f0, sp, F, J->nforc);
-        hlm_oracle_jacobian(J->uid, y, Jm, sp, F, J->nforc);
+        if (hlm_oracle_has_jacobian(J->uid)) {
+            hlm_oracle_jacobian(J->uid, y, Jm, sp, F, J->nforc);
+        } else { /* approx_jacobian, radau_step_dense.cuh:13-31 */
+            for (int j = 0; j < n; ++j) {
+                double yp[NEQ], f1[NEQ];
+                const double d = FD_EPS * fmax(1.0, fabs(y[j]));
+                for (int i = 0; i < n; ++i) yp[i] = y[i];
+                yp[j] += d;
+                hlm_oracle_rhs(J->uid, t, yp, f1, sp, F, J->nforc);
+                for (int i = 0; i < n; ++i) Jm[i][j] = (f1[i] - f0[i]) / d;
+            }
+        }
 
         /* LU of (g/h) I - J (Newton's real block AND the error estimator) and of ((a - ib)/h) I - J */
         double Mr[NEQ][NEQ], Cr[NEQ][NEQ], Ci[NEQ][NEQ], inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
         int piv_r[NEQ], piv_c[NEQ];
         const double g_h = MU_REAL / h, a_h = MU_CRE / h, b_h = MU_CIM / h;
-        for (int i = 0; i < NEQ; ++i)
-            for (int j = 0; j < NEQ; ++j) {
+        for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j) {
                 Mr[i][j] = ((i == j) ? g_h : 0.0) - Jm[i][j];
                 Cr[i][j] = ((i == j) ? a_h : 0.0) - Jm[i][j];
                 Ci[i][j] = (i == j) ? -b_h : 0.0;
             }
-        int ok = lu_real(Mr, piv_r, inv_r);
-        ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci) && ok;
+        int ok = lu_real(Mr, piv_r, inv_r, n);
+        ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, n) && ok;
 
         /* simplified Newton on W = (TI (x) I) Z, Z_i = Y_i - y */
         double Z[NS][NEQ], W[NS][NEQ];
@@ -206,18 +219,18 @@ static void radau_one(const hlm_oracle_job* J, int sys)
             double Fs[NS][NEQ], d0[NEQ], d1[NEQ], d2[NEQ];
             for (int s = 0; s < NS; ++s) {
                 double Y[NEQ];
-                for (int i = 0; i < NEQ; ++i) Y[i] = y[i] + Z[s][i];
+                for (int i = 0; i < n; ++i) Y[i] = y[i] + Z[s][i];
                 hlm_oracle_rhs(J->uid, t + RC[s] * h, Y, Fs[s], sp, F, J->nforc);
             }
-            for (int i = 0; i < NEQ; ++i) {
+            for (int i = 0; i < n; ++i) {
                 d0[i] = (RTI[0][0] * Fs[0][i] + RTI[0][1] * Fs[1][i] + RTI[0][2] * Fs[2][i]) - g_h * W[0][i];
                 d1[i] = (RTI[1][0] * Fs[0][i] + RTI[1][1] * Fs[1][i] + RTI[1][2] * Fs[2][i]) - (a_h * W[1][i] + b_h * W[2][i]);
                 d2[i] = (RTI[2][0] * Fs[0][i] + RTI[2][1] * Fs[1][i] + RTI[2][2] * Fs[2][i]) - (a_h * W[2][i] - b_h * W[1][i]);
             }
-            solve_real(Mr, piv_r, inv_r, d0);
-            solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, d1, d2);
+            solve_real(Mr, piv_r, inv_r, d0, n);
+            solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, d1, d2, n);
             double nrm = 0.0, chk = 0.0;
-            for (int i = 0; i < NEQ; ++i) {
+            for (int i = 0; i < n; ++i) {
                 chk += d0[i] + d1[i] + d2[i];
                 W[0][i] += d0[i];
                 W[1][i] += d1[i];
@@ -236,13 +249,13 @@ static void radau_one(const hlm_oracle_job* J, int sys)
 
         /* stiffly accurate: y_new = y + Z_3; RADAU5 error estimate */
         double y_new[NEQ], ev[NEQ];
-        for (int i = 0; i < NEQ; ++i) {
+        for (int i = 0; i < n; ++i) {
             y_new[i] = y[i] + Z[2][i];
             ev[i] = f0[i] + (RE[0] * Z[0][i] + RE[1] * Z[1][i] + RE[2] * Z[2][i]) / h;
         }
-        solve_real(Mr, piv_r, inv_r, ev);
+        solve_real(Mr, piv_r, inv_r, ev, n);
         double err = 0.0;
-        for (int i = 0; i < NEQ; ++i) {
+        for (int i = 0; i < n; ++i) {
             const double r = fabs(ev[i]) / (P->atol + P->rtol * fmax(fabs(y[i]), fabs(y_new[i])));
             if (r > err) err = r;
         }
@@ -252,7 +265,7 @@ static void radau_one(const hlm_oracle_job* J, int sys)
             const double t1 = t_end;
             while (next_q < J->nq && J->query[next_q] <= t1) { /* collocation polynomial */
                 const double th = (J->query[next_q] - t) / h;
-                for (int c = 0; c < NEQ; ++c) {
+                for (int c = 0; c < n; ++c) {
                     double acc = y[c], thp = th;
                     for (int m = 0; m < 3; ++m) {
                         acc += (RP[0][m] * Z[0][c] + RP[1][m] * Z[1][c] + RP[2][m] * Z[2][c]) * thp;
@@ -262,7 +275,7 @@ static void radau_one(const hlm_oracle_job* J, int sys)
                 }
                 ++next_q;
             }
-            for (int i = 0; i < NEQ; ++i) y[i] = y_new[i];
+            for (int i = 0; i < n; ++i) y[i] = y_new[i];
             t = t1;
             ++n_accept;
             h *= fmin(fmax(fac, P->minScale), P->maxScale);
@@ -277,10 +290,10 @@ static void radau_one(const hlm_oracle_job* J, int sys)
     if (J->t_reached) J->t_reached[sys] = t;
     if (capped && t < J->tf) {
         J->stiff[sys] = HLM_ORACLE_CAPPED;
-        for (int i = 0; i < NEQ; ++i) J->y_final[(size_t)sys * NEQ + i] = 0.0;
+        for (int i = 0; i < n; ++i) J->y_final[(size_t)sys * n + i] = 0.0;
         return;
     }
-    for (int i = 0; i < NEQ; ++i) J->y_final[(size_t)sys * NEQ + i] = y[i];
+    for (int i = 0; i < n; ++i) J->y_final[(size_t)sys * n + i] = y[i];
 }
 
 int hlm_oracle_radau_run(const hlm_oracle_job* J)

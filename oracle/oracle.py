@@ -16,7 +16,12 @@ _SO_FMA = os.path.join(_HERE, "libhlm_oracle_fma.so")  # conditioning yardstick,
 
 UID_DUMMY = 0
 UID_204 = 204
-NEQ = 5
+UID_TOY3 = 3   # the build's 3-state example model
+NEQ = 5        # the 5-state models; neq(uid) for any uid
+
+
+def neq(uid):
+    return {UID_DUMMY: 5, UID_204: 5, UID_TOY3: 3}.get(uid, NEQ)  # (an unknown uid is the C side's error to report)
 
 # I_O/parameters_loader.hpp:19-37 (136 bytes)
 SP_DTYPE = np.dtype(
@@ -66,6 +71,8 @@ def _declare(_lib):
         _lib.hlm_oracle_radau_run.restype = C.c_int
         _lib.hlm_oracle_reorder_dense.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         _lib.hlm_oracle_reorder_dense.restype = None
+        _lib.hlm_oracle_reorder_dense_n.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]
+        _lib.hlm_oracle_reorder_dense_n.restype = None
         _lib.hlm_oracle_rhs.argtypes = [C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         _lib.hlm_oracle_rhs.restype = None
         _lib.hlm_oracle_jacobian.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
@@ -104,7 +111,7 @@ def tableau():
 
 def rhs(uid, y, sp=None, F=(), t=0.0):
     y = np.ascontiguousarray(y, dtype=np.float64)
-    out = np.zeros(NEQ)
+    out = np.zeros(neq(uid))
     Fd = np.ascontiguousarray(np.asarray(F, dtype=np.float32).astype(np.float64))
     spa = None if sp is None else np.ascontiguousarray(sp, dtype=SP_DTYPE)
     lib().hlm_oracle_rhs(uid, t, _p(y), _p(out), _p(spa), _p(Fd) if len(Fd) else None, len(Fd))
@@ -151,7 +158,8 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     (hlm_oracle_radau_run); radau_only=True skips RK45 and sends every system through it.
     fma=True runs the FMA-contracted build instead: NOT a reference, only the yardstick for how far
     two valid roundings of the same computation separate on this input."""
-    y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, NEQ)
+    n = neq(uid)
+    y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, n)
     ns = y0.shape[0]
     q = np.zeros(0) if query is None else np.ascontiguousarray(query, dtype=np.float64)
     nq = q.shape[0]
@@ -175,8 +183,8 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
         keep += [f, dt, nT]
     j.p = _SolverParams(*[float(x) for x in params])
     j.fixed_step, j.attempt_cap, j.nthreads = float(fixed_step), int(attempt_cap), int(nthreads)
-    yf = np.empty((ns, NEQ))
-    raw = np.empty((ns, NEQ, nq)) if nq else None
+    yf = np.empty((ns, n))
+    raw = np.empty((ns, n, nq)) if nq else None
     stiff = np.empty(ns, dtype=np.int32)
     na = np.zeros(ns, dtype=np.uint32)
     nacc = np.zeros(ns, dtype=np.uint32)
@@ -196,6 +204,6 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
             raise ValueError("hlm_oracle_radau_run: bad arguments")
     dense = raw
     if nq and reorder:
-        dense = np.empty((ns, nq, NEQ))
-        lib().hlm_oracle_reorder_dense(_p(raw), _p(dense), ns, nq)
+        dense = np.empty((ns, nq, n))
+        lib().hlm_oracle_reorder_dense_n(_p(raw), _p(dense), ns, nq, n)
     return {"y_final": yf, "dense": dense, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "t_reached": treach}

@@ -18,7 +18,7 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 35
+    assert len(names) == 38
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
@@ -287,3 +287,22 @@ def test_lookup_mapper_and_cell_columns_on_the_reference_sample_lookup(hlm, tmp_
     # a grid smaller than the table's indices: the stream has no valid cell -> an error, not a wild index
     bad = subprocess.run([exe, path, str(lat_size), str(lon_size - 1)], capture_output=True, text=True)
     assert bad.returncode == 3 and "has no valid grid cell" in bad.stdout
+
+
+def test_model_info_and_toy_model_host_side(hlm, oracle):
+    """The registry knows every model's N_EQ and forcing count without a device; the Python mirror of the
+    toy model's right-hand side equals the oracle's."""
+    assert hlm.api.model_info(hlm.Model204) == (5, 2)
+    assert hlm.api.model_info(hlm.DummyModel) == (5, 0)
+    assert hlm.api.model_info(hlm.ToyModel3) == (3, 1)
+    assert hlm.api.resume_bytes(10, hlm.Model204) == 760 and hlm.api.resume_bytes(10, hlm.ToyModel3) == 600
+    with pytest.raises(hlm.HlmError):
+        class Unknown:
+            UID = 77
+        hlm.api.model_info(Unknown)
+    from tiger_hlm_gpu_amd import synth
+    sp = synth.model204_params(0, 3)
+    for i, y in enumerate(([1.0, 0.5, 0.2], [0.0, 2.0, 3.0], [4.0, 0.0, 0.1])):
+        a = hlm.ToyModel3.rhs(0.0, y, sp[i], (0.03,))
+        b = oracle.rhs(oracle.UID_TOY3, np.array(y), sp[i:i + 1], (0.03,))
+        assert np.allclose(a, b, rtol=1e-15, atol=0)

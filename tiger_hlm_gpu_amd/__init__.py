@@ -7,10 +7,10 @@ loudly if it is missing.
 """
 from ._lib import (HlmError, MATH_FAST, MATH_STRICT, SYS_CAPPED, SYS_OK, SYS_STIFF, UID_204, UID_DUMMY,
                    LIB_PATH)
-from .models import DummyModel, Model204, Parameters, SP_DTYPE, initial_step_guess
+from .models import DummyModel, Model204, ToyModel3, Parameters, SP_DTYPE, initial_step_guess
 from .params import LookupMapper, load_spatial_params
 from . import api
 
 __all__ = ["HlmError", "MATH_FAST", "MATH_STRICT", "SYS_OK", "SYS_STIFF", "SYS_CAPPED", "UID_204",
-           "UID_DUMMY", "LIB_PATH", "DummyModel", "Model204", "Parameters", "SP_DTYPE",
+           "UID_DUMMY", "LIB_PATH", "DummyModel", "Model204", "ToyModel3", "Parameters", "SP_DTYPE",
            "initial_step_guess", "LookupMapper", "load_spatial_params", "api"]

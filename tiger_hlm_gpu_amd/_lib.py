@@ -16,6 +16,7 @@ HLM_NEQ = 5
 HLM_MAX_FORCINGS = 16
 UID_DUMMY = 0
 UID_204 = 204
+UID_TOY3 = 3
 MATH_STRICT = 0
 MATH_FAST = 1
 SYS_OK, SYS_STIFF, SYS_CAPPED = 0, 1, 2
@@ -35,7 +36,7 @@ class GpuBuffers(C.Structure):
     _fields_ = [
         ("d_y0_all", C.c_void_p), ("d_y_final_all", C.c_void_p), ("d_query_times", C.c_void_p),
         ("d_dense_all", C.c_void_p), ("d_stiff", C.c_void_p), ("d_n_attempt", C.c_void_p),
-        ("d_n_accept", C.c_void_p), ("num_systems", C.c_int), ("num_queries", C.c_int), ("dense_layout", C.c_int),
+        ("d_n_accept", C.c_void_p), ("num_systems", C.c_int), ("num_queries", C.c_int), ("neq", C.c_int), ("dense_layout", C.c_int),
     ]
 
 
@@ -89,6 +90,8 @@ SIGNATURES = {
                                         C.c_int64, C.c_void_p, C.c_double]),
     "hlm_clear_forcings": (C.c_int, []),
     "hlm_setup_gpu_buffers": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(GpuBuffers)]),
+    "hlm_setup_gpu_buffers_model": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(GpuBuffers)]),
+    "hlm_model_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hlm_launch_rk45_kernel": (C.c_int, [C.c_int, C.POINTER(GpuBuffers), C.c_double, C.c_double, C.c_void_p]),
     "hlm_retrieve_and_free": (C.c_int, [C.POINTER(GpuBuffers), C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
@@ -97,6 +100,7 @@ SIGNATURES = {
     "hlm_rk45_integrate_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p]),
     "hlm_radau_fallback_device": (C.c_int, [C.POINTER(DeviceJob), C.c_void_p]),
     "hlm_resume_bytes": (C.c_size_t, [C.c_int]),
+    "hlm_resume_bytes_model": (C.c_size_t, [C.c_int, C.c_int]),
     "hlm_rk45_integrate_streamed": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p,
                                               C.POINTER(StreamStats)]),
     "hlm_rk45_integrate_forcing_streamed": (C.c_int, [C.POINTER(DeviceJob), C.POINTER(C.c_void_p), C.c_double,

@@ -186,7 +186,8 @@ def setup_gpu_buffers(model, h_y0, h_query_times):
     q = np.ascontiguousarray(h_query_times if h_query_times is not None else [], dtype=np.float64).reshape(-1)
     ns = y0.size // model.N_EQ
     b = GpuBuffers()
-    check(lib().hlm_setup_gpu_buffers(_ptr(y0) if ns else None, ns, _ptr(q) if q.size else None, q.size, C.byref(b)))
+    check(lib().hlm_setup_gpu_buffers_model(_uid(model), _ptr(y0) if ns else None, ns, _ptr(q) if q.size else None, q.size,
+                                            C.byref(b)))
     return b
 
 
@@ -288,8 +289,18 @@ def integrate_streamed(job, window_queries, h_dense, stream=None):
             "dense_bytes": st.dense_bytes}
 
 
-def resume_bytes(ns):
-    return int(lib().hlm_resume_bytes(int(ns)))
+def resume_bytes(ns, model=None):
+    """Bytes of the integrator-state record of ``ns`` systems ((N_EQ + 2) doubles + 5 int32 each)."""
+    if model is None:
+        return int(lib().hlm_resume_bytes(int(ns)))
+    return int(lib().hlm_resume_bytes_model(_uid(model), int(ns)))
+
+
+def model_info(model):
+    """(N_EQ, number of forcings rhs reads) of a registered model, as the library has it."""
+    n, f = C.c_int(0), C.c_int(0)
+    check(lib().hlm_model_info(_uid(model), C.byref(n), C.byref(f)))
+    return n.value, f.value
 
 
 def time_device(job, iters, stream=None):

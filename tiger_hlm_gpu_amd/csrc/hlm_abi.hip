@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "hlm_hip.h"
@@ -46,10 +47,28 @@ struct ModelState {
     double fixed_step;
 };
 std::mutex g_mu;
-ModelState g_models[2] = {
+ModelState g_models[3] = {
     {HLM_UID_DUMMY, {0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0}, 0.0},  // model_204.hpp:22-30 defaults
     {HLM_UID_204, {0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0}, 0.0},
+    {HLM_UID_TOY3, {0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0}, 0.0},
 };
+
+// ---- the registered device models (hlm_models.h).  Adding a model = a struct there + a line here +
+// a host-side struct under include/hlm/models/ (the reference: README.md "Add a New Model",
+// model_registry.cpp:18-60).  f is called with a value of the model's type; R() for an unknown UID.
+template <class R, class F>
+R with_model(int uid, F&& f)
+{
+    switch (uid) {
+        case HLM_UID_204: return f(hlm::Model204Dev{});
+        case HLM_UID_DUMMY: return f(hlm::DummyDev{});
+        case HLM_UID_TOY3: return f(hlm::ToyDev{});
+        default: return R();
+    }
+}
+int model_neq(int uid) { return with_model<int>(uid, [](auto m) { return decltype(m)::N_EQ; }); }   // 0: unknown UID
+int model_nf(int uid) { return with_model<int>(uid, [](auto m) { return decltype(m)::NF; }); }
+bool model_needs_sp(int uid) { return uid == HLM_UID_204; }
 uint32_t g_cap = 1u << 24;
 int g_stream_path = 0;  // hlm_set_stream_path(): 0 copy engine (default), 1 / 2 transposing transfer kernel
 int g_stream_layout = hlm::DENSE_TILE_COMP;  // device layout of the tiled stream path (1 tile-row, 2 tile-comp)
@@ -141,9 +160,7 @@ KernelFn pick_dense_ring(int math, bool fixed, bool res)
 
 KernelFn pick_dense_ring(int uid, int math, bool fixed, bool res)
 {
-    if (uid == HLM_UID_204) return pick_dense_ring<hlm::Model204Dev>(math, fixed, res);
-    if (uid == HLM_UID_DUMMY) return pick_dense_ring<hlm::DummyDev>(math, fixed, res);
-    return nullptr;
+    return with_model<KernelFn>(uid, [&](auto m) { return pick_dense_ring<decltype(m)>(math, fixed, res); });
 }
 
 // the kernels with lane refill (hlm_rk45_refill_kernel.h): no dense output, no resume state
@@ -157,16 +174,12 @@ RefillFn pick_refill(int math, bool fixed)
 }
 RefillFn pick_refill(int uid, int math, bool fixed)
 {
-    if (uid == HLM_UID_204) return pick_refill<hlm::Model204Dev>(math, fixed);
-    if (uid == HLM_UID_DUMMY) return pick_refill<hlm::DummyDev>(math, fixed);
-    return nullptr;
+    return with_model<RefillFn>(uid, [&](auto m) { return pick_refill<decltype(m)>(math, fixed); });
 }
 
 KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
 {
-    if (uid == HLM_UID_204) return pick_kernel<hlm::Model204Dev>(math, dense, fixed, resumable);
-    if (uid == HLM_UID_DUMMY) return pick_kernel<hlm::DummyDev>(math, dense, fixed, resumable);
-    return nullptr;
+    return with_model<KernelFn>(uid, [&](auto m) { return pick_kernel<decltype(m)>(math, dense, fixed, resumable); });
 }
 
 // a job needs the resumable kernel variant when it carries state between launches or holds only
@@ -183,8 +196,7 @@ bool job_is_resumable(const hlm_device_job* j)
 int validate_job(const hlm_device_job* j)
 {
     if (!j) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
-    if (j->uid != HLM_UID_204 && j->uid != HLM_UID_DUMMY)
-        return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", j->uid);
+    if (model_neq(j->uid) == 0) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", j->uid);
     if (j->num_systems < 0 || j->num_queries < 0)
         return fail(HLM_ERR_INVALID_ARGUMENT, "negative num_systems/num_queries");
     if (j->num_systems == 0) return HLM_SUCCESS;
@@ -192,11 +204,13 @@ int validate_job(const hlm_device_job* j)
         return fail(HLM_ERR_INVALID_ARGUMENT, "d_y0 / d_y_final / d_stiff must not be NULL");
     if (j->num_queries > 0 && (!j->d_query || !j->d_dense))
         return fail(HLM_ERR_INVALID_ARGUMENT, "num_queries > 0 needs d_query and d_dense");
-    if (j->uid == HLM_UID_204 && !j->d_sp)
+    if (model_needs_sp(j->uid) && !j->d_sp)
         return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs d_sp (SpatialParams)");
     if (j->nforc < 0 || j->nforc > HLM_MAX_FORCINGS)
         return fail(HLM_ERR_INVALID_ARGUMENT, "nforc %d outside [0,%d]", j->nforc, HLM_MAX_FORCINGS);
-    const bool reads_forcings = j->uid != HLM_UID_DUMMY;  // DummyDev::NF == 0: registered forcings are ignored
+    // A model reads its first NF forcings; further registered ones are ignored, as the reference's rhs
+    // ignores them (model_204.hpp:82-83 reads F[0], F[1] and nothing else), and missing ones read as 0.
+    const bool reads_forcings = model_nf(j->uid) > 0;
     if (j->nforc > 0 && reads_forcings) {
         if (!j->d_forc) return fail(HLM_ERR_INVALID_ARGUMENT, "nforc > 0 needs d_forc");
         if (j->forc_ld <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "forc_ld must be > 0");
@@ -251,7 +265,7 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     unsigned long long base = 0;
     for (int k = 0; k < j->nforc; ++k) {
         const unsigned long long rows = j->forc_rows[k] ? j->forc_rows[k] : j->forc_nT[k];
-        if (k < 2) {
+        if (k < hlm::HLM_KERNEL_MAX_NF) {
             a.forc_dtmin[k] = j->forc_dt_hours[k] * 60.0;  // rk45_kernel.cu:90
             a.forc_nT[k] = j->forc_nT[k];
             a.forc_base[k] = base;
@@ -331,6 +345,22 @@ int launch(const hlm_device_job* j, hipStream_t stream)
     return HLM_SUCCESS;
 }
 
+// tile-major window -> host order, for the layout and N_EQ at hand (hlm_rk45_kernel.h: dense_tile_to_host)
+void launch_tile_to_host(int layout, int neq, dim3 grid, hipStream_t stream, const double* src, double* dst, int ns, int nq,
+                         int q_begin, int W)
+{
+    auto go = [&](auto n) {
+        constexpr int N = decltype(n)::value;
+        if (layout == hlm::DENSE_TILE_COMP)
+            hipLaunchKernelGGL((hlm::dense_tile_to_host<true, N>), grid, dim3(256), 0, stream, src, dst, ns, nq, q_begin, W);
+        else
+            hipLaunchKernelGGL((hlm::dense_tile_to_host<false, N>), grid, dim3(256), 0, stream, src, dst, ns, nq, q_begin, W);
+    };
+    if (neq == 3) go(std::integral_constant<int, 3>{});
+    else go(std::integral_constant<int, 5>{});
+    static_assert(hlm::ToyDev::N_EQ == 3 && hlm::Model204Dev::N_EQ == 5 && hlm::DummyDev::N_EQ == 5, "one instance per registered N_EQ");
+}
+
 // Radau-IIA pass over the systems the RK45 launch of the same job flagged (stream-ordered after it)
 int launch_radau(const hlm_device_job* j, hipStream_t stream)
 {
@@ -355,9 +385,11 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     const unsigned blocks = (unsigned)((ns + hlm::WAVE - 1) / hlm::WAVE);  // blocks past the count exit at once
     using RadauFn = void (*)(const hlm::Rk45Args, const int*, const int*);
     const bool fast = j->math_mode == HLM_MATH_FAST;
-    RadauFn rf = j->uid == HLM_UID_204
-                     ? (fast ? hlm::radau_fallback_kernel<hlm::Model204Dev, hlm::MATH_FAST> : hlm::radau_fallback_kernel<hlm::Model204Dev, hlm::MATH_STRICT>)
-                     : (fast ? hlm::radau_fallback_kernel<hlm::DummyDev, hlm::MATH_FAST> : hlm::radau_fallback_kernel<hlm::DummyDev, hlm::MATH_STRICT>);
+    RadauFn rf = with_model<RadauFn>(j->uid, [&](auto m) -> RadauFn {
+        using M = decltype(m);
+        return fast ? hlm::radau_fallback_kernel<M, hlm::MATH_FAST> : hlm::radau_fallback_kernel<M, hlm::MATH_STRICT>;
+    });
+    if (!rf) { (void)hipFreeAsync(scratch, stream); return fail(HLM_ERR_UNKNOWN_MODEL, "no Radau kernel for UID %d", j->uid); }
     hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, scratch + 1, scratch);
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(scratch, stream));  // stream-ordered: after the kernels above
@@ -595,9 +627,19 @@ int hlm_set_radau_fallback(int enabled)
     return HLM_SUCCESS;
 }
 
-size_t hlm_resume_bytes(int ns)
+size_t hlm_resume_bytes_model(int uid, int ns)
 {
-    return ns <= 0 ? 0 : (size_t)ns * (hlm::RESUME_F64 * sizeof(double) + hlm::RESUME_I32 * sizeof(int32_t));
+    const int neq = model_neq(uid);
+    return ns <= 0 || neq == 0 ? 0 : (size_t)ns * (hlm::resume_f64(neq) * sizeof(double) + hlm::RESUME_I32 * sizeof(int32_t));
+}
+size_t hlm_resume_bytes(int ns) { return hlm_resume_bytes_model(HLM_UID_204, ns); }
+
+int hlm_model_info(int uid, int* n_eq, int* n_forcings)
+{
+    if (model_neq(uid) == 0) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    if (n_eq) *n_eq = model_neq(uid);
+    if (n_forcings) *n_forcings = model_nf(uid);
+    return HLM_SUCCESS;
 }
 
 int hlm_host_alloc_pinned(void** hptr, size_t bytes)
@@ -632,7 +674,8 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
     if (!h_dense) return fail(HLM_ERR_INVALID_ARGUMENT, "h_dense is NULL");
     const int W = window_queries < nq ? window_queries : nq;
     const int nwin = (nq + W - 1) / W;
-    const size_t row = (size_t)HLM_NEQ * sizeof(double);  // 40 B per (system, query)
+    const int neq = model_neq(job->uid);
+    const size_t row = (size_t)neq * sizeof(double);  // 40 B per (system, query) for the 5-state models
 
     // Path 0 (default): linear device windows [ns][W][5] + hipMemcpy2DAsync on the copy engine.
     // Path 1 (hlm_set_stream_path(1), needs pinned h_dense): the RK45 kernel writes tile-major
@@ -669,7 +712,7 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
         ok(hipEventCreateWithFlags(&done_k[b], hipEventDisableTiming));
         ok(hipEventCreateWithFlags(&done_c[b], hipEventDisableTiming));
     }
-    ok(hipMalloc(&resume, hlm_resume_bytes(ns)));
+    ok(hipMalloc(&resume, hlm_resume_bytes_model(job->uid, ns)));
     ev.resize((size_t)nwin * 4, nullptr);
     for (auto& x : ev) ok(hipEventCreate(&x));
 
@@ -699,10 +742,7 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
         if (tiled) {
             const int Wk = qe - qb;
             const dim3 grid((unsigned)nblk, (unsigned)((Wk + hlm::TILE_TQ - 1) / hlm::TILE_TQ));
-            if (g_stream_layout == hlm::DENSE_TILE_COMP)
-                hipLaunchKernelGGL(hlm::dense_tile_to_host<true>, grid, dim3(256), 0, copy, buf[b], h_dense_dev, ns, nq, qb, Wk);
-            else
-                hipLaunchKernelGGL(hlm::dense_tile_to_host<false>, grid, dim3(256), 0, copy, buf[b], h_dense_dev, ns, nq, qb, Wk);
+            launch_tile_to_host(g_stream_layout, neq, grid, copy, buf[b], h_dense_dev, ns, nq, qb, Wk);
             ok(hipGetLastError());
         } else {
             // device [ns][qe-qb][5] -> host rows of nq*40 B, columns qb..qe
@@ -794,7 +834,7 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
         ok(hipEventCreateWithFlags(&uploaded[b], hipEventDisableTiming));
         ok(hipEventCreateWithFlags(&consumed[b], hipEventDisableTiming));
     }
-    ok(hipMalloc(&resume, hlm_resume_bytes(job->num_systems)));
+    ok(hipMalloc(&resume, hlm_resume_bytes_model(job->uid, job->num_systems)));
     for (int k = 0; k < nchunk && e == hipSuccess && rc == HLM_SUCCESS; ++k) {
         const int b = k & 1;
         hlm_device_job j = *job;
@@ -868,19 +908,20 @@ int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, c
 {
     if (n < 0 || (n > 0 && (!d_y || !d_F || !d_out))) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest_rhs buffers");
     if (math_mode != HLM_MATH_STRICT && math_mode != HLM_MATH_FAST) return fail(HLM_ERR_INVALID_ARGUMENT, "math mode %d", math_mode);
-    if (uid == HLM_UID_204 && n > 0 && !d_sp) return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs d_sp");
+    if (model_needs_sp(uid) && n > 0 && !d_sp) return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs d_sp");
     if (n == 0) return HLM_SUCCESS;
     hipStream_t s = static_cast<hipStream_t>(hip_stream);
     const dim3 grid((unsigned)((n + 255) / 256)), block(256);
     using namespace hlm;
-    if (uid == HLM_UID_204 && math_mode == HLM_MATH_FAST)
-        hipLaunchKernelGGL((selftest_rhs_kernel<Model204Dev, MATH_FAST>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, fast_path, n);
-    else if (uid == HLM_UID_204)
-        hipLaunchKernelGGL((selftest_rhs_kernel<Model204Dev, MATH_STRICT>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, fast_path, n);
-    else if (uid == HLM_UID_DUMMY)
-        hipLaunchKernelGGL((selftest_rhs_kernel<DummyDev, MATH_STRICT>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, 0, n);
-    else
-        return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    const bool known = with_model<bool>(uid, [&](auto m) {
+        using M = decltype(m);
+        if (math_mode == HLM_MATH_FAST)
+            hipLaunchKernelGGL((selftest_rhs_kernel<M, MATH_FAST>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, M::HAS_FASTPATH ? fast_path : 0, n);
+        else
+            hipLaunchKernelGGL((selftest_rhs_kernel<M, MATH_STRICT>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, M::HAS_FASTPATH ? fast_path : 0, n);
+        return true;
+    });
+    if (!known) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
     HLM_HIP_TRY(hipGetLastError());
     return HLM_SUCCESS;
 }
@@ -902,18 +943,26 @@ int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* scratch_
 // ---- three-phase host API ----------------------------------------------------------------
 int hlm_setup_gpu_buffers(const double* h_y0, int ns, const double* h_q, int nq, hlm_gpu_buffers* out)
 {
+    return hlm_setup_gpu_buffers_model(HLM_UID_204, h_y0, ns, h_q, nq, out);
+}
+
+int hlm_setup_gpu_buffers_model(int uid, const double* h_y0, int ns, const double* h_q, int nq, hlm_gpu_buffers* out)
+{
     if (!out) return fail(HLM_ERR_INVALID_ARGUMENT, "out is NULL");
     std::memset(out, 0, sizeof(*out));
+    const int neq = model_neq(uid);
+    if (neq == 0) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    out->neq = neq;
     if (ns < 0 || nq < 0) return fail(HLM_ERR_INVALID_ARGUMENT, "negative sizes");
     if ((ns > 0 && !h_y0) || (nq > 0 && !h_q)) return fail(HLM_ERR_INVALID_ARGUMENT, "NULL host input");
     out->num_systems = ns;
     out->num_queries = nq;
-    const size_t b_state = sizeof(double) * (size_t)ns * HLM_NEQ;
+    const size_t b_state = sizeof(double) * (size_t)ns * (size_t)neq;
     const size_t b_q = sizeof(double) * (size_t)nq;
     // dense rows live tile-major in HBM ([ceil(ns/64)][nq][5][64], whole cache lines per store:
     // hlm_rk45_dense_kernel.h); hlm_retrieve_and_free delivers the host order
     out->dense_layout = hlm::DENSE_TILE_COMP;
-    const size_t b_dense = sizeof(double) * (size_t)((ns + hlm::WAVE - 1) / hlm::WAVE) * hlm::WAVE * HLM_NEQ * (size_t)nq;
+    const size_t b_dense = sizeof(double) * (size_t)((ns + hlm::WAVE - 1) / hlm::WAVE) * hlm::WAVE * (size_t)neq * (size_t)nq;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMalloc(p, bytes);
@@ -940,6 +989,8 @@ int hlm_setup_gpu_buffers(const double* h_y0, int ns, const double* h_q, int nq,
 int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double tf, const void* d_sp)
 {
     if (!b) return fail(HLM_ERR_INVALID_ARGUMENT, "buffers are NULL");
+    if (b->neq != 0 && b->neq != model_neq(uid))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "buffers were set up for N_EQ = %d, model %d has %d", b->neq, uid, model_neq(uid));
     ForcingSlot* slot = forc_slot();
     if (!slot) return HLM_ERR_HIP;
     hlm_device_job j;
@@ -976,7 +1027,7 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     j.d_stiff = b->d_stiff;
     j.d_n_attempt = b->d_n_attempt;
     j.d_n_accept = b->d_n_accept;
-    const bool streamed = chunk_minutes > 0.0 && uid != HLM_UID_DUMMY;
+    const bool streamed = chunk_minutes > 0.0 && model_nf(uid) > 0;
     if (streamed && radau)
         return fail(HLM_ERR_INVALID_ARGUMENT, "the Radau fallback needs the forcing series resident in HBM "
                                               "(hlm_set_forcings), not streamed in time chunks");
@@ -994,21 +1045,18 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
 // dense rows of a tile-major device buffer -> h_dense in the host order (s*nq + q)*5 + c
 // (rk45_api.hpp:255-267).  Pinned, device-mapped host memory is written by the transposing kernel
 // directly; any other destination goes through a device staging buffer of whole tiles.
-static hipError_t dense_to_host_order(const double* d_dense, int layout, size_t ns, size_t nq, double* h_dense)
+static hipError_t dense_to_host_order(const double* d_dense, int layout, int neq, size_t ns, size_t nq, double* h_dense)
 {
     if (!h_dense || !d_dense || ns == 0 || nq == 0) return hipSuccess;
-    const size_t row = sizeof(double) * HLM_NEQ;
+    const size_t row = sizeof(double) * (size_t)neq;
     if (layout == hlm::DENSE_LINEAR) return hipMemcpy(h_dense, d_dense, ns * nq * row, hipMemcpyDeviceToHost);
     const int nblk = (int)((ns + hlm::WAVE - 1) / hlm::WAVE);
     auto launch_tiles = [&](int blk0, int nb, double* dst_for_sys0) {  // dst_for_sys0: where system 0's rows would start
         const dim3 grid((unsigned)nb, (unsigned)((nq + hlm::TILE_TQ - 1) / hlm::TILE_TQ));
-        const double* src = d_dense + (size_t)blk0 * nq * hlm::WAVE * HLM_NEQ;
-        double* dst = dst_for_sys0 + (size_t)blk0 * hlm::WAVE * nq * HLM_NEQ;
+        const double* src = d_dense + (size_t)blk0 * nq * hlm::WAVE * (size_t)neq;
+        double* dst = dst_for_sys0 + (size_t)blk0 * hlm::WAVE * nq * (size_t)neq;
         const int ns_left = (int)(ns - (size_t)blk0 * hlm::WAVE);
-        if (layout == hlm::DENSE_TILE_COMP)
-            hipLaunchKernelGGL(hlm::dense_tile_to_host<true>, grid, dim3(256), 0, nullptr, src, dst, ns_left, (int)nq, 0, (int)nq);
-        else
-            hipLaunchKernelGGL(hlm::dense_tile_to_host<false>, grid, dim3(256), 0, nullptr, src, dst, ns_left, (int)nq, 0, (int)nq);
+        launch_tile_to_host(layout, neq, grid, nullptr, src, dst, ns_left, (int)nq, 0, (int)nq);
         return hipGetLastError();
     };
     hipPointerAttribute_t at;
@@ -1027,8 +1075,8 @@ static hipError_t dense_to_host_order(const double* d_dense, int layout, size_t 
         const int nb = (int)((size_t)(nblk - b0) < tiles_per_pass ? (size_t)(nblk - b0) : tiles_per_pass);
         const size_t sys0 = (size_t)b0 * hlm::WAVE, nsys = (size_t)nb * hlm::WAVE < ns - sys0 ? (size_t)nb * hlm::WAVE : ns - sys0;
         // the kernel addresses dst by the system index within the launch: shift so that tile b0 lands at stage[0]
-        e = launch_tiles(b0, nb, stage - (size_t)b0 * hlm::WAVE * nq * HLM_NEQ);
-        if (e == hipSuccess) e = hipMemcpy(h_dense + sys0 * nq * HLM_NEQ, stage, nsys * nq * row, hipMemcpyDeviceToHost);
+        e = launch_tiles(b0, nb, stage - (size_t)b0 * hlm::WAVE * nq * (size_t)neq);
+        if (e == hipSuccess) e = hipMemcpy(h_dense + sys0 * nq * (size_t)neq, stage, nsys * nq * row, hipMemcpyDeviceToHost);
     }
     if (stage) (void)hipFree(stage);
     return e;
@@ -1043,8 +1091,9 @@ int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense, 
     auto d2h = [&](void* dst, const void* src, size_t bytes) {
         if (e == hipSuccess && dst && src && bytes) e = hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
     };
-    d2h(h_final, b->d_y_final_all, sizeof(double) * ns * HLM_NEQ);
-    if (e == hipSuccess) e = dense_to_host_order(b->d_dense_all, b->dense_layout, ns, nq, h_dense);
+    const int neq = b->neq ? b->neq : HLM_NEQ;
+    d2h(h_final, b->d_y_final_all, sizeof(double) * ns * (size_t)neq);
+    if (e == hipSuccess) e = dense_to_host_order(b->d_dense_all, b->dense_layout, neq, ns, nq, h_dense);
     d2h(h_stiff, b->d_stiff, sizeof(int32_t) * ns);
     d2h(h_n_attempt, b->d_n_attempt, sizeof(uint32_t) * ns);
     d2h(h_n_accept, b->d_n_accept, sizeof(uint32_t) * ns);
@@ -1061,7 +1110,7 @@ int hlm_run_rk45(int uid, const double* h_y0, int ns, double t0, double tf, cons
                  uint32_t* h_n_attempt, uint32_t* h_n_accept)
 {
     hlm_gpu_buffers b;
-    int rc = hlm_setup_gpu_buffers(h_y0, ns, h_q, nq, &b);
+    int rc = hlm_setup_gpu_buffers_model(uid, h_y0, ns, h_q, nq, &b);
     if (rc != HLM_SUCCESS) return rc;
     rc = hlm_launch_rk45_kernel(uid, &b, t0, tf, d_sp);
     if (rc != HLM_SUCCESS) {

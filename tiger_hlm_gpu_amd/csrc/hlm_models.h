@@ -1,10 +1,13 @@
 // Device-side model plug-ins for the RK45 kernel (one struct per Model::UID).
 //
 // A device model provides
-//   UID, NF (how many forcings rhs reads), struct Local (per-system constants kept in
-//   VGPRs for the whole integration), struct Forc (values derived from the held forcing
-//   samples), load(sp, sys), prep_forcing(P, F0, F1), rhs<MATH>(P, F, y, dydt) and optionally
-//   (HAS_FASTPATH) a cheaper rhs_fast that is exact while fastpath_ok(y) holds.
+//   UID, N_EQ (state variables; <= HLM_MAX_NEQ), NF (how many forcings rhs reads; <= HLM_KERNEL_MAX_NF),
+//   struct Local (per-system constants kept in VGPRs for the whole integration), struct Forc (values
+//   derived from the held forcing samples), load(sp, sys), prep_forcing(P, F[NF]), rhs<MATH>(P, F, y,
+//   dydt) and optionally (HAS_FASTPATH / HAS_NORAINPATH) cheaper RHS variants that are exact while a
+//   per-lane precondition holds, (HAS_JACOBIAN) the exact d(rhs)/dy for the Radau-IIA pass.
+// The kernels are templates over the model: N_EQ and NF are compile-time, every state array lives in
+// named registers (reference: rk45_kernel_multi<Model>, solver/rk45.h:51-66, Model::N_EQ).
 // This is the device half of the reference's plug-in concept (Model::UID / SP_TYPE /
 // rhs, reference src/models/model_204.hpp:15-115); the host half is include/hlm/models/.
 #pragma once
@@ -16,6 +19,7 @@
 
 namespace hlm {
 
+constexpr int HLM_KERNEL_MAX_NF = 4;  // forcings a model's rhs may read (kernel-argument arrays are this long)
 constexpr int MATH_STRICT = HLM_MATH_STRICT;
 constexpr int MATH_FAST = HLM_MATH_FAST;
 
@@ -130,7 +134,8 @@ __device__ __forceinline__ double pow_two_thirds(double x)
 // ------------------------------------------------------------------------------------
 struct Model204Dev {
     static constexpr int UID = HLM_UID_204;
-    static constexpr int NF = 2;  // F[0] = rainfall, F[1] = temperature (:82-83)
+    static constexpr int N_EQ = 5;  // Model204::N_EQ, model_204.hpp:19
+    static constexpr int NF = 2;    // F[0] = rainfall, F[1] = temperature (:82-83)
 
     struct Local {
         double infil, perco, Hu, L, A_h, alpha3, alpha4, melt_f, temp_thr;
@@ -190,8 +195,9 @@ struct Model204Dev {
         return P;
     }
 
-    static __device__ __forceinline__ Forc prep_forcing(const Local& P, double rainfall, double temperature)
+    static __device__ __forceinline__ Forc prep_forcing(const Local& P, const double (&held)[NF])
     {
+        const double rainfall = held[0], temperature = held[1];
         Forc F;
         F.rain = rainfall;
         F.melt_pot = temperature * P.melt_f;
@@ -205,7 +211,7 @@ struct Model204Dev {
     // left out bit-exactly.  rhs_fast reports d2 != 0 (inflow: the next stage state is wet).
     static constexpr bool HAS_FASTPATH = true;
     static constexpr int FAST_ZERO_COMP = 2;  // rhs_fast: dydt[2] == 0 unless it reports "broke"
-    static __device__ __forceinline__ bool fastpath_ok(const double (&y)[HLM_NEQ]) { return y[2] == 0.0; }
+    static __device__ __forceinline__ bool fastpath_ok(const double (&y)[N_EQ]) { return y[2] == 0.0; }
 
     // No-rain path: a dry surface store AND no rainfall in the held sample.  Then x1 is the
     // snowmelt alone and, while the static store stays below Hu, x2 = max(0, x1 + h_stat - Hu) = 0
@@ -214,13 +220,13 @@ struct Model204Dev {
     // expressions are the general ones with rain, x2, x3, x4, d2, d3 replaced by the literal 0.0
     // they evaluate to: same values.
     static constexpr bool HAS_NORAINPATH = true;
-    static __device__ __forceinline__ bool norainpath_ok(const Local& P, const Forc& F, const double (&y)[HLM_NEQ])
+    static __device__ __forceinline__ bool norainpath_ok(const Local& P, const Forc& F, const double (&y)[N_EQ])
     {
         return y[2] == 0.0 && F.rain == 0.0 && P.nonneg;
     }
     template <int MATH>
-    static __device__ __forceinline__ bool rhs_norain(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
-                                                      double (&dydt)[HLM_NEQ])
+    static __device__ __forceinline__ bool rhs_norain(const Local& P, const Forc& F, const double (&y)[N_EQ],
+                                                      double (&dydt)[N_EQ])
     {
         const double h_snow = y[0], h_stat = y[1], h_grav = y[3], h_aq = y[4];
         const double x1 =
@@ -245,14 +251,14 @@ struct Model204Dev {
     }
 
     template <int MATH>
-    static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
-                                               double (&dydt)[HLM_NEQ])
+    static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[N_EQ],
+                                               double (&dydt)[N_EQ])
     {
         (void)rhs_impl<MATH, false>(P, F, y, dydt);
     }
     template <int MATH>
-    static __device__ __forceinline__ bool rhs_fast(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
-                                                    double (&dydt)[HLM_NEQ])
+    static __device__ __forceinline__ bool rhs_fast(const Local& P, const Forc& F, const double (&y)[N_EQ],
+                                                    double (&dydt)[N_EQ])
     {
         return rhs_impl<MATH, true>(P, F, y, dydt);
     }
@@ -263,13 +269,13 @@ struct Model204Dev {
     static constexpr bool HAS_JACOBIAN = true;
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;  // a cascade: store i only feels stores j <= i
     template <int MATH>
-    static __device__ __forceinline__ void jacobian(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
-                                                    double (&J)[HLM_NEQ][HLM_NEQ])
+    static __device__ __forceinline__ void jacobian(const Local& P, const Forc& F, const double (&y)[N_EQ],
+                                                    double (&J)[N_EQ][N_EQ])
     {
 #pragma unroll
-        for (int i = 0; i < HLM_NEQ; ++i)
+        for (int i = 0; i < N_EQ; ++i)
 #pragma unroll
-            for (int j = 0; j < HLM_NEQ; ++j) J[i][j] = 0.0;
+            for (int j = 0; j < N_EQ; ++j) J[i][j] = 0.0;
         const double h_snow = y[0], h_stat = y[1], h_surf = y[2];
         const bool warm = F.warm_mask != 0ull;
         const double snowmelt = warm ? fmin(h_snow, F.melt_pot) : 0.0;
@@ -311,8 +317,8 @@ struct Model204Dev {
     }
 
     template <int MATH, bool DRY>
-    static __device__ __forceinline__ bool rhs_impl(const Local& P, const Forc& F, const double (&y)[HLM_NEQ],
-                                                    double (&dydt)[HLM_NEQ])
+    static __device__ __forceinline__ bool rhs_impl(const Local& P, const Forc& F, const double (&y)[N_EQ],
+                                                    double (&dydt)[N_EQ])
     {
         const double h_snow = y[0], h_stat = y[1], h_surf = y[2], h_grav = y[3], h_aq = y[4];
 
@@ -374,41 +380,42 @@ struct Model204Dev {
 // ------------------------------------------------------------------------------------
 struct DummyDev {
     static constexpr int UID = HLM_UID_DUMMY;
+    static constexpr int N_EQ = 5;
     static constexpr int NF = 0;
     struct Local {};
     struct Forc {};
     static constexpr bool HAS_FASTPATH = false;
     static constexpr bool HAS_NORAINPATH = false;
     static constexpr int FAST_ZERO_COMP = 0;
-    static __device__ __forceinline__ bool norainpath_ok(const Local&, const Forc&, const double (&)[HLM_NEQ]) { return false; }
+    static __device__ __forceinline__ bool norainpath_ok(const Local&, const Forc&, const double (&)[N_EQ]) { return false; }
     template <int MATH>
-    static __device__ __forceinline__ bool rhs_norain(const Local&, const Forc&, const double (&)[HLM_NEQ],
-                                                      double (&)[HLM_NEQ]) { return true; }
-    static __device__ __forceinline__ bool fastpath_ok(const double (&)[HLM_NEQ]) { return false; }
+    static __device__ __forceinline__ bool rhs_norain(const Local&, const Forc&, const double (&)[N_EQ],
+                                                      double (&)[N_EQ]) { return true; }
+    static __device__ __forceinline__ bool fastpath_ok(const double (&)[N_EQ]) { return false; }
     template <int MATH>
-    static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[HLM_NEQ],
-                                                    double (&)[HLM_NEQ]) { return true; }
+    static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[N_EQ],
+                                                    double (&)[N_EQ]) { return true; }
     static constexpr bool HAS_JACOBIAN = true;  // constant: the system is linear
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;
     template <int MATH>
-    static __device__ __forceinline__ void jacobian(const Local&, const Forc&, const double (&)[HLM_NEQ],
-                                                    double (&J)[HLM_NEQ][HLM_NEQ])
+    static __device__ __forceinline__ void jacobian(const Local&, const Forc&, const double (&)[N_EQ],
+                                                    double (&J)[N_EQ][N_EQ])
     {
-        const double M[HLM_NEQ][HLM_NEQ] = {{-0.5, 0, 0, 0, 0}, {0.5, -0.9, 0, 0, 0}, {0, 0.3, 0, 0, 0},
+        const double M[N_EQ][N_EQ] = {{-0.5, 0, 0, 0, 0}, {0.5, -0.9, 0, 0, 0}, {0, 0.3, 0, 0, 0},
                                             {0, 0.6, 0, -0.4, 0}, {0, 0, 0, 0.4, 0}};
 #pragma unroll
-        for (int i = 0; i < HLM_NEQ; ++i)
+        for (int i = 0; i < N_EQ; ++i)
 #pragma unroll
-            for (int j = 0; j < HLM_NEQ; ++j) J[i][j] = M[i][j];
+            for (int j = 0; j < N_EQ; ++j) J[i][j] = M[i][j];
     }
 
     template <int MATH>
     static __device__ __forceinline__ Local load(const void*, int) { return Local{}; }
-    static __device__ __forceinline__ Forc prep_forcing(const Local&, double, double) { return Forc{}; }
+    static __device__ __forceinline__ Forc prep_forcing(const Local&, const double (&)[1]) { return Forc{}; }
 
     template <int MATH>
-    static __device__ __forceinline__ void rhs(const Local&, const Forc&, const double (&y)[HLM_NEQ],
-                                               double (&dydt)[HLM_NEQ])
+    static __device__ __forceinline__ void rhs(const Local&, const Forc&, const double (&y)[N_EQ],
+                                               double (&dydt)[N_EQ])
     {
         const double H0 = y[0], H1 = y[1], H3 = y[3];
         const double Y0 = 0.5 * H0, X2 = 0.3 * H1, I2 = 0.6 * H1, I3 = 0.4 * H3;
@@ -417,6 +424,61 @@ struct DummyDev {
         dydt[2] = X2 - 0.2;
         dydt[3] = I2 - I3 - 0.3;
         dydt[4] = I3 - 0.1;
+    }
+};
+
+// ------------------------------------------------------------------------------------
+// ToyModel3: a three-store model that exists to prove the plug-in surface is generic (the reference's
+// README "Add a New Model": a struct with UID / N_EQ / Parameters / rhs registered in model_registry):
+// N_EQ = 3, one forcing, no cheap RHS variants, no analytic Jacobian -- and a Jacobian that is NOT
+// triangular (store 2 feeds back into store 0), so the Radau pass takes its general route for it: finite
+// differences (radau_step_dense.cuh:13-31) and pivoted LU.
+//   dy0 = F0 - k1 y0 - c y0 y2        inflow, linear outflow, uptake by store 2
+//   dy1 = k1 y0 - k2 y1^2             quadratic outflow
+//   dy2 = k2 y1^2 - k3 y2 + c y0 y2
+// k1 = 1 / alpha3, k2 = 0.02, k3 = 1 / alpha4 read from the SpatialParams record (or k1 = 0.05, k3 = 0.01
+// without one, or where the record holds no positive value), c = 0.3.
+// ------------------------------------------------------------------------------------
+struct ToyDev {
+    static constexpr int UID = HLM_UID_TOY3;
+    static constexpr int N_EQ = 3;
+    static constexpr int NF = 1;
+    struct Local { double k1, k3; };
+    struct Forc { double inflow; };
+    static constexpr bool HAS_FASTPATH = false;
+    static constexpr bool HAS_NORAINPATH = false;
+    static constexpr bool HAS_JACOBIAN = false;
+    static constexpr bool JACOBIAN_LOWER_TRIANGULAR = false;
+    static constexpr int FAST_ZERO_COMP = 0;
+    static __device__ __forceinline__ bool norainpath_ok(const Local&, const Forc&, const double (&)[N_EQ]) { return false; }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_norain(const Local&, const Forc&, const double (&)[N_EQ], double (&)[N_EQ]) { return true; }
+    static __device__ __forceinline__ bool fastpath_ok(const double (&)[N_EQ]) { return false; }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[N_EQ], double (&)[N_EQ]) { return true; }
+    template <int MATH>
+    static __device__ __forceinline__ void jacobian(const Local&, const Forc&, const double (&)[N_EQ], double (&)[N_EQ][N_EQ]) {}
+
+    template <int MATH>
+    static __device__ __forceinline__ Local load(const void* sp_base, int sys)
+    {
+        Local P{0.05, 0.01};
+        if (sp_base) {
+            const hlm_spatial_params& S = static_cast<const hlm_spatial_params*>(sp_base)[sys];
+            if (S.alpha3 > 0.0) P.k1 = 1.0 / S.alpha3;
+            if (S.alpha4 > 0.0) P.k3 = 1.0 / S.alpha4;
+        }
+        return P;
+    }
+    static __device__ __forceinline__ Forc prep_forcing(const Local&, const double (&held)[NF]) { return Forc{held[0]}; }
+
+    template <int MATH>
+    static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[N_EQ], double (&dydt)[N_EQ])
+    {
+        const double out0 = P.k1 * y[0], up = 0.3 * y[0] * y[2], out1 = 0.02 * y[1] * y[1];
+        dydt[0] = F.inflow - out0 - up;
+        dydt[1] = out0 - out1;
+        dydt[2] = out1 - P.k3 * y[2] + up;
     }
 };
 

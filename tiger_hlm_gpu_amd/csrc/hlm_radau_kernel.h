@@ -55,6 +55,7 @@ __device__ __forceinline__ void cswap(bool sw, double& a, double& b)
 }
 
 // real 5x5 LU with partial pivoting, all indices compile-time (registers); inv = reciprocal pivots
+template <int NEQ>
 __device__ __forceinline__ bool lu_real(double (&a)[NEQ][NEQ], int (&piv)[NEQ], double (&inv)[NEQ])
 {
     bool ok = true;
@@ -87,6 +88,7 @@ __device__ __forceinline__ bool lu_real(double (&a)[NEQ][NEQ], int (&piv)[NEQ], 
     return ok;
 }
 
+template <int NEQ>
 __device__ __forceinline__ void solve_real(const double (&a)[NEQ][NEQ], const int (&piv)[NEQ],
                                            const double (&inv)[NEQ], double (&b)[NEQ])
 {
@@ -107,6 +109,7 @@ __device__ __forceinline__ void solve_real(const double (&a)[NEQ][NEQ], const in
 }
 
 // the same for a complex matrix held as (re, im); pivot on |re| + |im|
+template <int NEQ>
 __device__ __forceinline__ bool lu_cplx(double (&ar)[NEQ][NEQ], double (&ai)[NEQ][NEQ], int (&piv)[NEQ],
                                         double (&ir)[NEQ], double (&ii)[NEQ])
 {
@@ -150,6 +153,7 @@ __device__ __forceinline__ bool lu_cplx(double (&ar)[NEQ][NEQ], double (&ai)[NEQ
     return ok;
 }
 
+template <int NEQ>
 __device__ __forceinline__ void solve_cplx(const double (&ar)[NEQ][NEQ], const double (&ai)[NEQ][NEQ],
                                            const int (&piv)[NEQ], const double (&ir)[NEQ], const double (&ii)[NEQ],
                                            double (&br)[NEQ], double (&bi)[NEQ])
@@ -186,6 +190,7 @@ __device__ __forceinline__ void solve_cplx(const double (&ar)[NEQ][NEQ], const d
 // factorisation, no pivoting (LU with partial pivoting would not pivot either: |mu/h - J_ii| exceeds the
 // entries below it), the solves are forward substitutions.  Entries a model's jacobian() leaves at the
 // literal 0.0 drop out at compile time.
+template <int NEQ>
 __device__ __forceinline__ void solve_real_tri(const double (&Jm)[NEQ][NEQ], const double (&inv)[NEQ], double (&b)[NEQ])
 {
 #pragma unroll
@@ -196,6 +201,7 @@ __device__ __forceinline__ void solve_real_tri(const double (&Jm)[NEQ][NEQ], con
         b[i] = s * inv[i];
     }
 }
+template <int NEQ>
 __device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], const double (&ir)[NEQ], const double (&ii)[NEQ],
                                                double (&br)[NEQ], double (&bi)[NEQ])
 {
@@ -235,6 +241,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                                                                  const int* __restrict__ count)
 {
     using namespace radau;
+    constexpr int NEQ = Model::N_EQ, NFA = Model::NF > 0 ? Model::NF : 1;
     const int lane = (int)threadIdx.x;
     const int slot = (int)(blockIdx.x * WAVE) + lane;
     if (slot >= *count) return;
@@ -245,12 +252,12 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
 
-    const bool use_f0 = Model::NF > 0 && A.nforc > 0;
-    const bool use_f1 = Model::NF > 1 && A.nforc > 1;
     size_t fcol = 0;
     if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
-    double tb0 = -__builtin_inf(), tb1 = -__builtin_inf(), F0 = 0.0, F1 = 0.0;
-    typename Model::Forc FV = Model::prep_forcing(P, F0, F1);
+    double tb[NFA], F[NFA];
+#pragma unroll
+    for (int j = 0; j < NFA; ++j) { tb[j] = -__builtin_inf(); F[j] = 0.0; }
+    typename Model::Forc FV = Model::prep_forcing(P, F);
 
     // dense layouts as in hlm_rk45_dense_kernel.h: 0 / 3 [sys][q][c], 1 [tile][q][lane][c], 2 [tile][q][c][lane]
     const bool tiled = A.dense_tiled == 1 || A.dense_tiled == 2;
@@ -286,13 +293,18 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll 1
     while (t < tf) {
         if (n_attempt >= A.cap) { capped = true; break; }
+        double t_b = __builtin_inf();  // the next sample boundary of any stream
         if constexpr (Model::NF > 0) {
             bool moved = false;
-            if (use_f0 && !(t < tb0)) { F0 = sample(0, tb0); moved = true; }
-            if (use_f1 && !(t < tb1)) { F1 = sample(1, tb1); moved = true; }
-            if (moved) FV = Model::prep_forcing(P, F0, F1);
+#pragma unroll
+            for (int j = 0; j < Model::NF; ++j) {
+                if (j < A.nforc) {
+                    if (!(t < tb[j])) { F[j] = sample(j, tb[j]); moved = true; }
+                    t_b = fmin(t_b, tb[j]);
+                }
+            }
+            if (moved) FV = Model::prep_forcing(P, F);
         }
-        const double t_b = fmin(use_f0 ? tb0 : __builtin_inf(), use_f1 ? tb1 : __builtin_inf());
         const double h_ctl = h;
         double t_end = t + h;
         bool clipped = false;

@@ -41,6 +41,7 @@ template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R>
 __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
 {
     using namespace dp;
+    constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
     // XCD-aware block -> hillslope-chunk map (see rk45_multi_kernel)
     const unsigned nblk = gridDim.x, orig = blockIdx.x;
     const unsigned xcd = orig & 7u, qd = nblk >> 3, rm = nblk & 7u;
@@ -70,7 +71,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
 
     // Query window [qb, qe) of this launch (the whole range unless the host streams the dense output
     // in windows, hlm_rk45_integrate_streamed); the buffer holds exactly these rows, tile-major:
-    // element (q, c) of this lane = row0[(q - qb) * 320 + c * 64].
+    // element (q, c) of this lane = row0[(q - qb) * 64 N_EQ + c * 64].
     const int qb = A.q_begin, qe = A.q_end;
     const int q_hi = A.nq < qe ? A.nq : qe;
     constexpr size_t Q_STRIDE = (size_t)WAVE * NEQ;
@@ -94,8 +95,8 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         } else {
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
-            t = A.resume[(size_t)5 * A.ns + sys];
-            h = A.resume[(size_t)6 * A.ns + sys];
+            t = A.resume[(size_t)NEQ * A.ns + sys];
+            h = A.resume[(size_t)(NEQ + 1) * A.ns + sys];
             reject_count = resume_i[(size_t)0 * A.ns + sys];
             n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
             n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     double k0[NEQ], k6[NEQ], yt[NEQ], Q1[NEQ], Q2[NEQ], Q3[NEQ];
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) k0[i] = k6[i] = yt[i] = Q1[i] = Q2[i] = Q3[i] = 0.0;
-    typename Model::Forc FV = Model::prep_forcing(P, held.F0, held.F1);
+    typename Model::Forc FV = Model::prep_forcing(P, held.F);
     // A PENDING step: accepted, not yet committed because rows of it are still to be produced (the
     // ring is full, or the launch's query window ends inside it).  While a lane waits its registers
     // are not written (it is masked off in the attempt code), so the step lives where the attempt
@@ -207,7 +208,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         [[maybe_unused]] const double inv_h = MATH == MATH_FAST ? fast_rcp(h) : 0.0;
         while (want && next_q < q_flush + R && next_q < q_hi) {
             const double tq_after = next_q + 1 < A.nq ? query_at(next_q + 1) : inf;  // fetched while the row is computed
-            double row[NEQ] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            double row[NEQ] = {};
             if (tq_next > t) {  // then the step is pending: rk45_step_dense.cuh:235-243
                 double th;
                 if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
@@ -278,8 +279,8 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             if (status == SYS_PAUSED) {
 #pragma unroll
                 for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
-                A.resume[(size_t)5 * A.ns + sys] = t;
-                A.resume[(size_t)6 * A.ns + sys] = h;
+                A.resume[(size_t)NEQ * A.ns + sys] = t;
+                A.resume[(size_t)(NEQ + 1) * A.ns + sys] = h;
                 resume_i[(size_t)0 * A.ns + sys] = reject_count;
                 resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
                 resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;

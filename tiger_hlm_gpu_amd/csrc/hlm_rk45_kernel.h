@@ -28,27 +28,27 @@ namespace hlm {
 #define HLM_MIN_WAVES_PER_SIMD_LEAN 3
 #endif
 
-constexpr int NEQ = HLM_NEQ;
 constexpr int WAVE = 64;
 constexpr int SYS_PAUSED = 3;  // internal: lane stopped at the end of its query window
 
-// resume record (SoA over systems): 7 doubles {y[5], t, h} then 5 int32 {reject_count,
-// n_attempt, n_accept, next_q, status}
-constexpr int RESUME_F64 = 7, RESUME_I32 = 5;
+// resume record of a model with N state variables (SoA over systems): N + 2 doubles {y[N], t, h}
+// then 5 int32 {reject_count, n_attempt, n_accept, next_q, status}
+constexpr int resume_f64(int n_eq) { return n_eq + 2; }
+constexpr int RESUME_I32 = 5;
 
 // Kernel arguments (kernarg segment -> SGPRs; everything here is wave-uniform).
 struct Rk45Args {
-    const double* y0;       // [ns][5]
+    const double* y0;       // [ns][N_EQ]
     const double* query;    // [nq]
     const void* sp;         // [ns] x 136 B
     const float* forc;      // [sum nT][ld]
     const int32_t* forc_col;
     long long forc_ld;
-    double forc_dtmin[2];          // dt_hours * 60 (rk45_kernel.cu:90), only the NF<=2 used rows
-    unsigned long long forc_nT[2];
-    unsigned long long forc_base[2];  // sum_{k<j} rows_k * ld (rk45_kernel.cu:101-104)
-    unsigned long long forc_first[2]; // sample index of the first row present in this block
-    unsigned long long forc_rows[2];  // rows present (= nT unless the host streams time chunks)
+    double forc_dtmin[HLM_KERNEL_MAX_NF];          // dt_hours * 60 (rk45_kernel.cu:90), the forcings a model can read
+    unsigned long long forc_nT[HLM_KERNEL_MAX_NF];
+    unsigned long long forc_base[HLM_KERNEL_MAX_NF];  // sum_{k<j} rows_k * ld (rk45_kernel.cu:101-104)
+    unsigned long long forc_first[HLM_KERNEL_MAX_NF]; // sample index of the first row present in this block
+    unsigned long long forc_rows[HLM_KERNEL_MAX_NF];  // rows present (= nT unless the host streams time chunks)
     int nforc;
     int ns, nq;
     double t0, tf;
@@ -56,9 +56,9 @@ struct Rk45Args {
     double h0, rtol, atol, safety, min_scale, max_scale;  // Model::Parameters
     double fixed_step;
     uint32_t cap;
-    double* y_final;     // [ns][5]
-    double* dense;       // rows of this launch's query window, linear [ns][W][5] or tile-major
-    int dense_tiled;     // 1: [ceil(ns/64)][W][64][5] (W = q_end - q_begin), coalesced across a wave
+    double* y_final;     // [ns][N_EQ]
+    double* dense;       // rows of this launch's query window, linear [ns][W][N_EQ] or tile-major
+    int dense_tiled;     // 1: [ceil(ns/64)][W][64][N_EQ], 2: [ceil(ns/64)][W][N_EQ][64] (W = q_end - q_begin)
     int q_begin, q_end;  // global query indices [q_begin, q_end) written by this launch
     double* resume;      // nullable: per-system integrator state carried between launches
     int resume_in;       // 0 = start from y0, 1 = continue from `resume`
@@ -130,17 +130,21 @@ __device__ __forceinline__ size_t forcing_row(unsigned long long idx, unsigned l
 // PATH_NORAIN = Model::rhs_norain: the dry path's regime with no rainfall in the held sample.
 constexpr int PATH_GENERAL = 0, PATH_DRY = 1, PATH_NORAIN = 2;
 
+// index of the c-th moving component when component Z is pinned (identity for Z >= N)
+constexpr int moving_component(int c, int Z) { return c < Z ? c : c + 1; }
+
 template <class Model, int MATH, int PATH>
 __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const typename Model::Forc& FV,
-                                          const double (&y)[NEQ], double h, bool have_k0, double (&k0)[NEQ],
-                                          double (&k1)[NEQ], double (&k2)[NEQ], double (&k3)[NEQ], double (&k4)[NEQ],
-                                          double (&k5)[NEQ], double (&k6)[NEQ], double (&yt)[NEQ])
+                                          const double (&y)[Model::N_EQ], double h, bool have_k0, double (&k0)[Model::N_EQ],
+                                          double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ], double (&k3)[Model::N_EQ],
+                                          double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ], double (&k6)[Model::N_EQ],
+                                          double (&yt)[Model::N_EQ])
 {
     using namespace dp;
-    // components that move: all five, or all but the one the fast path pins
+    constexpr int NEQ = Model::N_EQ;
+    // components that move: all of them, or all but the one the fast path pins
     constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : NEQ;
     constexpr int NC = PATH != PATH_GENERAL ? NEQ - 1 : NEQ;
-    constexpr int COMP[NEQ] = {0 < Z ? 0 : 1, 1 < Z ? 1 : 2, 2 < Z ? 2 : 3, 3 < Z ? 3 : 4, 4};
     bool broke = false;
     auto f = [&](const double (&state)[NEQ], double (&slope)[NEQ]) {
         if constexpr (PATH == PATH_NORAIN) broke |= Model::template rhs_norain<MATH>(P, FV, state, slope);
@@ -155,32 +159,32 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     {
         const double a10 = h * A10;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a10, k0[i]); }
+        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a10, k0[i]); }
         f(yt, k1);
     }
     {
         const double a20 = h * A20, a21 = h * A21;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a20, k0[i], a21, k1[i]); }
+        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a20, k0[i], a21, k1[i]); }
         f(yt, k2);
     }
     {
         const double a30 = h * A30, a31 = h * A31, a32 = h * A32;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]); }
+        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]); }
         f(yt, k3);
     }
     {
         const double a40 = h * A40, a41 = h * A41, a42 = h * A42, a43 = h * A43;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = COMP[c]; yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]); }
+        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]); }
         f(yt, k4);
     }
     {
         const double a50 = h * A50, a51 = h * A51, a52 = h * A52, a53 = h * A53, a54 = h * A54;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int i = COMP[c];
+            const int i = moving_component(c, Z);
             yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
         }
         f(yt, k5);
@@ -190,7 +194,7 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
         const double hb0 = h * B0, hb2 = h * B2, hb3 = h * B3, hb4 = h * B4, hb5 = h * B5;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int i = COMP[c];
+            const int i = moving_component(c, Z);
             yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
         }
         f(yt, k6);
@@ -208,22 +212,23 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
 // the paths join.
 template <class Model, int MATH, int PATH, bool FIXED>
 __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const typename Model::Forc& FV,
-                                           const Rk45Args& A, const double (&y)[NEQ], double h, bool have_k0,
-                                           double (&k0)[NEQ], double (&k1)[NEQ], double (&k2)[NEQ], double (&k3)[NEQ],
-                                           double (&k4)[NEQ], double (&k5)[NEQ], double (&k6)[NEQ], double (&yt)[NEQ],
-                                           double& err, double& jump)
+                                           const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool have_k0,
+                                           double (&k0)[Model::N_EQ], double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ],
+                                           double (&k3)[Model::N_EQ], double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ],
+                                           double (&k6)[Model::N_EQ], double (&yt)[Model::N_EQ], double& err, double& jump)
 {
     using namespace dp;
+    constexpr int NEQ = Model::N_EQ;
     const bool broke = rk_stages<Model, MATH, PATH>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
     if constexpr (!FIXED) {
         constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : -1;  // pinned component, if any
         const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5, he6 = h * E6;
         // yt is the 5th-order solution: b[6] = 0 makes it the same chain of operations as the
         // stage-6 state (rk45_step_dense.cuh:111-117)
-        if constexpr (MATH == MATH_FAST) {
+        if constexpr (MATH == MATH_FAST && NEQ == 5) {
             // max_i |e_i| / tol_i with ONE reciprocal: max_i(|e_i| * prod_{j != i} tol_j) / prod_j tol_j
-            // (tol_i in [atol, ~rtol*|y|]: the 5-fold products stay far from the double range)
-            static_assert(NEQ == 5, "the product tree below is written for 5 components");
+            // (tol_i in [atol, ~rtol*|y|]: the 5-fold products stay far from the double range); the product
+            // tree is written out for the 5-component models
             double e[NEQ], tl[NEQ];
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) {
@@ -243,6 +248,14 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
             for (int i = 0; i < NEQ; ++i)
                 if (i != Z) num = vmax_abs2(num, e[i] * others[i]);
             err = num * fast_rcp(all);
+        } else if constexpr (MATH == MATH_FAST) {
+            err = 0.0;  // any other N_EQ: one Newton-refined reciprocal per component
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) {
+                if (i == Z) continue;
+                const double y_err = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                err = vmax_abs2(err, y_err * fast_rcp(__builtin_fma(A.rtol, vmax_abs(y[i], yt[i]), A.atol)));
+            }
         } else {
             err = 0.0;
 #pragma unroll
@@ -270,36 +283,44 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
 // from the reference.)
 template <class Model, bool RESUMABLE>
 struct HeldForcing {
+    static constexpr int NF = Model::NF, NFA = NF > 0 ? NF : 1;
+    static_assert(NF <= HLM_KERNEL_MAX_NF, "a model may read at most HLM_KERNEL_MAX_NF forcings");
     size_t fcol = 0;
-    double tb0 = -__builtin_inf(), tb1 = -__builtin_inf();
-    double tb_next = -__builtin_inf();  // min(tb0, tb1): when the held samples expire
-    double F0 = 0.0, F1 = 0.0;
+    double tb[NFA];                     // when sample j expires
+    double tb_next = -__builtin_inf();  // min_j tb[j]: when the held samples expire
+    double F[NFA];                      // the held samples, widened to double (model_204.hpp:82-83)
 
+    __device__ __forceinline__ HeldForcing()
+    {
+#pragma unroll
+        for (int j = 0; j < NFA; ++j) { tb[j] = -__builtin_inf(); F[j] = 0.0; }
+    }
     __device__ __forceinline__ void init(const Rk45Args& A, int sys)
     {
-        if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
+        if constexpr (NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
     }
     // One rarely-taken branch per attempt: has t (which only moves on an accepted step) reached the
     // end of a held sample?  Returns true when a sample changed (FV was rebuilt; k0 is stale).
+    // A forcing the host did not register (j >= nforc) stays 0, as model_204.hpp:82-83 has it.
     __device__ __forceinline__ bool refresh(const Rk45Args& A, const typename Model::Local& P, double t,
                                             typename Model::Forc& FV)
     {
-        if constexpr (Model::NF > 0) {
+        if constexpr (NF > 0) {
             if (!(t < tb_next)) {
-                const bool use_f0 = Model::NF > 0 && A.nforc > 0;
-                const bool use_f1 = Model::NF > 1 && A.nforc > 1;
-                if (use_f0 && !(t < tb0)) {
-                    const unsigned long long i0 = forcing_index(t, A.forc_dtmin[0], A.forc_nT[0]);
-                    tb0 = (i0 + 1ull < A.forc_nT[0]) ? (double)(i0 + 1ull) * A.forc_dtmin[0] : __builtin_inf();
-                    F0 = (double)A.forc[A.forc_base[0] + (RESUMABLE ? forcing_row(i0, A.forc_first[0], A.forc_rows[0]) : (size_t)i0) * (size_t)A.forc_ld + fcol];
+                double next = __builtin_inf();
+#pragma unroll
+                for (int j = 0; j < NF; ++j) {
+                    if (j < A.nforc) {
+                        if (!(t < tb[j])) {
+                            const unsigned long long i = forcing_index(t, A.forc_dtmin[j], A.forc_nT[j]);
+                            tb[j] = (i + 1ull < A.forc_nT[j]) ? (double)(i + 1ull) * A.forc_dtmin[j] : __builtin_inf();
+                            F[j] = (double)A.forc[A.forc_base[j] + (RESUMABLE ? forcing_row(i, A.forc_first[j], A.forc_rows[j]) : (size_t)i) * (size_t)A.forc_ld + fcol];
+                        }
+                        next = fmin(next, tb[j]);
+                    }
                 }
-                if (use_f1 && !(t < tb1)) {
-                    const unsigned long long i1 = forcing_index(t, A.forc_dtmin[1], A.forc_nT[1]);
-                    tb1 = (i1 + 1ull < A.forc_nT[1]) ? (double)(i1 + 1ull) * A.forc_dtmin[1] : __builtin_inf();
-                    F1 = (double)A.forc[A.forc_base[1] + (RESUMABLE ? forcing_row(i1, A.forc_first[1], A.forc_rows[1]) : (size_t)i1) * (size_t)A.forc_ld + fcol];
-                }
-                tb_next = fmin(use_f0 ? tb0 : __builtin_inf(), use_f1 ? tb1 : __builtin_inf());
-                FV = Model::prep_forcing(P, F0, F1);
+                tb_next = next;
+                FV = Model::prep_forcing(P, F);
                 return true;
             }
         }
@@ -316,10 +337,10 @@ struct HeldForcing {
 // reject / slope-jump retry) and yt is the 5th-order solution.
 template <class Model, int MATH, bool FIXED>
 __device__ __forceinline__ void attempt_on_cheapest_path(const typename Model::Local& P, const typename Model::Forc& FV,
-                                                         const Rk45Args& A, const double (&y)[NEQ], double h, bool& have_k0,
-                                                         double (&k0)[NEQ], double (&k1)[NEQ], double (&k2)[NEQ],
-                                                         double (&k3)[NEQ], double (&k4)[NEQ], double (&k5)[NEQ],
-                                                         double (&k6)[NEQ], double (&yt)[NEQ], double& err, double& jump)
+                                                         const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool& have_k0,
+                                                         double (&k0)[Model::N_EQ], double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ],
+                                                         double (&k3)[Model::N_EQ], double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ],
+                                                         double (&k6)[Model::N_EQ], double (&yt)[Model::N_EQ], double& err, double& jump)
 {
     bool general = true;
     if constexpr (Model::HAS_NORAINPATH) {
@@ -369,6 +390,7 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     rk45_multi_kernel(const Rk45Args A)
 {
     using namespace dp;
+    constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
     // XCD-aware block -> hillslope-chunk map: workgroups are dealt round-robin over the
     // 8 XCDs, so give each XCD one contiguous range of hillslopes (neighbouring
     // hillslopes share forcing rows -> they hit in that XCD's L2).  Bijective for any
@@ -456,8 +478,8 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         }
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
-        t = A.resume[(size_t)5 * A.ns + sys];
-        h = A.resume[(size_t)6 * A.ns + sys];
+        t = A.resume[(size_t)NEQ * A.ns + sys];
+        h = A.resume[(size_t)(NEQ + 1) * A.ns + sys];
         reject_count = resume_i[(size_t)0 * A.ns + sys];
         n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
         n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
@@ -482,7 +504,7 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     // the previous value IS the reference's k0, bit for bit.  have_k0 tracks that.
     bool have_k0 = false;
     double k0[NEQ];
-    typename Model::Forc FV = Model::prep_forcing(P, held.F0, held.F1);
+    typename Model::Forc FV = Model::prep_forcing(P, held.F);
 
     // t_stop (time chunks / checkpoints): a lane whose t has reached it pauses BEFORE its next
     // attempt, so the continuation in the next launch repeats nothing and changes nothing.
@@ -594,8 +616,8 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         if (status == SYS_PAUSED) {
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
-            A.resume[(size_t)5 * A.ns + sys] = t;
-            A.resume[(size_t)6 * A.ns + sys] = h;
+            A.resume[(size_t)NEQ * A.ns + sys] = t;
+            A.resume[(size_t)(NEQ + 1) * A.ns + sys] = h;
             resume_i[(size_t)0 * A.ns + sys] = reject_count;
             resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
             resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
@@ -657,8 +679,12 @@ __global__ void selftest_rhs_kernel(const double* __restrict__ y, const void* sp
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    constexpr int NEQ = Model::N_EQ, NFA = Model::NF > 0 ? Model::NF : 1;
     const typename Model::Local P = Model::template load<MATH>(sp, i);
-    const typename Model::Forc FV = Model::prep_forcing(P, (double)F[2 * i], (double)F[2 * i + 1]);
+    double held[NFA];
+#pragma unroll
+    for (int j = 0; j < NFA; ++j) held[j] = j < 2 ? (double)F[2 * i + j] : 0.0;  // d_F holds two samples per evaluation
+    const typename Model::Forc FV = Model::prep_forcing(P, held);
     double yy[NEQ], d[NEQ];
 #pragma unroll
     for (int c = 0; c < NEQ; ++c) yy[c] = y[(size_t)i * NEQ + c];
@@ -677,10 +703,10 @@ __global__ void selftest_rhs_kernel(const double* __restrict__ y, const void* sp
 // device: the kernel IS the device-to-host transfer (PCIe writes in 640-byte contiguous runs), running
 // on its own stream beside the integration of the next window -- or a device staging buffer
 // (hlm_retrieve_and_free).  One workgroup = 64 systems x TQ queries staged through LDS.
-// COMP_MAJOR: src is [blk][W][5][64] (the wave-synchronous kernel's layout), else [blk][W][64][5].
+// COMP_MAJOR: src is [blk][W][NEQ][64] (the wave-synchronous kernel's layout), else [blk][W][64][NEQ].
 constexpr int TILE_TQ = 16;
 
-template <bool COMP_MAJOR>
+template <bool COMP_MAJOR, int NEQ>
 __global__ void __launch_bounds__(256) dense_tile_to_host(const double* __restrict__ src, double* __restrict__ dst,
                                                           int ns, int nq, int q_begin, int W)
 {

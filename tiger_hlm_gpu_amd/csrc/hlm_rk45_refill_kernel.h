@@ -27,6 +27,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
     rk45_refill_kernel(const Rk45Args A, unsigned int* __restrict__ queue)  // *queue: next unassigned system (starts at gridDim.x * 64)
 {
     using namespace dp;
+    constexpr int NEQ = Model::N_EQ;
     const int lane = (int)threadIdx.x;
     int sys = (int)(blockIdx.x * WAVE) + lane;
     bool retired = sys >= A.ns;  // nothing left for this lane
@@ -46,7 +47,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
     uint32_t n_attempt = 0, n_accept = 0;
     bool have_k0 = false;
     double k0[NEQ];
-    typename Model::Forc FV = Model::prep_forcing(P, held.F0, held.F1);
+    typename Model::Forc FV = Model::prep_forcing(P, held.F);
 
     while (__builtin_amdgcn_ballot_w64(!retired) != 0ull) {
         const bool active = !retired && t < tf && status == HLM_SYS_OK && n_attempt < A.cap;
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                     for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
                     held = HeldForcing<Model, false>{};
                     held.init(A, sys);
-                    FV = Model::prep_forcing(P, held.F0, held.F1);
+                    FV = Model::prep_forcing(P, held.F);
                     t = A.t0;
                     h = FIXED ? A.fixed_step : A.h0;
                     reject_count = 0;

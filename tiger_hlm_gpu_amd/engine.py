@@ -43,8 +43,8 @@ class ShardEngine:
         # y_final | stiff | n_attempt | n_accept live in ONE allocation (52 B per hillslope), so the
         # end-of-run gather to rank 0 is a single collective on `result_blob`
         ns8 = -(-self.ns // 2) * 2  # keeps every section 8-byte aligned
-        self.result_blob = torch.empty(self.ns * 40 + 3 * ns8 * 4, dtype=torch.uint8, device=dev)
-        o = self.ns * 40
+        self.result_blob = torch.empty(self.ns * 8 * model.N_EQ + 3 * ns8 * 4, dtype=torch.uint8, device=dev)
+        o = self.ns * 8 * model.N_EQ
         self.y_final = self.result_blob[:o].view(torch.float64).view(self.ns, model.N_EQ)
         # device layout of the dense buffer (hlm_device_job.dense_tiled): 2 (default) tile-major
         # [tile][q][c][lane], the kernel with wave-synchronous stores; 0 host order and 1 [tile][q][lane][c],
@@ -113,7 +113,7 @@ class ShardEngine:
 
     def _resume_buffer(self):
         if getattr(self, "_resume", None) is None:
-            self._resume = torch.zeros(api.resume_bytes(self.ns), dtype=torch.uint8, device=self.device)
+            self._resume = torch.zeros(api.resume_bytes(self.ns, self.model), dtype=torch.uint8, device=self.device)
         return self._resume
 
     def checkpoint(self):

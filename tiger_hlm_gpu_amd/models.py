@@ -8,7 +8,7 @@ from dataclasses import dataclass, astuple
 
 import numpy as np
 
-from ._lib import UID_204, UID_DUMMY
+from ._lib import UID_TOY3, UID_204, UID_DUMMY
 
 # I_O/parameters_loader.hpp:19-37 -- 2 x long + 15 x double = 136 B, field order is ABI
 SP_DTYPE = np.dtype(
@@ -82,7 +82,28 @@ class DummyModel:
         return np.array([1.0 - Y0, 1.2 + Y0 - X2 - 0.4 - I2, X2 - 0.2, I2 - I3 - 0.3, I3 - 0.1])
 
 
-MODELS = {Model204.UID: Model204, DummyModel.UID: DummyModel}
+class ToyModel3:
+    """The build's "Add a New Model" example (reference README.md, plug-in section): three stores, one
+    forcing, a feedback from the last store to the first (csrc/hlm_models.h: ToyDev;
+    include/hlm/models/model_toy3.hpp).  k1 = 1/alpha3 and k3 = 1/alpha4 come from the SpatialParams
+    record when one is given, else 0.05 and 0.01."""
+    UID = UID_TOY3
+    N_EQ = 3
+    SP_TYPE = SP_DTYPE
+    Parameters = Parameters
+    STATE_NAMES = ("store0", "store1", "store2")
+
+    @staticmethod
+    def rhs(t, y, sp=None, F=()):
+        y0, y1, y2 = (float(v) for v in y)
+        k1 = 1.0 / float(sp["alpha3"]) if sp is not None and sp["alpha3"] > 0 else 0.05
+        k3 = 1.0 / float(sp["alpha4"]) if sp is not None and sp["alpha4"] > 0 else 0.01
+        inflow = float(np.float32(F[0])) if len(F) > 0 else 0.0
+        out0, up, out1 = k1 * y0, 0.3 * y0 * y2, 0.02 * y1 * y1
+        return np.array([inflow - out0 - up, out0 - out1, out1 - k3 * y2 + up])
+
+
+MODELS = {Model204.UID: Model204, DummyModel.UID: DummyModel, ToyModel3.UID: ToyModel3}
 
 
 def initial_step_guess(model, y0_row, sp_row, F=(), rtol=1e-6, atol=1e-9):

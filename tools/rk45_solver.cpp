@@ -33,6 +33,7 @@
 #include "hlm/model_registry.hpp"
 #include "hlm/models/model_204.hpp"
 #include "hlm/models/model_dummy.hpp"
+#include "hlm/models/model_toy3.hpp"
 #include "hlm/output_csv.hpp"
 #include "hlm/rk45_api.hpp"
 #include "hlm/stream.hpp"
@@ -73,7 +74,7 @@ struct Options {
 {
     if (msg) std::fprintf(stderr, "rk45_solver: %s\n", msg);
     std::fprintf(stderr,
-                 "usage: rk45_solver [--config run.yaml] [--init-file states.csv] [--model dummy|204] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
+                 "usage: rk45_solver [--config run.yaml] [--init-file states.csv] [--model dummy|204|toy3] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
@@ -89,7 +90,8 @@ void apply_config(Options& o, const std::string& path)
     const hlm_config::RunConfig c = hlm_config::from_yaml(hlm_config::load_yaml_file(path), slash == std::string::npos ? std::string() : path.substr(0, slash));
     if (c.model_uid == 0) o.model = "dummy";
     else if (c.model_uid == 204) o.model = "204";
-    else throw std::runtime_error("config: model.uid " + std::to_string(c.model_uid) + " is not registered (0 = DummyModel, 204)");
+    else if (c.model_uid == 3) o.model = "toy3";
+    else throw std::runtime_error("config: model.uid " + std::to_string(c.model_uid) + " is not registered (0 = DummyModel, 3 = ToyModel3, 204)");
     if (c.has_time) { o.t0 = 0.0; o.tf = c.tf_minutes; }  // t counts minutes from time.start (main.cpp:610-611)
     if (!c.params_file.empty()) o.params = c.params_file;
     if (c.initial_mode == "hot") o.init_file = c.initial_file;
@@ -176,7 +178,7 @@ template <class Model>
 double scipy_initial_step(const SpatialParams* sp, const float* F, int nForc, double rtol, double atol)
 {
     constexpr int N = Model::N_EQ;
-    double y[N] = {0, 0, 0, 0, 0}, f[N];
+    double y[N] = {}, f[N];
     Model::rhs(0.0, y, f, N, 0, sp, F, nForc);
     double d0 = 0, d1 = 0;
     for (int i = 0; i < N; ++i) {
@@ -192,15 +194,17 @@ int run(const Options& o, hlm_io::CsvStyle style)
 {
     constexpr int N_EQ = Model::N_EQ;
     const bool is204 = Model::UID == HLM_UID_204;
+    const bool is_toy = Model::UID == HLM_UID_TOY3;
 
     // ---- streams ---------------------------------------------------------------------------
     std::vector<SpatialParams> spatial;
     if (!o.params.empty()) spatial = loadSpatialParams(o.params);
     else if (is204) usage("--model 204 needs --params <csv>");
     else spatial.assign((size_t)o.num_systems, SpatialParams{});
-    const std::array<double, N_EQ> y0_common =
-        is204 ? std::array<double, N_EQ>{0.01, 3.0, 0.0, 5.0, 0.2}   // main.cpp:376
-              : std::array<double, N_EQ>{1.0, 1.0, 1.0, 1.0, 1.0};
+    std::array<double, N_EQ> y0_common;
+    y0_common.fill(1.0);
+    if constexpr (Model::UID == HLM_UID_204) y0_common = {0.01, 3.0, 0.0, 5.0, 0.2};  // main.cpp:376
+    if constexpr (Model::UID == HLM_UID_TOY3) y0_common = {1.0, 0.5, 0.2};
     std::vector<Stream<Model>> streams;
     streams.reserve(spatial.size());
     for (const auto& sp : spatial) streams.emplace_back(sp, y0_common);
@@ -255,6 +259,11 @@ int run(const Options& o, hlm_io::CsvStyle style)
 #else
         usage("--forcing-nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
 #endif
+    } else if (is_toy) {
+        // one constant inflow (--rain), hourly samples
+        fb.ld = 1;
+        const size_t n_hours = (size_t)std::ceil((tf - t0) / 60.0);
+        fb.add_constant((float)o.rain, n_hours ? n_hours : 1, 1.0);
     } else if (is204) {
         // constant rain / temperature (the stub forcings of model_204.hpp:76-77) with the
         // reference's hourly and daily sampling (main.cpp:513-514): one shared column
@@ -468,7 +477,8 @@ int main(int argc, char** argv)
         const Options o = parse(argc, argv);
         if (o.model == "204") return run<Model204>(o, hlm_io::CsvStyle::Model204);
         if (o.model == "dummy") return run<DummyModel>(o, hlm_io::CsvStyle::Dummy);
-        usage("--model must be dummy or 204");
+        if (o.model == "toy3") return run<ToyModel3>(o, hlm_io::CsvStyle::Dummy);
+        usage("--model must be dummy, 204 or toy3");
     } catch (const std::exception& e) {
         std::fprintf(stderr, "rk45_solver: %s\n", e.what());
         return 1;
