@@ -98,31 +98,34 @@ __device__ __forceinline__ bool divisor_in_safe_range(double d)
 //         shuffling:
 //           seed   hi32(w0) = 0x553ee979 - hi32(x)/3          |1 - x w0^3| <= 0.103 (all normal x)
 //           step 1 w1 = w0 (1 + e0/3 + 2/9 e0^2 + 14/81 e0^3 + 35/243 e0^4)   |e1| <= 4.4e-6
-//           step 2 r  = x w1 (1 + e1/3 + 2/9 e1^2 + 14/81 e1^3)               remainder ~1e-22
+//           step 2 r  = x w1 (1 + e1/3 + 2/9 e1^2)                            remainder 14/81 e1^3 <= 1.5e-17
 //         Result within 2 ulp of cbrt(x)^2 (hlm_selftest_math, tests).  x < 0 must stay NaN like
 //         pow() so that fmin(1.0, NaN) == 1.0 keeps the reference's behaviour for a negative
-//         surface store (SURVEY A.1 note 6); subnormal x (seed out of range) returns 0, 1e-205
-//         away from the true value; x == 0 gives 0 through the same select.
+//         surface store (SURVEY A.1 note 6); zero and subnormal x give a value <= 1.8e-205 (the true
+//         one is below that as well; the RHS multiplies it by x again, so x == 0 still contributes 0).
 template <int MATH>
 __device__ __forceinline__ double pow_two_thirds(double x)
 {
     if constexpr (MATH == MATH_STRICT) {
         return pow(x, 2.0 / 3.0);
     } else {
-        const unsigned hi = (unsigned)__double2hiint(x);
+        // zero and subnormal arguments (the seed would be out of range) are lifted to the smallest normal
+        // number: the result is then <= 1.8e-205 instead of the true value, which is below that too -- one
+        // v_max_f64 instead of a compare and two selects; a NaN argument is lifted as well, harmlessly
+        // (the caller multiplies the result by the argument again)
+        const double xs = vmax(x, 2.3e-308);
+        const unsigned hi = (unsigned)__double2hiint(xs);
         const unsigned whi = 0x553ee979u - __umulhi(hi, 0x55555556u);
         const double w0 = __hiloint2double((int)whi, 0);
-        const double e0 = __builtin_fma(-x, w0 * w0 * w0, 1.0);
+        const double e0 = __builtin_fma(-xs, w0 * w0 * w0, 1.0);
         double p = __builtin_fma(e0, 35.0 / 243.0, 14.0 / 81.0);
         p = __builtin_fma(e0, p, 2.0 / 9.0);
         p = __builtin_fma(e0, p, 1.0 / 3.0);
         const double w1 = __builtin_fma(w0 * e0, p, w0);
-        const double e1 = __builtin_fma(-x, w1 * w1 * w1, 1.0);
-        double q = __builtin_fma(e1, 14.0 / 81.0, 2.0 / 9.0);
-        q = __builtin_fma(e1, q, 1.0 / 3.0);
-        const double xw = x * w1;
-        double r = __builtin_fma(xw * e1, q, xw);
-        r = x < 2.3e-308 ? 0.0 : r;
+        const double e1 = __builtin_fma(-xs, w1 * w1 * w1, 1.0);   // |e1| <= 4.4e-6
+        const double q = __builtin_fma(e1, 2.0 / 9.0, 1.0 / 3.0);  // the next term, 14/81 e1^3 <= 1.5e-17, is dropped
+        const double xw = xs * w1;
+        const double r = __builtin_fma(xw * e1, q, xw);
         return x < 0.0 ? __builtin_nan("") : r;
     }
 }

@@ -5,7 +5,7 @@
 #      with tracing (guide: MI355X_MICROARCH.md "rocprofv3 PMC slots")
 set -e
 ROOTDIR="${GRAFT_REPO_ROOT:-$PWD}"
-OUT="$ROOTDIR/gpurun_out/prof_${1:-r01}"
+OUT="$ROOTDIR/gpurun_out/prof_${1:-r02}"
 ARGS="--steps 3 --warmup 1 --no-variants --no-cpu-baseline ${2:-}"
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp

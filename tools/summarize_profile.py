@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Condense a tools/profile_r01.sh output directory into the tracked profiles/ files.
+"""Condense a tools/profile_round.sh output directory into the tracked profiles/ files.
 
 usage: python tools/summarize_profile.py gpurun_out/prof_<tag> <tag>
 writes profiles/<tag>_kernel_stats.csv   (rocprofv3 --kernel-trace --stats summary, verbatim top rows)
