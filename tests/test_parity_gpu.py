@@ -242,6 +242,59 @@ def test_three_phase_api_equals_run_rk45(gpu):
     assert np.array_equal(f1, f2) and np.array_equal(d1, d2)
 
 
+def test_host_api_defaults_fast_math_with_automatic_strict_and_lane_refill_switch(gpu, tmp_path):
+    """A reference-style run_rk45<Model204> call with no extra knobs runs the FAST kernels (the headline
+    arithmetic); with tolerances FAST cannot take (atol = 0: its error norm multiplies the five
+    tolerances) the library switches to STRICT by itself instead of failing -- as long as the caller has
+    not chosen a mode.  Run in a fresh process: the choice is process-global.  Also: hlm_set_lane_refill
+    changes which lane integrates which hillslope, nothing else."""
+    import subprocess
+    import sys
+    from conftest import ROOT
+    script = tmp_path / "defaults.py"
+    script.write_text(f"""
+import sys
+sys.path.insert(0, {ROOT!r})
+import numpy as np
+import tiger_hlm_gpu_amd as H
+from tiger_hlm_gpu_amd import synth
+from tiger_hlm_gpu_amd.engine import ShardEngine
+ns, days = 700, 2
+sp = synth.model204_params(0, ns)
+y0 = synth.model204_y0(ns, wet_surface=True)
+cells = synth.cell_of_system(0, ns, run_len=64)
+pr, t2m, dt, nT = synth.forcing_tables(days=days)
+d_sp = H.api.upload_spatial_params(sp)
+f = H.api.set_forcings(np.concatenate([pr, t2m]), dt, nT, ld=pr.shape[1], col=cells)
+def engine(mode, atol):
+    e = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, math_mode=mode, params=H.Parameters(0.01, 1e-6, atol, 0.9, 0.2, 10.0))
+    e.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+    e.integrate()
+    return e.results()["y_final"]
+# default parameters, no mode chosen: the FAST kernel's bits
+a = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5)
+assert np.array_equal(a, engine(H.MATH_FAST, 1e-9)) and not np.array_equal(a, engine(H.MATH_STRICT, 1e-9))
+# lane refill through the host API: same bits
+H.api.set_lane_refill(True)
+assert np.array_equal(H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5), a)
+H.api.set_lane_refill(False)
+# atol = 0: still no mode chosen -> STRICT by itself
+H.api.set_model_parameters(H.Model204, H.Parameters(0.01, 1e-6, 0.0, 0.9, 0.2, 10.0))
+b = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5)
+assert np.array_equal(b, engine(H.MATH_STRICT, 0.0))
+# an explicit FAST with atol = 0 is an error, not a silent switch
+H.api.set_math_mode(H.MATH_FAST)
+try:
+    H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)
+    raise SystemExit("expected an error")
+except H.HlmError as e:
+    assert "atol" in str(e)
+print("ok")
+""")
+    p = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-3000:]
+
+
 # ---- size-independent properties at larger sizes ---------------------------------------------------
 def test_shard_invariance_and_idempotence_bitwise(gpu):
     """Lanes are independent: any split of the hillslopes gives bit-identical per-system

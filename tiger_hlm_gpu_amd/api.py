@@ -105,6 +105,11 @@ def set_math_mode(mode):
     check(lib().hlm_set_math_mode(int(mode)))
 
 
+def set_lane_refill(enabled):
+    """Host API launches without dense output use the lane-refill kernel (hlm_device_job.lane_refill)."""
+    check(lib().hlm_set_lane_refill(int(bool(enabled))))
+
+
 def set_radau_fallback(enabled):
     """Host API (run_rk45 / launch_rk45_kernel): re-integrate flagged systems with Radau IIA."""
     check(lib().hlm_set_radau_fallback(int(bool(enabled))))

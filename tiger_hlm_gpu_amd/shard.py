@@ -69,9 +69,22 @@ def gather_blobs(blob, total, group=None, root=0, n_eq=5):
     if blob.numel() != smax:
         pad = torch.zeros(smax, dtype=blob.dtype, device=blob.device)
         pad[: blob.numel()] = blob
-    if rank == root:
-        bufs = [torch.empty_like(pad) for _ in range(world)]
-        dist.gather(pad, gather_list=bufs, dst=root, group=group)
-        return [b[:n] for b, n in zip(bufs, sizes)]
-    dist.gather(pad, gather_list=None, dst=root, group=group)
-    return None
+    global _GATHER_VIA_ALL_GATHER
+    if not _GATHER_VIA_ALL_GATHER:
+        try:
+            if rank == root:
+                bufs = [torch.empty_like(pad) for _ in range(world)]
+                dist.gather(pad, gather_list=bufs, dst=root, group=group)
+                return [b[:n] for b, n in zip(bufs, sizes)]
+            dist.gather(pad, gather_list=None, dst=root, group=group)
+            return None
+        except (RuntimeError, NotImplementedError):
+            # a backend without gather (every rank takes the same branch: the call fails before any
+            # communication): the same bytes reach the root through an all-gather from now on
+            _GATHER_VIA_ALL_GATHER = True
+    bufs = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(bufs, pad, group=group)
+    return [b[:n] for b, n in zip(bufs, sizes)] if rank == root else None
+
+
+_GATHER_VIA_ALL_GATHER = False
