@@ -83,11 +83,13 @@ def parse():
                     help="minutes between dense queries (0 = no dense output)")
     ap.add_argument("--dense-tiled", type=int, nargs="?", const=1, default=0,
                     help="with --dense-stride: device layout of the in-HBM dense buffer (0 host order, 1 tile-row, "
-                         "2 tile-comp wave-synchronous, 3 host order wave-synchronous)")
+                         "2 tile-comp with wave-synchronous stores)")
     ap.add_argument("--wet-surface", action="store_true",
                     help="headline pass on the wet-surface regime (y0[2] = 0.01: the Manning x^(2/3) term in all 7 stages)")
     ap.add_argument("--tmin", type=float, default=0.5,
                     help="lower end of the daily temperatures; -5 is SURVEY 8d's C3 generator (cold cells get flagged stiff)")
+    ap.add_argument("--compact-minutes", type=float, default=0.0,
+                    help="> 0: the pass in launches of this many minutes with the surviving hillslopes compacted between them")
     ap.add_argument("--lane-refill", action="store_true",
                     help="persistent grid with lane refill (a lane whose hillslope is finished or flagged takes the next one)")
     ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
@@ -143,7 +145,7 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    extra = (";refill" if args.lane_refill else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "")
+    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "")
     return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
@@ -437,6 +439,8 @@ def main():
     if args.radau:
         plain = eng.integrate
         eng.integrate = lambda: plain(radau=True)
+    elif args.compact_minutes > 0:
+        eng.integrate = lambda: eng.integrate_compacting(args.compact_minutes)
     wall, kernel_ms, gather_ms = timed_passes(eng, total, world, args.warmup, args.steps)
     cdev = _coll_device(eng.device) if world > 1 else eng.device
     attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=cdev)
@@ -483,6 +487,7 @@ def main():
                 % ("C3" if args.scaling == "weak" else "C4 (strong scaling, reference split rule)",
                    eng.ns, total, args.days, args.layout,
                    "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})", args.math)
+                + (f", launches of {args.compact_minutes:g} min with compaction" if args.compact_minutes > 0 else "")
                 + (", lane refill" if args.lane_refill else "") + (", WET surface store" if args.wet_surface else "") + (f", T in [{args.tmin:g}, 15]" if args.tmin != 0.5 else "")
                 + (", + Radau-IIA fallback" if args.radau else ""))
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/); only quoted
@@ -591,6 +596,16 @@ def main():
                 res[tag] = {"ms": ms, "attempts": att, "steps_per_s": att / (ms * 1e-3)}
                 if not radau:
                     res["flagged_fraction"] = float((e.stiff == 1).sum().item()) / e.ns
+            # the same RK45 pass in one-day launches with the survivors compacted between them (bit-identical)
+            e.integrate_compacting(1440.0)
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            nl = e.integrate_compacting(1440.0)
+            b.record()
+            torch.cuda.synchronize()
+            res["rk45_compacting"] = {"ms": a.elapsed_time(b), "launches": nl, "interval_minutes": 1440.0,
+                                      "steps_per_s": res["rk45"]["attempts"] / (a.elapsed_time(b) * 1e-3)}
             res["rk45_plus_radau"]["implicit_attempts"] = res["rk45_plus_radau"]["attempts"] - res["rk45"]["attempts"]
             res["rk45_plus_radau"]["unsolved_after"] = int((e.stiff == 2).sum().item())
             res["lane_utilisation_rk45"] = ("40.6 of 64 lanes active per VALU instruction (rocprofv3 SQ_THREAD_CYCLES_VALU / "

@@ -288,6 +288,16 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
 int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* const* h_tables,
                                         double chunk_minutes, void* hip_stream, int* chunks);
 
+/* The integration cut into launches of interval_minutes with the systems still integrating COMPACTED between
+ * them (build feature; SURVEY 7 step 5a "keep divergent adaptive steppers converged").  A hillslope that is
+ * flagged stiff after a few hundred attempts leaves its lane idle until the slowest hillslope of its wave is
+ * through; here every launch but the first runs only the survivors of the one before, in their original order
+ * (so that the lanes of a wave still share a forcing cell and the model's cheap RHS variants keep applying --
+ * which in-kernel lane refill, hlm_device_job.lane_refill, loses).  Lanes pause at the interval ends exactly as
+ * with t_stop: results are bit-identical to hlm_rk45_integrate_device.  For jobs without dense output.
+ * Asynchronous on hip_stream like hlm_rk45_integrate_device.  *launches (nullable): RK45 launches made. */
+int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_minutes, void* hip_stream, int* launches);
+
 /* Transfer path of hlm_rk45_integrate_streamed.  0 (default): linear device windows +
  * hipMemcpy2DAsync on the copy engine (fastest end to end: 54.8 GB/s measured).  1: tile-major
  * device windows (coalesced kernel stores) + a transposing kernel that writes pinned host

@@ -1044,6 +1044,56 @@ def test_cpp_driver_toy_model(gpu, tmp_path):
     assert dh.startswith("time,Var0_sys0,Var1_sys0,Var2_sys0,Var0_sys1") and len(drows) == 5
 
 
+@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "toy-ragged", "dummy-capped"])
+def test_compaction_between_launches_is_bit_identical(gpu, case):
+    """hlm_rk45_integrate_compacting: the window cut into launches, every launch but the first running only
+    the hillslopes that are still integrating, compacted in their original order.  Lanes pause at the
+    interval ends as with t_stop, so finals, flags and both counters equal the single launch bit for bit:
+    cold cells (42 % drop out along the way), the benchmark workload (nobody drops out), a 3-state model on
+    a ragged size, and the attempt cap (everybody drops out in the first launch)."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    kw, forcing, sp = {}, None, None
+    if case == "cold-cells":
+        ns, days, interval = 100_003, 6, 700.0
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
+        forcing = (pr, t2m, synth.cell_of_system(0, ns, run_len=64), dt, nT)
+    elif case == "benchmark":
+        ns, days, interval = 70_000, 3, 1440.0
+        pr, t2m, dt, nT = synth.forcing_tables(days=days)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
+        forcing = (pr, t2m, synth.cell_of_system(0, ns), dt, nT)
+    elif case == "toy-ragged":
+        y0, sp, inflow, cells, tf = _toy_case(ns=1000, days=2)
+        model, interval = H.ToyModel3, 333.0
+    else:
+        ns = 5000
+        model, y0, tf, interval, kw = H.DummyModel, synth.dummy_y0(0, ns), 500.0, 50.0, dict(attempt_cap=100)
+
+    def engine():
+        eng = ShardEngine(model, y0, 0.0, tf, sp=sp, **kw)
+        if forcing is not None:
+            eng.set_forcings_per_cell(forcing[:2], forcing[2], forcing[3], forcing[4])
+        if case == "toy-ragged":
+            eng.set_forcings_per_cell((inflow,), cells, (1.0,), (inflow.shape[0],))
+        return eng
+
+    a = engine()
+    a.integrate()
+    one = a.results()
+    b = engine()
+    assert b.integrate_compacting(interval) == int(np.ceil(tf / interval))
+    two = b.results()
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(one[k], two[k]), (case, k)
+    if case == "cold-cells":
+        assert 0.05 < (one["stiff"] == 1).mean() < 0.95
+    with pytest.raises(H.HlmError):  # jobs with dense output keep the fixed map
+        ShardEngine(H.DummyModel, synth.dummy_y0(0, 10), 0.0, 5.0, query=[1.0, 2.0]).integrate_compacting(1.0)
+
+
 def test_c4_four_million_hillslopes_whole_equals_its_eight_shards(gpu):
     """BASELINE config 4 size: 4 000 000 hillslopes.  Without 8 GPUs at hand the eight contiguous
     shards of the reference's split rule (main.cpp:275-307; 500 000 each) run one after the other on

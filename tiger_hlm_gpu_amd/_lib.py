@@ -105,6 +105,7 @@ SIGNATURES = {
                                               C.POINTER(StreamStats)]),
     "hlm_rk45_integrate_forcing_streamed": (C.c_int, [C.POINTER(DeviceJob), C.POINTER(C.c_void_p), C.c_double,
                                                       C.c_void_p, C.POINTER(C.c_int)]),
+    "hlm_rk45_integrate_compacting": (C.c_int, [C.POINTER(DeviceJob), C.c_double, C.c_void_p, C.POINTER(C.c_int)]),
     "hlm_set_stream_path": (C.c_int, [C.c_int]),
     "hlm_host_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "hlm_host_free_pinned": (C.c_int, [C.c_void_p]),

@@ -870,6 +870,68 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
     return rc;
 }
 
+int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_minutes, void* hip_stream, int* launches)
+{
+    if (!job) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
+    if (!(interval_minutes > 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "interval_minutes must be > 0");
+    int rc = validate_job(job);
+    if (rc != HLM_SUCCESS) return rc;
+    if (job->num_queries > 0 || job_is_resumable(job))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "integrate_compacting takes a plain job without dense output (no queries, "
+                                              "no d_resume / t_stop / query window / forcing chunk)");
+    if (launches) *launches = 0;
+    const int ns = job->num_systems;
+    if (ns == 0) return HLM_SUCCESS;
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    std::vector<double> edge{job->t0};
+    while (edge.back() < job->tf) edge.push_back(std::fmin(job->tf, edge.back() + interval_minutes));
+    const int nchunk = (int)edge.size() - 1;
+    if (nchunk <= 1) {  // one interval (or tf <= t0): nothing to compact
+        rc = launch(job, stream);
+        if (rc == HLM_SUCCESS && launches) *launches = 1;
+        return rc;
+    }
+    const int nb = (ns + hlm::COMPACT_BLOCK - 1) / hlm::COMPACT_BLOCK;
+    const size_t rbytes = hlm_resume_bytes_model(job->uid, ns);
+    const size_t ibytes = sizeof(int32_t) * ((size_t)ns + (size_t)nb + 1);  // index | block counts | count
+    char* pool = nullptr;
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + ibytes, stream));
+    void* resume = pool;
+    int32_t* index = reinterpret_cast<int32_t*>(pool + rbytes);
+    int* block_count = index + ns;
+    int* count = block_count + nb;
+    const int* status = reinterpret_cast<const int*>(static_cast<const double*>(resume) + (size_t)hlm::resume_f64(model_neq(job->uid)) * ns) + (size_t)4 * ns;
+    hipError_t e = hipSuccess;
+    int done = 0;
+    for (int k = 0; k < nchunk && rc == HLM_SUCCESS && e == hipSuccess; ++k) {
+        hlm_device_job j = *job;
+        j.d_resume = resume;
+        j.resume_in = k > 0;
+        j.use_t_stop = edge[k + 1] < job->tf;
+        j.t_stop = edge[k + 1];
+        KernelFn fn = pick(j.uid, j.math_mode, false, j.fixed_step > 0.0, true);
+        hlm::Rk45Args a = make_args(&j);
+        if (k > 0) {
+            // the systems still integrating, in their original order
+            hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, ns, block_count);
+            hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count);
+            hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, ns, block_count, index);
+            a.index = index;
+            a.index_count = count;
+        }
+        // (the grid stays ceil(ns / 64): waves beyond the survivor count read it from device memory and leave at
+        // once -- no host round trip between the launches)
+        hipLaunchKernelGGL(fn, dim3((unsigned)((ns + hlm::WAVE - 1) / hlm::WAVE)), dim3(hlm::WAVE), 0, stream, a);
+        e = hipGetLastError();
+        ++done;
+    }
+    const hipError_t ef = hipFreeAsync(pool, stream);  // stream-ordered: after the last kernel
+    if (e != hipSuccess) return fail(HLM_ERR_HIP, "integrate_compacting: %s", hipGetErrorString(e));
+    HLM_HIP_TRY(ef);
+    if (launches) *launches = done;
+    return rc;
+}
+
 int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms)
 {
     if (iters < 0 || (iters > 0 && !ms)) return fail(HLM_ERR_INVALID_ARGUMENT, "iters/ms");

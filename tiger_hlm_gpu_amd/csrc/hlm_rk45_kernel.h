@@ -65,6 +65,11 @@ struct Rk45Args {
     int32_t* stiff;
     uint32_t* n_attempt;
     uint32_t* n_accept;
+    // RESUMABLE launches only: integrate the systems index[0 .. *index_count) instead of 0 .. ns-1 (slot s of
+    // the grid takes system index[s]): the survivors of earlier launches, compacted in their original order
+    // (hlm_rk45_integrate_compacting).  NULL: the identity.
+    const int32_t* index;
+    const int32_t* index_count;
 };
 
 // y + sum c_j * k_j accumulated left to right with one FMA per term, the order the
@@ -398,7 +403,15 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     const unsigned nblk = gridDim.x, orig = blockIdx.x;
     const unsigned xcd = orig & 7u, qd = nblk >> 3, rm = nblk & 7u;
     const unsigned blk = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + (orig >> 3);
-    const int sys = (int)(blk * WAVE + threadIdx.x);
+    const int slot = (int)(blk * WAVE + threadIdx.x);
+    int sys_of_slot = slot;
+    if constexpr (RESUMABLE) {
+        if (A.index) {
+            if (slot >= *A.index_count) return;
+            sys_of_slot = A.index[slot];
+        }
+    }
+    const int sys = sys_of_slot;
     if (sys >= A.ns) return;
 
     const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
@@ -640,6 +653,69 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
             for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
         }
     }
+}
+
+// ---- ordered compaction of the systems still integrating (hlm_rk45_integrate_compacting) -------------
+// index[0 .. count) = the systems whose resume status is SYS_PAUSED, in ascending order (neighbouring
+// hillslopes share a forcing cell: keeping the order keeps the waves of the next launch uniform, which
+// is what the cheap RHS variants need).  Three small launches: per-block counts, a scan of the block
+// counts by one block, the scatter.  status = the 5th int32 section of the resume record.
+constexpr int COMPACT_BLOCK = 1024;
+
+__global__ void __launch_bounds__(COMPACT_BLOCK) compact_count_kernel(const int* __restrict__ status, int ns, int* __restrict__ block_count)
+{
+    __shared__ int wave_count[COMPACT_BLOCK / WAVE];
+    const int i = (int)(blockIdx.x * COMPACT_BLOCK + threadIdx.x);
+    const bool alive = i < ns && status[i] == SYS_PAUSED;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+    if ((threadIdx.x & (WAVE - 1)) == 0) wave_count[threadIdx.x / WAVE] = __builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int c = 0;
+#pragma unroll
+        for (int w = 0; w < COMPACT_BLOCK / WAVE; ++w) c += wave_count[w];
+        block_count[blockIdx.x] = c;
+    }
+}
+
+// exclusive scan of block_count[0 .. nb) in place (nb is ~1000 for a million systems: one block, serial
+// chunks per thread), total -> *count
+__global__ void __launch_bounds__(COMPACT_BLOCK) compact_scan_kernel(int* __restrict__ block_count, int nb, int* __restrict__ count)
+{
+    __shared__ int part[COMPACT_BLOCK];
+    const int per = (nb + COMPACT_BLOCK - 1) / COMPACT_BLOCK;
+    const int lo = (int)threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    int sum = 0;
+    for (int i = lo; i < hi; ++i) sum += block_count[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < COMPACT_BLOCK; ++i) { const int v = part[i]; part[i] = run; run += v; }
+        *count = run;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = lo; i < hi; ++i) { const int v = block_count[i]; block_count[i] = run; run += v; }
+}
+
+__global__ void __launch_bounds__(COMPACT_BLOCK) compact_scatter_kernel(const int* __restrict__ status, int ns,
+                                                                        const int* __restrict__ block_offset, int32_t* __restrict__ index)
+{
+    __shared__ int wave_offset[COMPACT_BLOCK / WAVE];
+    const int i = (int)(blockIdx.x * COMPACT_BLOCK + threadIdx.x);
+    const bool alive = i < ns && status[i] == SYS_PAUSED;
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+    const int lane = (int)(threadIdx.x & (WAVE - 1)), w = (int)(threadIdx.x / WAVE);
+    if (lane == 0) wave_offset[w] = __builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = block_offset[blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < COMPACT_BLOCK / WAVE; ++k) { const int v = wave_offset[k]; wave_offset[k] = run; run += v; }
+    }
+    __syncthreads();
+    if (alive) index[wave_offset[w] + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
 }
 
 // ---- self-test of the FAST-mode elementary functions (hlm_selftest_math) ---------------------

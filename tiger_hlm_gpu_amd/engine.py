@@ -111,6 +111,17 @@ class ShardEngine:
         if radau:
             api.radau_fallback_device(j, s)
 
+    def integrate_compacting(self, interval_minutes, stream=None):
+        """One pass cut into launches of ``interval_minutes`` with the hillslopes still integrating
+        compacted between them (hlm_rk45_integrate_compacting): bit-identical results, no idle lanes
+        behind hillslopes that were flagged early.  Returns the number of RK45 launches."""
+        import ctypes as C
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        n = C.c_int(0)
+        j = self.job()
+        _lib.check(_lib.lib().hlm_rk45_integrate_compacting(C.byref(j), float(interval_minutes), s.cuda_stream, C.byref(n)))
+        return n.value
+
     def _resume_buffer(self):
         if getattr(self, "_resume", None) is None:
             self._resume = torch.zeros(api.resume_bytes(self.ns, self.model), dtype=torch.uint8, device=self.device)
