@@ -74,3 +74,51 @@ def test_gather_is_identity_without_process_group():
     from tiger_hlm_gpu_amd.shard import gather_to_root
     x = torch.arange(10.0)
     assert gather_to_root(x, 10) is x
+
+
+def _blob_worker(rank, world, port, total, force_fallback, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tiger_hlm_gpu_amd import shard
+        if force_fallback:  # a backend without gather: the same bytes must arrive through all_gather
+            def no_gather(*a, **k):
+                raise RuntimeError("gather is not supported by this backend")
+            dist.gather = no_gather
+        start, count = shard.shard_bounds(total, world, rank)
+        blob = torch.arange(shard.result_blob_bytes(count), dtype=torch.int64).mul_(rank + 3).remainder_(251).to(torch.uint8)
+        for _ in range(2):  # the second call takes the remembered route
+            got = shard.gather_blobs(blob, total)
+        if rank == 0:
+            q.put([g.numpy().copy() for g in got])
+        else:
+            assert got is None
+            q.put(None)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("force_fallback", [False, True])
+def test_gather_blobs_unequal_shards_and_fallback(force_fallback):
+    """The end-of-run gather as one collective over 52-byte-per-hillslope blobs: unequal shards (1001 over 3
+    ranks: 334/334/333) are padded for the collective and cut back on the root; a backend that refuses
+    gather gets the same result through all_gather."""
+    from tiger_hlm_gpu_amd import shard
+    world, total = 3, 1001
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_blob_worker, args=(r, world, port, total, force_fallback, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res = [g for g in got if g is not None]
+    assert len(res) == 1 and len(res[0]) == world
+    for r in range(world):
+        count = shard.shard_bounds(total, world, r)[1]
+        want = (np.arange(shard.result_blob_bytes(count), dtype=np.int64) * (r + 3) % 251).astype(np.uint8)
+        assert np.array_equal(res[0][r], want), r
