@@ -370,14 +370,17 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
                     "in one launch (no d_resume / t_stop / query window / forcing chunk)");
     if (j->fixed_step > 0.0) return HLM_SUCCESS;  // fixed-step runs never flag
     const int ns = j->num_systems;
-    int* scratch = nullptr;  // [0] = count, [1 .. ns] = compacted indices of flagged systems
-    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + 1), stream));
-    if (hipError_t e = hipMemsetAsync(scratch, 0, sizeof(int), stream); e != hipSuccess) {
-        (void)hipFreeAsync(scratch, stream);
-        return fail(HLM_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
-    }
-    hipLaunchKernelGGL(hlm::radau_collect_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream,
-                       j->d_stiff, ns, scratch + 1, scratch);
+    // the flagged systems, compacted IN ORDER: neighbours share a forcing cell and take similar numbers of
+    // implicit attempts, so the lanes of a Radau wave finish together (an atomic append scatters them)
+    const int nb = (ns + hlm::COMPACT_BLOCK - 1) / hlm::COMPACT_BLOCK;
+    int* scratch = nullptr;  // [0 .. ns) indices of flagged systems | [ns .. ns+nb) block counts | [ns+nb] count
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + (size_t)nb + 1), stream));
+    int* const list = scratch;
+    int* const block_count = scratch + ns;
+    int* const count = block_count + nb;
+    hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count);
+    hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count);
+    hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count, list);
     hlm::Rk45Args a = make_args(j);
     // an implicit attempt costs ~30 us of a wave: the default cap of this pass is 2^20 attempts per
     // system (half a minute), not the RK45 loop's 2^24, so a hopeless system cannot hold a wave for long
@@ -390,7 +393,7 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
         return fast ? hlm::radau_fallback_kernel<M, hlm::MATH_FAST> : hlm::radau_fallback_kernel<M, hlm::MATH_STRICT>;
     });
     if (!rf) { (void)hipFreeAsync(scratch, stream); return fail(HLM_ERR_UNKNOWN_MODEL, "no Radau kernel for UID %d", j->uid); }
-    hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, scratch + 1, scratch);
+    hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, list, count);
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(scratch, stream));  // stream-ordered: after the kernels above
     HLM_HIP_TRY(launched);
@@ -913,9 +916,9 @@ int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_min
         hlm::Rk45Args a = make_args(&j);
         if (k > 0) {
             // the systems still integrating, in their original order
-            hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, ns, block_count);
+            hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, (int)hlm::SYS_PAUSED, ns, block_count);
             hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count);
-            hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, ns, block_count, index);
+            hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, (int)hlm::SYS_PAUSED, ns, block_count, index);
             a.index = index;
             a.index_count = count;
         }

@@ -10,8 +10,8 @@
 // implicit step would otherwise hold one sample across many).  The CPU restatement the parity
 // tests check it against lives under oracle/; both are validated against SciPy's Radau.
 //
-// Mapping to CDNA4: one lane per flagged system (the flag list is compacted first so a wave
-// holds 64 stiff systems).  The 15x15 Newton system is block-diagonalised with the RADAU5
+// Mapping to CDNA4: one lane per flagged system (the flag list is compacted first, in order -- the
+// compact_* kernels of hlm_rk45_kernel.h -- so a wave holds 64 stiff systems that are neighbours).  The 15x15 Newton system is block-diagonalised with the RADAU5
 // transformation (T, TI) into one real and one complex 5x5 system per attempt, small enough to
 // factor and solve entirely in VGPRs: partial pivoting is done with per-lane selects (a row swap
 // is 5 conditional exchanges), so no lane-indexed memory is needed at all.  A first version
@@ -43,6 +43,14 @@ constexpr double PD[NS][3] = {
     {13.0 / 3.0 + 7.0 * SQRT6 / 3.0, -23.0 / 3.0 - 22.0 * SQRT6 / 3.0, 10.0 / 3.0 + 5.0 * SQRT6},
     {13.0 / 3.0 - 7.0 * SQRT6 / 3.0, -23.0 / 3.0 + 22.0 * SQRT6 / 3.0, 10.0 / 3.0 - 5.0 * SQRT6},
     {1.0 / 3.0, -8.0 / 3.0, 10.0 / 3.0}};
+// 1/x in the job's arithmetic: IEEE division (STRICT) or the Newton-refined v_rcp_f64 the RK45 loop uses
+// for its error ratio (FAST) -- an attempt of this pass divides ~30 times
+template <int MATH>
+__device__ __forceinline__ double recip(double x)
+{
+    if constexpr (MATH == MATH_FAST) return fast_rcp(x); else return 1.0 / x;
+}
+
 constexpr int NEWTON_MAXITER = 10;
 constexpr double NEWTON_TOL = 1e-3;
 constexpr double FD_EPS = 1e-8;
@@ -220,14 +228,6 @@ __device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], con
 
 }  // namespace radau
 
-// compacts the indices of the systems flagged HLM_SYS_STIFF into list[0 .. *count)
-__global__ void radau_collect_kernel(const int32_t* __restrict__ stiff, int ns, int* __restrict__ list,
-                                     int* __restrict__ count)
-{
-    const int i = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-    if (i < ns && stiff[i] == HLM_SYS_STIFF) list[atomicAdd(count, 1)] = i;
-}
-
 // MATH: the arithmetic of the model's RHS (hlm_set_math_mode / hlm_device_job.math_mode), as in the RK45
 // kernel.  It matters here more than there: an attempt evaluates the RHS 6 + 3 per Newton iteration
 // = ~14 times, and STRICT's OCML pow costs ~200 instructions each.
@@ -338,14 +338,15 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         [[maybe_unused]] double Mr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Cr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Ci[TRI ? 1 : NEQ][TRI ? 1 : NEQ];
         double inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
         [[maybe_unused]] int piv_r[NEQ], piv_c[NEQ];
-        const double g_h = MU_REAL / h, a_h = MU_CRE / h, b_h = MU_CIM / h;
+        const double inv_h = recip<MATH>(h);
+        const double g_h = MU_REAL * inv_h, a_h = MU_CRE * inv_h, b_h = MU_CIM * inv_h;
         bool ok = true;
         if constexpr (TRI) {
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) {
                 const double dr = g_h - Jm[i][i], cr = a_h - Jm[i][i];
-                inv_r[i] = 1.0 / dr;
-                const double d = 1.0 / (cr * cr + b_h * b_h);  // 1 / ((a/h - J_ii) - i b/h)
+                inv_r[i] = recip<MATH>(dr);
+                const double d = recip<MATH>(cr * cr + b_h * b_h);  // 1 / ((a/h - J_ii) - i b/h)
                 inv_cr[i] = cr * d;
                 inv_ci[i] = b_h * d;
                 ok = ok && fabs(dr) > 1e-300;
@@ -375,6 +376,9 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         for (int s = 0; s < NS; ++s)
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) Z[s][i] = W[s][i] = 0.0;
+        double inv_sc[NEQ];  // 1 / (atol + rtol |y_i|): the Newton increment is measured in these units
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) inv_sc[i] = recip<MATH>(A.atol + A.rtol * fabs(y[i]));
         bool converged = false;
         double prev = __builtin_inf();
 #pragma unroll 1
@@ -402,8 +406,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 W[0][i] += d0[i];
                 W[1][i] += d1[i];
                 W[2][i] += d2[i];
-                const double sc = A.atol + A.rtol * fabs(y[i]);
-                const double r = fmax(fmax(fabs(d0[i]), fabs(d1[i])), fabs(d2[i])) / sc;
+                const double r = fmax(fmax(fabs(d0[i]), fabs(d1[i])), fabs(d2[i])) * inv_sc[i];
                 if (r > nrm) nrm = r;
 #pragma unroll
                 for (int s = 0; s < NS; ++s) Z[s][i] = T[s][0] * W[0][i] + T[s][1] * W[1][i] + T[s][2] * W[2][i];
@@ -419,22 +422,25 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) {
             y_new[i] = y[i] + Z[2][i];
-            ev[i] = f0[i] + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) / h;
+            ev[i] = f0[i] + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) * inv_h;
         }
         solve_r(ev);
         double err = 0.0;
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) {
-            const double r = fabs(ev[i]) / (A.atol + A.rtol * fmax(fabs(y[i]), fabs(y_new[i])));
+            const double r = fabs(ev[i]) * recip<MATH>(A.atol + A.rtol * fmax(fabs(y[i]), fabs(y_new[i])));
             if (r > err) err = r;
         }
         if (!(err == err)) { h *= 0.5; continue; }  // NaN estimate: treat like a failed Newton
-        const double fac = A.safety * pow(1.0 / (err + 1e-16), 0.25);
+        // (1 / (err + 1e-16))^(1/4): two square roots in FAST, pow as the oracle writes it in STRICT
+        double root4;
+        if constexpr (MATH == MATH_FAST) root4 = sqrt(sqrt(recip<MATH>(err + 1e-16))); else root4 = pow(1.0 / (err + 1e-16), 0.25);
+        const double fac = A.safety * root4;
         if (err <= 1.0) {
             while (next_q < A.nq) {
                 const double tq = A.query[next_q];
                 if (!(tq <= t_end)) break;
-                const double th = (tq - t) / h;
+                const double th = (tq - t) * inv_h;
                 double* o = dense_row + (size_t)next_q * q_stride;
 #pragma unroll
                 for (int c = 0; c < NEQ; ++c) {

@@ -656,17 +656,18 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
 }
 
 // ---- ordered compaction of the systems still integrating (hlm_rk45_integrate_compacting) -------------
-// index[0 .. count) = the systems whose resume status is SYS_PAUSED, in ascending order (neighbouring
-// hillslopes share a forcing cell: keeping the order keeps the waves of the next launch uniform, which
-// is what the cheap RHS variants need).  Three small launches: per-block counts, a scan of the block
-// counts by one block, the scatter.  status = the 5th int32 section of the resume record.
+// index[0 .. count) = the systems i with status[i] == want, in ascending order (neighbouring hillslopes
+// share a forcing cell: keeping the order keeps the waves of the next launch uniform -- which is what the
+// cheap RHS variants need, and what makes the lanes of a Radau wave take similar numbers of attempts).
+// Three small launches: per-block counts, a scan of the block counts by one block, the scatter.
+// status = the 5th int32 section of the resume record (want = SYS_PAUSED), or stiff[] (want = HLM_SYS_STIFF).
 constexpr int COMPACT_BLOCK = 1024;
 
-__global__ void __launch_bounds__(COMPACT_BLOCK) compact_count_kernel(const int* __restrict__ status, int ns, int* __restrict__ block_count)
+__global__ void __launch_bounds__(COMPACT_BLOCK) compact_count_kernel(const int* __restrict__ status, int want, int ns, int* __restrict__ block_count)
 {
     __shared__ int wave_count[COMPACT_BLOCK / WAVE];
     const int i = (int)(blockIdx.x * COMPACT_BLOCK + threadIdx.x);
-    const bool alive = i < ns && status[i] == SYS_PAUSED;
+    const bool alive = i < ns && status[i] == want;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
     if ((threadIdx.x & (WAVE - 1)) == 0) wave_count[threadIdx.x / WAVE] = __builtin_popcountll(m);
     __syncthreads();
@@ -699,12 +700,12 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) compact_scan_kernel(int* __rest
     for (int i = lo; i < hi; ++i) { const int v = block_count[i]; block_count[i] = run; run += v; }
 }
 
-__global__ void __launch_bounds__(COMPACT_BLOCK) compact_scatter_kernel(const int* __restrict__ status, int ns,
+__global__ void __launch_bounds__(COMPACT_BLOCK) compact_scatter_kernel(const int* __restrict__ status, int want, int ns,
                                                                         const int* __restrict__ block_offset, int32_t* __restrict__ index)
 {
     __shared__ int wave_offset[COMPACT_BLOCK / WAVE];
     const int i = (int)(blockIdx.x * COMPACT_BLOCK + threadIdx.x);
-    const bool alive = i < ns && status[i] == SYS_PAUSED;
+    const bool alive = i < ns && status[i] == want;
     const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
     const int lane = (int)(threadIdx.x & (WAVE - 1)), w = (int)(threadIdx.x / WAVE);
     if (lane == 0) wave_offset[w] = __builtin_popcountll(m);
