@@ -1,0 +1,78 @@
+#!/usr/bin/env python3
+"""Development probe: one seed of tests/fuzz_parity.py's Radau case; for the hillslopes where the FAST GPU
+result and the oracle differ by more than the bound, who is closer to a tight-tolerance (rtol 1e-10)
+oracle run?  python tools/radau_fuzz_diag.py [seed] [ns] [days]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import tiger_hlm_gpu_amd as H  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tiger_hlm_gpu_amd import synth  # noqa: E402
+from tiger_hlm_gpu_amd.engine import ShardEngine  # noqa: E402
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
+ns = int(sys.argv[2]) if len(sys.argv) > 2 else 512
+days = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+rng = np.random.default_rng(seed)
+sp = synth.model204_params(0, ns, seed=seed)
+sp["Hu"] = 10.0 ** rng.uniform(np.log10(3.05), 2.4, ns) * rng.choice([1.0, 1.0, 0.02], ns)
+sp["infil"] = 10.0 ** rng.uniform(-5.5, -2.5, ns)
+sp["perco"] = 10.0 ** rng.uniform(-6, -3.5, ns)
+y0 = synth.model204_y0(ns)
+y0[:, 2] = np.where(rng.random(ns) < 0.3, rng.uniform(0, 0.02, ns), 0.0)
+if seed % 3 == 1:
+    y0[:, 2] = 0.0
+    sp["infil"] = 10.0 ** rng.uniform(-1, 1, ns)
+    sp["Hu"] = 10.0 ** rng.uniform(np.log10(3.05), 2.4, ns) * rng.choice([1.0, 0.9, 0.5], ns)
+y0[:, 0] = rng.uniform(0, 0.02, ns) * (rng.random(ns) < 0.5)
+y0[:, 1] = rng.uniform(0.5, 3.0, ns) if seed % 3 != 1 else rng.uniform(2.0, 3.2, ns)
+run_len = int(rng.choice([1, 7, 64, 512]))
+cells = synth.cell_of_system(0, ns, ncell=64, run_len=run_len)
+pr, t2m, dt, nT = synth.forcing_tables(days=days, ncell=64, seed=seed, wet_prob=float(rng.uniform(0.05, 0.5)),
+                                       intensity=float(10.0 ** rng.uniform(-4.5, -3.0)), tmin=-5.0, tmax=20.0)
+tf = days * 1440.0
+q = synth.minute_queries(0.0, tf, float(rng.choice([17.0, 60.0, 240.0])))
+per_cell = bool(rng.random() < 0.5)
+block = synth.expand_per_stream(pr, t2m, cells)
+kw = dict(sp=sp, query=q, forc=block, forc_dt_h=dt, forc_nT=nT, attempt_cap=2_000_000)
+ref = O.run(O.UID_204, y0, 0.0, tf, radau=True, **kw)
+res = {}
+for mm in (0, 1):
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, math_mode=mm, attempt_cap=2_000_000)
+    if per_cell:
+        eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+    else:
+        eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    eng.integrate(radau=True)
+    res[mm] = eng.results()
+tol = 1e-9 + 1e-6 * np.abs(ref["y_final"])
+told = 1e-9 + 1e-6 * np.abs(ref["dense"])
+dev = {mm: np.maximum((np.abs(res[mm]["y_final"] - ref["y_final"]) / tol).max(axis=1),
+                      (np.abs(res[mm]["dense"] - ref["dense"]) / told).reshape(ns, -1).max(axis=1)) for mm in (0, 1)}
+same = (ref["stiff"] == res[1]["stiff"])
+bad = np.flatnonzero((dev[1] > 1.0) & same)
+print("flagged", int((ref["stiff"] == 1).sum()), "FAST beyond bound:", [(int(i), int(ref["stiff"][i])) for i in bad],
+      "STRICT beyond bound:", np.flatnonzero((dev[0] > 1.0) & (ref["stiff"] == res[0]["stiff"])).tolist(),
+      "flag mismatches FAST:", np.flatnonzero(~same).tolist())
+if len(bad):
+    # tight reference: everything through Radau at rtol 1e-10
+    # tight reference: RK45 at rtol 1e-10 for the unflagged ones is not the same trajectory family (the explicit
+    # loop holds a forcing sample over a step that straddles its end), so: everything through Radau at rtol 1e-10
+    tight = O.run(O.UID_204, y0[bad], 0.0, tf, query=q, sp=sp[bad], forc=block[:, bad], forc_dt_h=dt, forc_nT=nT, attempt_cap=20_000_000,
+                  radau_only=True, params=(0.01, 1e-10, 1e-13, 0.9, 0.2, 10.0))
+    fma = O.run(O.UID_204, y0[bad], 0.0, tf, query=q, sp=sp[bad], forc=block[:, bad], forc_dt_h=dt, forc_nT=nT, attempt_cap=2_000_000, radau=True, fma=True)
+    for k, i in enumerate(bad):
+        e_ref = np.abs(ref["dense"][i] - tight["dense"][k]) / told[i]
+        e_gpu = np.abs(res[1]["dense"][i] - tight["dense"][k]) / told[i]
+        dd = np.abs(res[1]["dense"][i] - ref["dense"][i]) / told[i]
+        r, c = np.unravel_index(np.argmax(dd), dd.shape)
+        print(f"   worst row {r} (t = {q[r]:g}) comp {c}: gpu {res[1]['dense'][i, r, c]!r} oracle {ref['dense'][i, r, c]!r} tight {tight['dense'][k, r, c]!r};"
+              f" rows beyond bound: {int((dd.max(axis=1) > 1).sum())} of {len(q)}, first {int(np.argmax(dd.max(axis=1) > 1))}")
+        sep = (np.abs(fma["dense"][k] - ref["dense"][i]) / told[i]).max()
+        print(f"sys {i} (flag {ref['stiff'][i]}, oracle-vs-its-FMA-build separation {sep:.3g}): Hu {sp['Hu'][i]:.3g} attempts oracle/gpu {ref['n_attempt'][i]}/{res[1]['n_attempt'][i]}  "
+              f"|oracle - tight| {e_ref.max():.3g} x bound   |gpu FAST - tight| {e_gpu.max():.3g} x bound   |gpu - oracle| {dev[1][i]:.3g}")
