@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development probe: one seed of tests/fuzz_parity.py's Radau case; for the hillslopes where the FAST GPU
 result and the oracle differ by more than the bound, who is closer to a tight-tolerance (rtol 1e-10)
-oracle run?  python tools/radau_fuzz_diag.py [seed] [ns] [days]"""
+oracle run?  python tests/radau_fuzz_diag.py [seed] [ns] [days]"""
 import os
 import sys
 
