@@ -295,6 +295,33 @@ print("ok")
     assert p.returncode == 0 and p.stdout.strip().endswith("ok"), p.stderr[-3000:]
 
 
+def test_retrieve_and_free_transposes_the_tile_layout_on_every_route(gpu):
+    """hlm_retrieve_and_free delivers dense[(s*nq+q)*N_EQ+c] from the tile-major device buffer: through the
+    256 MB device staging buffer in several passes (pageable destination; 70 001 hillslopes x 101 queries =
+    283 MB, ragged last tile) and by the transposing kernel writing pinned host memory directly -- both equal
+    the engine's own re-ordering of the same run."""
+    H = gpu
+    import torch
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns = 70_001
+    y0 = synth.dummy_y0(0, ns)
+    q = synth.dummy_query_times(5.0, 101)
+    eng = ShardEngine(H.DummyModel, y0, 0.0, 5.0, query=q)
+    eng.integrate()
+    ref = eng.results()
+    outs = []
+    for pinned in (False, True):
+        b = H.api.setup_gpu_buffers(H.DummyModel, y0.reshape(-1), q)
+        assert b.dense_layout == 2 and b.neq == 5
+        H.api.launch_rk45_kernel(H.DummyModel, b, 0.0, 5.0, None)
+        dst = torch.full((ns * len(q) * 5,), -3.0, dtype=torch.float64, pin_memory=pinned)
+        f, d = H.api.retrieve_and_free(H.DummyModel, b, dense_out=dst)
+        outs.append((f.reshape(ns, 5), dst.numpy().reshape(ns, len(q), 5).copy()))
+    for f, d in outs:
+        assert np.array_equal(f, ref["y_final"]) and np.array_equal(d, ref["dense"])
+
+
 # ---- size-independent properties at larger sizes ---------------------------------------------------
 def test_shard_invariance_and_idempotence_bitwise(gpu):
     """Lanes are independent: any split of the hillslopes gives bit-identical per-system

@@ -201,10 +201,16 @@ def launch_rk45_kernel(model, bufs, t0, tf, d_sp):
     check(lib().hlm_launch_rk45_kernel(_uid(model), C.byref(bufs), float(t0), float(tf), sp_ptr))
 
 
-def retrieve_and_free(model, bufs, with_info=False):
+def retrieve_and_free(model, bufs, with_info=False, dense_out=None):
+    """``dense_out``: optional float64 array / pinned torch tensor of ns*nq*N_EQ elements to receive the dense
+    rows (pinned, device-mapped memory is written by the transposing kernel directly)."""
     ns, nq, neq = bufs.num_systems, bufs.num_queries, model.N_EQ
     final = np.empty(ns * neq)
-    dense = np.empty(ns * nq * neq)
+    if dense_out is None:
+        dense = np.empty(ns * nq * neq)
+    else:
+        dense = dense_out.numpy().reshape(-1) if hasattr(dense_out, "numpy") else np.asarray(dense_out).reshape(-1)
+        assert dense.dtype == np.float64 and dense.size == ns * nq * neq and dense.flags.c_contiguous
     stiff = np.empty(ns, dtype=np.int32)
     na = np.empty(ns, dtype=np.uint32)
     nacc = np.empty(ns, dtype=np.uint32)
