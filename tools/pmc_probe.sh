@@ -15,6 +15,7 @@ out=sys.argv[1]
 for f in sorted(glob.glob(out+'/p*/*/*_counter_collection.csv')):
     agg=collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        if 'rk45' in r['Kernel_Name']: agg[r['Counter_Name']].append(float(r['Counter_Value']))
+        k = 'radau' if 'radau_fallback' in r['Kernel_Name'] else ('rk45' if 'rk45' in r['Kernel_Name'] else None)
+        if k: agg[k + ' ' + r['Counter_Name']].append(float(r['Counter_Value']))
     for k,v in agg.items(): print(f.split('/')[-3], k, sum(v)/len(v), len(v))
 PY
