@@ -3,22 +3,28 @@ box: python tests/fuzz_parity.py [n_seeds] [ns] [days]; lives under tests/ becau
 workload -- static-store capacities that do and do not saturate (surface store goes wet), wet / dry /
 mixed starts, rain frequency and intensity, infiltration capacities around the rain rates, per-cell
 and per-stream layouts -- and checks flags, step counts and values at the solver tolerance in both
-math modes.  Because such workloads are full of min / max kinks, "tolerance" is per hillslope the solver
-tolerance plus 5x the separation of three yardstick runs of the oracle itself (FMA-contracted build,
-rtol * (1 +- 1e-12)); a few hillslopes per thousand sit on a discrete event that none of the three
-happens to move and are allowed (<= 0.5 %).  Exit code 1 and a report line per failing seed.
-Typical result (24 seeds x 1024 hillslopes x 3 days, both modes): 0 flag mismatches in 49 152
-hillslope runs, step counts within 6, <= 4 hillslopes per run beyond the bound."""
+math modes with the rule of tests/conftest.py: every hillslope within the parity bound with the oracle's
+flag, OR individually shown ill-conditioned by the yardstick (the oracle's FMA build, the oracle and the
+GPU with rtol / h0 changed by a relative 1e-12 .. 1e-10).  A seed fails on more than one hillslope per
+thousand that the yardstick does not explain, on more than 15 % exemptions (these workloads sit on
+min / max kinks on purpose: 0.2 .. 12 % of the hillslopes of a seed are ill-conditioned at 1e-6), or on
+a non-finite result; exit code 1 and a report line per failing seed.
+Measured (40 seeds x 1024 hillslopes x 3 days, both modes, profiles/r02_fuzz40_summary.txt): 1 flag
+mismatch pair (shown ill-conditioned), exemptions STRICT 1531 / FAST 1536 of 40 960 each, 1 hillslope
+unexplained (FAST, 1.11 x the bound with a yardstick spread of 0.43), step counts within 11."""
 import os
 import sys
 
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import tiger_hlm_gpu_amd as H  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from tiger_hlm_gpu_amd import synth  # noqa: E402
 from tiger_hlm_gpu_amd.engine import ShardEngine  # noqa: E402
+from conftest import (DEFAULT_PARAMS, YARDSTICK_PERTURBATIONS, parity_or_shown_ill_conditioned,  # noqa: E402
+                      perturbed_params, yardstick_runs)
 
 
 RADAU = False  # argv[4] == "radau": cold cells (negative ET stub flags hillslopes) + the Radau-IIA pass on both sides
@@ -47,42 +53,34 @@ def one(seed, ns, days):
     q = synth.minute_queries(0.0, days * 1440.0, float(rng.choice([17.0, 60.0, 240.0])))
     per_cell = bool(rng.random() < 0.5)
     block = synth.expand_per_stream(pr, t2m, cells)
-    ref = O.run(O.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, forc=block, forc_dt_h=dt, forc_nT=nT, attempt_cap=2_000_000, radau=RADAU)
-    # yardstick: the same text compiled with FMA contraction.  How far it lands from `ref` on a
-    # hillslope is how far two valid roundings of one computation separate there (min / max kinks:
-    # Emax = min(e_pot, h_stat), the capacity overflow max(0, x1 + h_stat - Hu), ...)
-    alt = O.run(O.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, forc=block, forc_dt_h=dt, forc_nT=nT, attempt_cap=2_000_000, fma=True, radau=RADAU)
-    # second yardstick: the plain build with rtol scaled by (1 +- 1e-12) -- some hillslopes sit on a
-    # discrete event (the saturated static store draining through Hu, the surface store first
-    # getting wet) whose step the FMA pattern happens not to move but any other rounding does
-    alts = [alt] + [O.run(O.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, forc=block, forc_dt_h=dt, forc_nT=nT, attempt_cap=2_000_000,
-                          params=(0.01, 1e-6 * (1.0 + e), 1e-9, 0.9, 0.2, 10.0), radau=RADAU) for e in (1e-12, -1e-12)]
+    kw = dict(query=q, sp=sp, forc=block, forc_dt_h=dt, forc_nT=nT, attempt_cap=2_000_000, radau=RADAU)
+    ref = O.run(O.UID_204, y0, 0.0, days * 1440.0, **kw)
+    # the yardstick of tests/conftest.py: the oracle's FMA build + the oracle with rtol / h0 changed by a
+    # relative 1e-12 .. 1e-10, and (below) the GPU itself under the first four of those perturbations
+    alts = yardstick_runs(O, O.UID_204, y0, 0.0, days * 1440.0, perturbations=YARDSTICK_PERTURBATIONS, **kw)
     problems = []
     for mm in (0, 1):
-        eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, math_mode=mm, attempt_cap=2_000_000)
-        if per_cell:
-            eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
-        else:
-            eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
-        eng.integrate(radau=RADAU)
-        got = eng.results()
-        flags = got["stiff"] != ref["stiff"]
-        ok = ~flags & ((ref["stiff"] == 0) | (RADAU & (ref["stiff"] == 1)))
-        # per hillslope: |gpu - ref| <= tolerance + 5 x (largest separation among the yardstick runs)
-        over = np.zeros(ns)
-        for name in ("y_final", "dense"):
-            tol = 1e-9 + 1e-6 * np.abs(ref[name])
-            d = (np.abs(got[name] - ref[name]) / tol).reshape(ns, -1).max(axis=1)
-            spread = np.max([(np.abs(a[name] - ref[name]) / tol).reshape(ns, -1).max(axis=1) for a in alts], axis=0)
-            over = np.maximum(over, d / (1.0 + 5.0 * spread))
-        usable = ok & np.all([a["stiff"] == ref["stiff"] for a in alts], axis=0)
-        dn = np.abs(got["n_attempt"][ok].astype(np.int64) - ref["n_attempt"][ok].astype(np.int64))
+        def gpu(params):
+            eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, math_mode=mm, attempt_cap=2_000_000, params=H.Parameters(*params))
+            if per_cell:
+                eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+            else:
+                eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+            eng.integrate(radau=RADAU)
+            return eng.results()
+        got = gpu(DEFAULT_PARAMS)
+        got_alts = [gpu(perturbed_params(DEFAULT_PARAMS, er, eh)) for er, eh in YARDSTICK_PERTURBATIONS[:4]]
+        within, exempt, dev, spread = parity_or_shown_ill_conditioned(got, ref, alts, got_alts=got_alts)
+        bad = ~(within | exempt)
+        same = got["stiff"] == ref["stiff"]
+        dn = np.abs(got["n_attempt"][same].astype(np.int64) - ref["n_attempt"][same].astype(np.int64))
         info = dict(seed=seed, math=mm, per_cell=per_cell, run_len=run_len, flagged=int((ref["stiff"] != 0).sum()),
-                    wet_end=int((ref["y_final"][:, 2] != 0).sum()), flag_mismatch=int(flags.sum()),
-                    flag_mismatch_of_yardstick=int((alt["stiff"] != ref["stiff"]).sum()),
-                    worst_over_bound=round(float(over[usable].max()), 3), beyond_bound=int((over[usable] > 1).sum()),
+                    wet_end=int((ref["y_final"][:, 2] != 0).sum()), flag_mismatch=int((~same).sum()),
+                    worst_within=round(float(dev[within].max()), 4) if within.any() else 0.0, exempt=int(exempt.sum()),
+                    unexplained=int(bad.sum()), unexplained_detail=[(int(i), round(float(dev[i]), 2), round(float(spread[i]), 3))
+                                                                     for i in np.flatnonzero(bad)[:6]],
                     max_dn=int(dn.max()) if dn.size else 0, finite=bool(np.isfinite(got["y_final"]).all()))
-        if flags.sum() > max(3, 3 * info["flag_mismatch_of_yardstick"]) or info["beyond_bound"] > 0.005 * ns or not info["finite"]:
+        if info["unexplained"] > max(1, ns // 1000) or info["exempt"] > 0.15 * ns or not info["finite"]:
             problems.append(info)
         print(info, flush=True)
     return problems
