@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     };
 
     bool capped = false;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no prologue load is waited for inside the loop, behind the row stores
 #pragma unroll 1
     while (t < tf) {
         if (n_attempt >= A.cap) { capped = true; break; }

@@ -134,6 +134,13 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     // attempt, (B) lanes with rows to produce put them into the ring while it has room, committing
     // their step after its last row, (C) the wave flushes the rows every lane is through with.
     bool wave_on = true;  // wave-uniform
+    if (live && t < t_end) held.refresh(A, P, t, FV);  // the samples of the first attempt (have_k0 is false)
+    // Every load issued so far (parameters, state, resume record) lands HERE, not at its first use
+    // inside the loop: gfx950 has one counter (vmcnt) for loads AND stores, so a wait for a prologue
+    // load that the compiler places in the loop body would, on every iteration, also wait for the row
+    // stores of the previous flush to be acknowledged by memory -- the stores must drain behind the
+    // next attempt's arithmetic instead.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     while (wave_on) {
         bool progress = false;
         // ---- (A) one attempt ------------------------------------------------------------------
@@ -145,8 +152,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         if (can_step) {
             progress = true;
             if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
-            if (held.refresh(A, P, t, FV)) have_k0 = false;
-            ++n_attempt;
+            ++n_attempt;  // (the forcing samples held for this t were fetched before the loop or in (B'))
             double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ];
             [[maybe_unused]] double err = 0.0, jump = 0.0;
             attempt_on_cheapest_path<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
@@ -236,6 +242,15 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             ++n_accept;
             pending = false;
             progress = true;
+        }
+
+        // ---- (B') the forcing samples of the next attempt ----------------------------------------
+        // Fetched here, BEFORE this iteration's row stores are issued: the wait for the load then
+        // only covers the stores of the previous flush, which have had a whole iteration to drain
+        // (one vmcnt for loads and stores, see above).  t only changes in the commit above, so this is
+        // the refresh the next attempt would do (rk45_kernel.cu:62-75), same samples, same k0 handling.
+        if (live && !pending && t < t_end) {
+            if (held.refresh(A, P, t, FV)) have_k0 = false;
         }
 
         // ---- (C) flush: row q_flush goes to HBM once every lane is through with it ----------------

@@ -522,6 +522,10 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     // t_stop (time chunks / checkpoints): a lane whose t has reached it pauses BEFORE its next
     // attempt, so the continuation in the next launch repeats nothing and changes nothing.
     const double t_end = RESUMABLE ? fmin(tf, A.t_stop) : tf;
+    // With dense rows stored inside the loop, the prologue's loads are waited for here rather than at
+    // their first use in the loop body: gfx950 counts loads and stores in one counter (vmcnt), so such
+    // a wait would hold every attempt until the previous step's row stores are acknowledged.
+    if constexpr (DENSE) __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
         if constexpr (DENSE) {
             // slide the query-time window when the wave's first active lane nears its end
