@@ -41,6 +41,7 @@ template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R>
 __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
 {
     using namespace dp;
+    static_assert(R > 0 && (R & (R - 1)) == 0, "the ring slot of row q is q & (R - 1)");
     constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
     // XCD-aware block -> hillslope-chunk map (see rk45_multi_kernel)
     const unsigned nblk = gridDim.x, orig = blockIdx.x;
@@ -209,13 +210,15 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         }
         // A lane has a row to produce when its pending step contains the next query (rk45_kernel.cu:139-146),
         // or when that query is not later than its current time: such a row is never produced by the
-        // reference (rk45_kernel.cu:141: "if (tq > t)") and stays 0.
-        bool want = !owes_zeros && ((pending && tq_next <= t1) || tq_next <= t);
+        // reference (rk45_kernel.cu:141: "if (tq > t)") and stays 0 -- as does every row of a lane that
+        // has stopped for good, which it puts into the ring like any other (the flush then never has to
+        // tell a produced row from an owed zero).
+        bool want = owes_zeros || (pending && tq_next <= t1) || tq_next <= t;
         [[maybe_unused]] const double inv_h = MATH == MATH_FAST ? fast_rcp(h) : 0.0;
         while (want && next_q < q_flush + R && next_q < q_hi) {
             const double tq_after = next_q + 1 < A.nq ? query_at(next_q + 1) : inf;  // fetched while the row is computed
             double row[NEQ] = {};
-            if (tq_next > t) {  // then the step is pending: rk45_step_dense.cuh:235-243
+            if (pending && tq_next > t) {  // rk45_step_dense.cuh:235-243
                 double th;
                 if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
                 const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
@@ -225,12 +228,12 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                     row[i] = __builtin_fma(h, poly, y[i]);
                 }
             }
-            const lds_double_ptr slot = ring + (next_q % R) * (NEQ * WAVE);
+            const lds_double_ptr slot = ring + (next_q & (R - 1)) * (NEQ * WAVE);
 #pragma unroll
             for (int c = 0; c < NEQ; ++c) slot[c * WAVE] = row[c];
             ++next_q;
             tq_next = tq_after;
-            want = (pending && tq_next <= t1) || tq_next <= t;
+            want = owes_zeros || (pending && tq_next <= t1) || tq_next <= t;
             progress = true;
         }
         if (pending && !(tq_next <= t1)) {
@@ -257,21 +260,23 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         // (Reading all ready rows from the ring before the first store -- one LDS latency per batch --
         // was measured: no gain, 40 more live registers, spills.)
         bool flushed = false;
+        const unsigned long long paused = __builtin_amdgcn_ballot_w64(stuck);  // they produce nothing more in this launch
         while (q_flush < q_hi) {
             const bool has_row = next_q > q_flush;
-            if (__builtin_amdgcn_ballot_w64(!(has_row || owes_zeros || stuck)) != 0ull) break;  // somebody is still on its way
-            // nobody has produced it: only a wave whose lanes have ALL stopped for good fills in zeros here
-            if (__builtin_amdgcn_ballot_w64(has_row) == 0ull && __builtin_amdgcn_ballot_w64(!owes_zeros) != 0ull) break;
-            // every lane reads its column of the slot (five reads in flight, one wait); what it has not
-            // produced is replaced by the zeros it owes
-            const lds_double_ptr slot = ring + (q_flush % R) * (NEQ * WAVE);
+            const unsigned long long have = __builtin_amdgcn_ballot_w64(has_row);
+            // somebody is still on its way to this row, or only paused lanes are left (their rows belong to the next launch)
+            if (__builtin_amdgcn_ballot_w64(!has_row) & ~paused) break;
+            if (have == 0ull) break;
+            // every lane reads its column of the slot (five reads in flight, one wait) and stores it:
+            // per component 64 lanes x 8 B = 512 contiguous bytes
+            const lds_double_ptr slot = ring + (q_flush & (R - 1)) * (NEQ * WAVE);
             double v[NEQ];
 #pragma unroll
             for (int c = 0; c < NEQ; ++c) v[c] = slot[c * WAVE];
-            if (q_flush >= my_start_q && (has_row || owes_zeros)) {
+            if (has_row && q_flush >= my_start_q) {
                 double* o = row0 + (size_t)(q_flush - qb) * Q_STRIDE;
 #pragma unroll
-                for (int c = 0; c < NEQ; ++c) o[c * WAVE] = has_row ? v[c] : 0.0;  // 64 lanes x 8 B: 512 contiguous bytes
+                for (int c = 0; c < NEQ; ++c) o[c * WAVE] = v[c];
             }
             ++q_flush;
             flushed = true;
