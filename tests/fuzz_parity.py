@@ -10,7 +10,7 @@ thousand that the yardstick does not explain, on more than 15 % exemptions (thes
 min / max kinks on purpose: 0.2 .. 12 % of the hillslopes of a seed are ill-conditioned at 1e-6), or on
 a non-finite result; exit code 1 and a report line per failing seed.
 Measured (40 seeds x 1024 hillslopes x 3 days, both modes, profiles/r02_fuzz40_summary.txt): 1 flag
-mismatch pair (shown ill-conditioned), exemptions STRICT 1531 / FAST 1536 of 40 960 each, 1 hillslope
+mismatch pair (shown ill-conditioned), exemptions STRICT 1532 / FAST 1535 of 40 960 each, 1 hillslope
 unexplained (FAST, 1.11 x the bound with a yardstick spread of 0.43), step counts within 11."""
 import os
 import sys
