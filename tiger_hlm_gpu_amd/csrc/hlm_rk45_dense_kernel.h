@@ -215,27 +215,35 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         // tell a produced row from an owed zero).
         bool want = owes_zeros || (pending && tq_next <= t1) || tq_next <= t;
         [[maybe_unused]] const double inv_h = MATH == MATH_FAST ? fast_rcp(h) : 0.0;
-        while (want && next_q < q_flush + R && next_q < q_hi) {
-            const double tq_after = next_q + 1 < A.nq ? query_at(next_q + 1) : inf;  // fetched while the row is computed
-            double row[NEQ] = {};
-            if (pending && tq_next > t) {  // rk45_step_dense.cuh:235-243
-                double th;
-                if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
-                const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
+        // one row per trip; ZEROS = false is the variant for a wave none of whose lanes produces a zero row
+        // in this iteration (the usual case: no select, no inner branch)
+        const int q_lim = q_flush + R < q_hi ? q_flush + R : q_hi;  // room in the ring, end of the launch's window
+        auto produce_rows = [&](auto zeros_tag) {
+            constexpr bool ZEROS = decltype(zeros_tag)::value;
+            while (want && next_q < q_lim) {
+                const double tq_after = query_at(next_q + 1);  // fetched while the row is computed (the window holds inf past the last query)
+                double row[NEQ] = {};
+                if (!ZEROS || (pending && tq_next > t)) {  // rk45_step_dense.cuh:235-243
+                    double th;
+                    if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
+                    const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
 #pragma unroll
-                for (int i = 0; i < NEQ; ++i) {
-                    const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
-                    row[i] = __builtin_fma(h, poly, y[i]);
+                    for (int i = 0; i < NEQ; ++i) {
+                        const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
+                        row[i] = __builtin_fma(h, poly, y[i]);
+                    }
                 }
-            }
-            const lds_double_ptr slot = ring + (next_q & (R - 1)) * (NEQ * WAVE);
+                const lds_double_ptr slot = ring + (next_q & (R - 1)) * (NEQ * WAVE);
 #pragma unroll
-            for (int c = 0; c < NEQ; ++c) slot[c * WAVE] = row[c];
-            ++next_q;
-            tq_next = tq_after;
-            want = owes_zeros || (pending && tq_next <= t1) || tq_next <= t;
-            progress = true;
-        }
+                for (int c = 0; c < NEQ; ++c) slot[c * WAVE] = row[c];
+                ++next_q;
+                tq_next = tq_after;
+                want = (ZEROS && owes_zeros) || (pending && tq_next <= t1) || (ZEROS && tq_next <= t);
+                progress = true;
+            }
+        };
+        if (__builtin_amdgcn_ballot_w64(owes_zeros || tq_next <= t) == 0ull) produce_rows(std::false_type{});
+        else produce_rows(std::true_type{});
         if (pending && !(tq_next <= t1)) {
             // the step's last row is out: commit it (the only place a step is committed)
 #pragma unroll
@@ -273,7 +281,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             double v[NEQ];
 #pragma unroll
             for (int c = 0; c < NEQ; ++c) v[c] = slot[c * WAVE];
-            if (has_row && q_flush >= my_start_q) {
+            if (has_row && (!RESUMABLE || q_flush >= my_start_q)) {  // (a first launch owns every row of its window)
                 double* o = row0 + (size_t)(q_flush - qb) * Q_STRIDE;
 #pragma unroll
                 for (int c = 0; c < NEQ; ++c) o[c * WAVE] = v[c];
