@@ -127,7 +127,15 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     // ring is full, or the launch's query window ends inside it).  While a lane waits its registers
     // are not written (it is masked off in the attempt code), so the step lives where the attempt
     // left it: y (old state), yt (new state), k0, k6 (the next k0), Q1..Q3 (rk45_step_dense.cuh:222-231).
-    bool pending = false;
+    // The lane's state, one integer in a VGPR (tested where it is needed; four booleans carried through the
+    // loop's divergent control flow cost three scalar instructions at every join):
+    //   LIVE    integrating;
+    //   PENDING holding an accepted step (see above);
+    //   STUCK   paused at t_stop: it continues in the next launch, which also owes its remaining rows;
+    //   ZEROS   stopped for good (tf reached, flagged, capped, or finished in an earlier launch): its rows
+    //           from next_q on are 0.
+    constexpr int M_LIVE = 0, M_PENDING = 1, M_STUCK = 2, M_ZEROS = 3;
+    int mode = live ? M_LIVE : M_ZEROS;
     double t1 = t, h_next = h;
     const double t_end = RESUMABLE ? fmin(tf, A.t_stop) : tf;
 
@@ -143,15 +151,15 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     // next attempt's arithmetic instead.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
     while (wave_on) {
-        bool progress = false;
+        int progress = 0;
         // ---- (A) one attempt ------------------------------------------------------------------
-        const bool can_step = live && !pending && t < t_end && n_attempt < A.cap;
-        if (live && !pending && !can_step) {
-            live = false;
+        const bool can_step = mode == M_LIVE && t < t_end && n_attempt < A.cap;
+        if (mode == M_LIVE && !can_step) {
             if (t < t_end) status = HLM_SYS_CAPPED;  // attempt cap (the build's guard, see hlm_hip.h)
+            mode = (status == HLM_SYS_OK && t < tf) ? M_STUCK : M_ZEROS;  // (paused at t_stop : tf reached or capped)
         }
         if (can_step) {
-            progress = true;
+            progress = 1;
             if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
             ++n_attempt;  // (the forcing samples held for this t were fetched before the loop or in (B'))
             double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ];
@@ -174,7 +182,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                     h *= f;
                     if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) {
                         status = HLM_SYS_STIFF;
-                        live = false;
+                        mode = M_ZEROS;
                     }
                     accepted = false;
                 }
@@ -183,7 +191,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 // committed in (B), after the step's last row
                 t1 = t + h;
                 h_next = FIXED ? A.fixed_step : h * fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
-                pending = true;
+                mode = M_PENDING;
                 if (tq_next <= t1) {
                     // Q_m = sum_j P[j][m] k_j once per step; Q_0 = k0 (rk45_step_dense.cuh:222-231)
 #pragma unroll
@@ -195,9 +203,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 }
             }
         }
-        // stopped for good (tf reached, flagged, capped -- not: paused at t_stop): rows from next_q on are 0
-        const bool stuck = !live && !pending && status == HLM_SYS_OK && t < tf;
-        const bool owes_zeros = !live && !pending && !stuck;
+        const bool owes_zeros = mode == M_ZEROS;
 
         // ---- (B) rows -------------------------------------------------------------------------
         // slide the query-time window (the lanes' cursors are within R rows of the flush cursor)
@@ -213,6 +219,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         // reference (rk45_kernel.cu:141: "if (tq > t)") and stays 0 -- as does every row of a lane that
         // has stopped for good, which it puts into the ring like any other (the flush then never has to
         // tell a produced row from an owed zero).
+        bool pending = mode == M_PENDING;
         bool want = owes_zeros || (pending && tq_next <= t1) || tq_next <= t;
         [[maybe_unused]] const double inv_h = MATH == MATH_FAST ? fast_rcp(h) : 0.0;
         // one row per trip; ZEROS = false is the variant for a wave none of whose lanes produces a zero row
@@ -239,7 +246,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 ++next_q;
                 tq_next = tq_after;
                 want = (ZEROS && owes_zeros) || (pending && tq_next <= t1) || (ZEROS && tq_next <= t);
-                progress = true;
+                progress = 1;
             }
         };
         if (__builtin_amdgcn_ballot_w64(owes_zeros || tq_next <= t) == 0ull) produce_rows(std::false_type{});
@@ -251,8 +258,8 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             t = t1;
             h = h_next;
             ++n_accept;
-            pending = false;
-            progress = true;
+            mode = M_LIVE;
+            progress = 1;
         }
 
         // ---- (B') the forcing samples of the next attempt ----------------------------------------
@@ -260,7 +267,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         // only covers the stores of the previous flush, which have had a whole iteration to drain
         // (one vmcnt for loads and stores, see above).  t only changes in the commit above, so this is
         // the refresh the next attempt would do (rk45_kernel.cu:62-75), same samples, same k0 handling.
-        if (live && !pending && t < t_end) {
+        if (mode == M_LIVE && t < t_end) {
             if (held.refresh(A, P, t, FV)) have_k0 = false;
         }
 
@@ -268,7 +275,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         // (Reading all ready rows from the ring before the first store -- one LDS latency per batch --
         // was measured: no gain, 40 more live registers, spills.)
         bool flushed = false;
-        const unsigned long long paused = __builtin_amdgcn_ballot_w64(stuck);  // they produce nothing more in this launch
+        const unsigned long long paused = __builtin_amdgcn_ballot_w64(mode == M_STUCK);  // they produce nothing more in this launch
         while (q_flush < q_hi) {
             const bool has_row = next_q > q_flush;
             const unsigned long long have = __builtin_amdgcn_ballot_w64(has_row);
@@ -289,16 +296,16 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             ++q_flush;
             flushed = true;
         }
-        wave_on = flushed || __builtin_amdgcn_ballot_w64(progress) != 0ull;
+        wave_on = flushed || __builtin_amdgcn_ballot_w64(progress != 0) != 0ull;
     }
 
-    if (pending) {
+    if (mode == M_PENDING) {
         // the launch's query window ends inside this step: it is given back -- (y, t, h) are still the
         // step's start and the attempt is redone in the next launch, which then produces the rest of its rows
         --n_attempt;
         status = SYS_PAUSED;
     }
-    if (RESUMABLE && !live && status == HLM_SYS_OK && t < tf) status = SYS_PAUSED;  // stopped at t_stop
+    if (RESUMABLE && mode == M_STUCK) status = SYS_PAUSED;  // stopped at t_stop
     if (resume_i) {
         // a lane that has stopped for good has (zero-)written every row the wave flushed
         resume_i[(size_t)3 * A.ns + sys] = (status != SYS_PAUSED && q_flush > next_q) ? q_flush : next_q;
