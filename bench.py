@@ -103,6 +103,10 @@ def parse():
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
                     help="gloo only to rehearse N > 1 ranks on a one-GPU box (ranks share the card)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--init-timeout", type=float, default=180.0,
+                    help="seconds a rank waits in init_process_group / a collective before it gives up (non-zero exit)")
+    ap.add_argument("--launch-timeout", type=float, default=1500.0,
+                    help="self-launch only: seconds after which the launcher kills its ranks' process group and exits 124")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     return ap.parse_args()
 
@@ -159,20 +163,23 @@ def gather_results(eng, total, world):
     every rank's shard arrive on rank 0 in ONE collective -- the engine keeps them in a single
     52-byte-per-hillslope allocation.  Shards differ by at most one hillslope (strong scaling
     with a remainder): the blobs are then padded to the longest one."""
-    return gather_blobs(eng.result_blob, total)  # list of per-rank blobs on rank 0
+    # (a one-rank process group -- bench.py under a one-rank torchrun -- runs the collective for real too)
+    return gather_blobs(eng.result_blob, total, single_rank_collective=True)  # list of per-rank blobs on rank 0
 
 
 def timed_passes(eng, total, world, warmup, steps):
     """W untimed passes, then EXACTLY K timed ones between barrier + synchronize on both sides.
     Returns (wall seconds: max over ranks, kernel ms per pass, gather ms per pass) of this rank;
-    the per-pass times are HIP events on the stream the kernel is launched on."""
+    the per-pass times are HIP events on the stream the kernel is launched on.  The end-of-run
+    gather is part of every pass whenever a process group exists (under torchrun, any world size)."""
     dev = eng.device
+    grouped = dist.is_initialized()
     for _ in range(warmup):
         eng.integrate()
-        if world > 1:
+        if grouped:
             gather_results(eng, total, world)
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize(dev)
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(steps)]
@@ -181,17 +188,17 @@ def timed_passes(eng, total, world, warmup, steps):
         ev[i][0].record()
         eng.integrate()
         ev[i][1].record()
-        if world > 1:
+        if grouped:
             gather_results(eng, total, world)
         ev[i][2].record()
     torch.cuda.synchronize(dev)
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize(dev)
     wall = time.perf_counter() - t0
     kernel_ms = [e[0].elapsed_time(e[1]) for e in ev]
-    gather_ms = [e[1].elapsed_time(e[2]) for e in ev] if world > 1 else [0.0] * steps
-    if world > 1:
+    gather_ms = [e[1].elapsed_time(e[2]) for e in ev] if grouped else [0.0] * steps
+    if grouped:
         w = torch.tensor([wall], dtype=torch.float64, device=_coll_device(dev))
         dist.all_reduce(w, op=dist.ReduceOp.MAX)
         wall = float(w.item())
@@ -263,8 +270,8 @@ def dense_section(args):
             "roofline": {"bound": "hbm", "achieved": ab / (k * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": ab / (k * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": ab,
                          "kernel": "hlm::rk45_dense_ring_kernel<Model204Dev>",
-                         "measured_fill_GBps": 4800.0,
-                         "note": "write-only traffic; a pure fill of the same bytes reaches 4.8 TB/s on MI355X (tools/hbm_write_probe.py)"}}
+                         "note": "write-only traffic; NOT measured in this run: a pure fill of the same bytes reached 4.8 TB/s "
+                                 "on an MI355X of this pool (tools/hbm_write_probe.py, profiles/r02_hbm_write_probe.txt)"}}
         del e2
         torch.cuda.empty_cache()
     return out
@@ -326,6 +333,22 @@ def cpu_baseline(args):
                       f"{steps} attempted steps in {t_used:.1f} s (oracle/hlm_oracle.c, gcc -O2 -fopenmp)"}
 
 
+def _optional(section, *a):
+    """The sections after the headline are optional: one that fails (out of memory on a smaller or shared card,
+    a missing compiler for the CPU oracle ...) is recorded as {"error": ...} and the line is printed all the
+    same -- the headline figure measured before it is never lost."""
+    try:
+        return section(*a)
+    except Exception as e:  # noqa: BLE001 -- whatever it was, it belongs in the line, not in a lost run
+        import traceback
+        traceback.print_exc(file=sys.stderr)
+        try:
+            torch.cuda.empty_cache()
+        except Exception:
+            pass
+        return {"error": "%s: %s" % (type(e).__name__, str(e)[:400])}
+
+
 def self_launch(args):
     """``python bench.py --gpus N`` outside torchrun: start the N ranks as a FRESH child process
     tree (never a re-exec of this one; this process has imported neither torch nor the HIP
@@ -341,7 +364,36 @@ def self_launch(args):
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     env = dict(os.environ)
     env.setdefault("OMP_NUM_THREADS", "1")  # what torchrun would set (with a warning) for every rank
-    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)  # ranks' stderr passes through
+    # own session = own process group: on a timeout exactly the ranks started here are killed, nothing else
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True, start_new_session=True)  # ranks' stderr passes through
+    try:
+        stdout, _ = child.communicate(timeout=args.launch_timeout if args.launch_timeout > 0 else None)
+    except subprocess.TimeoutExpired:
+        # torchrun puts every rank into a session of its own: end exactly the processes descended from the
+        # child started here (by PID), then the child
+        import signal
+        victims = []
+        try:
+            import psutil
+            victims = psutil.Process(child.pid).children(recursive=True)
+        except Exception:
+            pass
+        for v in victims:
+            try:
+                v.kill()
+            except Exception:
+                pass
+        try:
+            os.killpg(child.pid, signal.SIGKILL)
+        except ProcessLookupError:
+            pass
+        child.communicate()
+        print(f"bench.py: the ranks did not finish within --launch-timeout {args.launch_timeout:g} s: killed", file=sys.stderr)
+        return 124
+
+    class p:  # (what the code below reads)
+        returncode = child.returncode
+    p.stdout = stdout
     line = None
     for ln in p.stdout.splitlines():
         if ln.startswith("{") and '"metric"' in ln:  # rank 0's result line
@@ -367,8 +419,14 @@ def rehearse(args):
     from tiger_hlm_gpu_amd.shard import gather_blobs, result_blob_bytes, shard_bounds
     world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
     if world > 1:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        fail_rank = os.environ.get("HLM_BENCH_TEST_FAIL_INIT_RANK")  # the same hook as in main()
+        if fail_rank is not None and int(fail_rank) == rank:
+            raise SystemExit("bench.py: rank %d fails before init_process_group (HLM_BENCH_TEST_FAIL_INIT_RANK)" % rank)
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=args.init_timeout))
+        if os.environ.get("HLM_BENCH_TEST_HANG_RANK") == str(rank):  # tests: a rank that never comes back
+            time.sleep(3600)
     total = total_hillslopes(args, world)
 
     def blob_of(r):
@@ -399,22 +457,46 @@ def rehearse(args):
     ok = True
     if rank == 0:
         ok = len(g) == world and all(torch.equal(g[r], blob_of(r)[0]) for r in range(world))
-        print(json.dumps({"metric": "rehearsal (launch + shard + gather plumbing only; nothing integrated)",
+        _print_result({"metric": "rehearsal (launch + shard + gather plumbing only; nothing integrated)",
                           "value": None, "unit": "hillslope-ODE-steps/s", "n_gpus": world, "steps": args.steps,
                           "warmup": args.warmup, "scaling": args.scaling, "data": "signature",
                           "hillslopes_total": int(counts.item()), "gather_ok": bool(ok),
                           "shards": [shard_bounds(total, world, r)[1] for r in range(world)],
-                          "wall_s_max_over_ranks": float(wall.item())}))
+                          "wall_s_max_over_ranks": float(wall.item())})
     if world > 1:
         dist.destroy_process_group()
     if not ok:
         sys.exit(3)
 
 
+_RESULT_FD = None
+
+
+def _claim_stdout():
+    """A rank's stdout carries exactly ONE line, the result.  Libraries write there too, below Python (RCCL prints
+    a five-line version banner when its communicator is created, gloo its "[Gloo] Rank ..." lines): from here on
+    file descriptor 1 is the process's stderr, and the result line goes to the descriptor kept aside."""
+    global _RESULT_FD
+    if _RESULT_FD is None:
+        sys.stdout.flush()
+        _RESULT_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def _print_result(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    sys.stdout.flush()
+    if _RESULT_FD is None:
+        os.write(1, line)
+    else:
+        os.write(_RESULT_FD, line)
+
+
 def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
+    _claim_stdout()
     if args.rehearse:
         return rehearse(args)
     _load()
@@ -428,12 +510,22 @@ def main():
                          "(--backend gloo rehearses N ranks on fewer cards)")
     dev_index = local_rank if args.backend == "nccl" else local_rank % max(ndev, 1)
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # A process group exists whenever a launcher started this rank (WORLD_SIZE in the environment) -- also for
+    # ONE rank: ``torchrun --nproc-per-node 1 bench.py --gpus 1`` then creates the RCCL communicator and runs
+    # the end-of-run gather and the all-reduces as real collectives (the first 8-GPU contact is then not the
+    # first time that code executes).  Plain ``python bench.py`` (the driver's N = 1 form) creates none.
+    grouped = "WORLD_SIZE" in os.environ
+    if grouped:
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        fail_rank = os.environ.get("HLM_BENCH_TEST_FAIL_INIT_RANK")  # tests/test_bench_launcher.py: a rank that dies before init
+        if fail_rank is not None and int(fail_rank) == rank:
+            raise SystemExit("bench.py: rank %d fails before init_process_group (HLM_BENCH_TEST_FAIL_INIT_RANK)" % rank)
+        to = datetime.timedelta(seconds=args.init_timeout)
         if args.backend == "nccl":   # RCCL over xGMI: one rank per GPU
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"), timeout=to)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=to)
 
     eng, total = build_engine(args, rank, world, wet=args.wet_surface, tmin=args.tmin)
     if args.radau:
@@ -442,11 +534,11 @@ def main():
     elif args.compact_minutes > 0:
         eng.integrate = lambda: eng.integrate_compacting(args.compact_minutes)
     wall, kernel_ms, gather_ms = timed_passes(eng, total, world, args.warmup, args.steps)
-    cdev = _coll_device(eng.device) if world > 1 else eng.device
+    cdev = _coll_device(eng.device) if grouped else eng.device
     attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=cdev)
     flagged = torch.tensor([float((eng.stiff != 0).sum().item())], dtype=torch.float64, device=cdev)
     per_rank = None
-    if world > 1:
+    if grouped:
         dist.all_reduce(attempts)
         dist.all_reduce(flagged)
         # per-rank view for the line: hillslopes, mean kernel ms, mean gather ms (as seen by that rank)
@@ -510,7 +602,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {"workload": workload, "hillslopes_per_gpu": eng.ns, "hillslopes_total": total,
-                   "parallelism": f"shard{world}", "backend": args.backend if world > 1 else None,
+                   "parallelism": f"shard{world}", "backend": args.backend if grouped else None,
                    "per_gpu_key": _per_gpu_key(args, nq, eng.ns)},
         # The kernel is an FP64 per-lane ODE integrator: its binding roofline is the FP64
         # vector ALU, not HBM and not MFMA (north_star: "no MFMA").  Both are reported:
@@ -528,10 +620,12 @@ def main():
         "attempts_per_pass": attempts_all, "attempts_per_hillslope": attempts_all / total,
         "flagged_fraction": float(flagged.item()) / total, "kernel_ms_each": kernel_ms,
     }
-    if world > 1:
+    if grouped:
+        from tiger_hlm_gpu_amd.shard import gather_collective
         out["per_rank"] = per_rank   # hillslopes, mean kernel ms and mean end-of-run gather ms of every rank
         out["gather_ms_rank0_each"] = gather_ms
         out["gather_bytes_per_pass"] = 52.0 * total
+        out["gather_collective"] = gather_collective()   # decided from the backend's name before any communication
 
     if not args.no_variants and rank == 0 and world == 1:
         # extra single passes of the same shard: wet surface store (the Manning x^(2/3)
@@ -539,41 +633,46 @@ def main():
         del eng
         torch.cuda.empty_cache()
         other = "strict" if args.math == "fast" else "fast"
-        for name, wet, math in (("variant_wet_surface", True, args.math),
-                                ("variant_%s_math" % other, False, other),
-                                ("variant_%s_math_wet_surface" % other, True, other)):
+
+        def _pass_variant(wet, math):
             engv, _ = build_engine(args, rank, world, wet=wet, math=math)
             wallv, kms, _ = timed_passes(engv, total, 1, 1, 1)
             av = engv.total_attempts()
-            out[name] = {"value": av / wallv, "unit": "hillslope-ODE-steps/s", "kernel_ms": kms[0], "math": math,
-                         "attempts_per_hillslope": av / engv.ns,
-                         "flagged_fraction": float((engv.stiff != 0).sum().item()) / engv.ns,
-                         "valu_fp64_frac": av * F_STEP_204 / (kms[0] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS}
+            res = {"value": av / wallv, "unit": "hillslope-ODE-steps/s", "kernel_ms": kms[0], "math": math,
+                   "attempts_per_hillslope": av / engv.ns,
+                   "flagged_fraction": float((engv.stiff != 0).sum().item()) / engv.ns,
+                   "valu_fp64_frac": av * F_STEP_204 / (kms[0] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS}
             del engv
+            return res
+        for name, wet, math in (("variant_wet_surface", True, args.math),
+                                ("variant_%s_math" % other, False, other),
+                                ("variant_%s_math_wet_surface" % other, True, other)):
+            out[name] = _optional(_pass_variant, wet, math)
             torch.cuda.empty_cache()
+
         # BASELINE config 3 as worded ("forcings streamed"): the same pass with the per-stream forcing
         # series (3 GB for 1 M hillslopes x 30 days) left in pinned HOST memory and passed through HBM
         # in 1-day chunks, upload of chunk k+1 overlapped with the integration of chunk k.  PCIe-inclusive.
-        engs, _ = build_engine(args, rank, world, wet=False)
-        engs.forc = None
-        torch.cuda.empty_cache()
-        start, count = shard_bounds(total, world, rank)
-        cells = synth.cell_of_system(start, count)
-        pr, t2m, dt, nT = synth.forcing_tables(days=args.days)
-        tables = (pr, t2m) if args.layout == "per-cell" else (pr[:, cells], t2m[:, cells])
-        tables = [ShardEngine.pin_forcing_table(t) for t in tables]       # pinned once, outside the timed pass
-        col = cells if args.layout == "per-cell" else None
-        engs.integrate_forcing_streamed(tables, dt, 1440.0, cells=col)  # warm-up
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        engs.integrate_forcing_streamed(tables, dt, 1440.0, cells=col)
-        torch.cuda.synchronize()
-        ws = time.perf_counter() - t0
-        out["variant_forcings_streamed"] = {
-            "value": engs.total_attempts() / ws, "unit": "hillslope-ODE-steps/s", "wall_ms": ws * 1e3,
-            "chunk_minutes": 1440.0, "host_forcing_bytes": int(sum(t.numel() * 4 for t in tables)),
-            "note": "PCIe-inclusive: every chunk is uploaded from pinned host memory during the pass"}
-        del engs
+        def _forcings_streamed():
+            engs, _ = build_engine(args, rank, world, wet=False)
+            engs.forc = None
+            torch.cuda.empty_cache()
+            start, count = shard_bounds(total, world, rank)
+            cells = synth.cell_of_system(start, count)
+            pr, t2m, dt, nT = synth.forcing_tables(days=args.days)
+            tables = (pr, t2m) if args.layout == "per-cell" else (pr[:, cells], t2m[:, cells])
+            tables = [ShardEngine.pin_forcing_table(t) for t in tables]       # pinned once, outside the timed pass
+            col = cells if args.layout == "per-cell" else None
+            engs.integrate_forcing_streamed(tables, dt, 1440.0, cells=col)  # warm-up
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            engs.integrate_forcing_streamed(tables, dt, 1440.0, cells=col)
+            torch.cuda.synchronize()
+            ws = time.perf_counter() - t0
+            return {"value": engs.total_attempts() / ws, "unit": "hillslope-ODE-steps/s", "wall_ms": ws * 1e3,
+                    "chunk_minutes": 1440.0, "host_forcing_bytes": int(sum(t.numel() * 4 for t in tables)),
+                    "note": "PCIe-inclusive: every chunk is uploaded from pinned host memory during the pass"}
+        out["variant_forcings_streamed"] = _optional(_forcings_streamed)
         torch.cuda.empty_cache()
 
         # SURVEY 8d's C3 generator as written: daily temperatures U[-5, 15].  Below 0 C the reference's linear
@@ -608,24 +707,25 @@ def main():
                                       "steps_per_s": res["rk45"]["attempts"] / (a.elapsed_time(b) * 1e-3)}
             res["rk45_plus_radau"]["implicit_attempts"] = res["rk45_plus_radau"]["attempts"] - res["rk45"]["attempts"]
             res["rk45_plus_radau"]["unsolved_after"] = int((e.stiff == 2).sum().item())
-            res["lane_utilisation_rk45"] = ("40.6 of 64 lanes active per VALU instruction (rocprofv3 SQ_THREAD_CYCLES_VALU / "
-                                            "SQ_ACTIVE_INST_VALU, profiles/r02_cold_pmc.json); lane refill measured: slower, see DESIGN.md")
+            res["lane_utilisation_rk45_source"] = ("not measured in this run: 40.6 of 64 lanes active per VALU instruction in "
+                                                   "profiles/r02_cold_pmc.json (rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, round 2)")
             return res
-        out["variant_survey_c3_cold_cells"] = _cold()
+        out["variant_survey_c3_cold_cells"] = _optional(_cold)
         torch.cuda.empty_cache()
 
     if rank == 0 and world == 1 and not args.no_dense:
-        out["dense_output"] = dense_section(args)
+        out["dense_output"] = _optional(dense_section, args)
     if rank == 0 and world == 1 and not args.no_variants:
-        out["c2_dummy"] = c2_dummy_section(args)
+        out["c2_dummy"] = _optional(c2_dummy_section, args)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args)
-        out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
+        out["cpu_baseline"] = _optional(cpu_baseline, args)
+        if "value" in out["cpu_baseline"]:
+            out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
 
     if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
+        _print_result(out)
+    if grouped:
         dist.destroy_process_group()
 
 

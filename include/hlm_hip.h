@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HLM_ABI_VERSION 2
+#define HLM_ABI_VERSION 3
 #define HLM_NEQ 5           /* Model204::N_EQ, models/model_204.hpp:19 (and the DummyModel's) */
 #define HLM_MAX_NEQ 8       /* largest N_EQ a registered model may have (kernels are templates over it) */
 #define HLM_MAX_FORCINGS 16 /* I_O/forcing_data.h:5 */
@@ -107,6 +107,15 @@ int hlm_set_lane_refill(int enabled);
  * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free); 0 (default): flagged systems
  * keep stiff = 1 and zero rows, the reference's observable behaviour. */
 int hlm_set_radau_fallback(int enabled);
+/* Output selection of the host API: the reference's run configuration lists the state variables to write
+ * (data/config.yaml:44-52 "output.states", parsed by I_O/config_loader.cpp:19-84; the writers take the variable
+ * list, I_O/output_series.cpp:18-72).  n > 0: dense rows carry only the n components comps[0..n) (ascending,
+ * distinct, each < the model's N_EQ -- checked when buffers are set up for a model): hlm_setup_gpu_buffers*
+ * sizes d_dense_all for n doubles per row, the kernels store only those components (n/N_EQ of the HBM and PCIe
+ * bytes), hlm_retrieve_and_free / hlm_run_rk45 deliver h_dense [ns][nq][n].  n = 0 (default): all components.
+ * Final states are always complete (they are the next run's initial state).  "output.print_interval" needs no
+ * switch: it is the spacing of the query times the caller passes. */
+int hlm_set_output_states(int n, const int* comps);
 
 /* ---- forcing symbols (I_O/forcing_data.cu:5-10; uploads at main.cpp:559-574) -------
  * d_forc: DEVICE pointer, float [sum_j nT[j]][ld] forcing-major then time then column
@@ -140,6 +149,9 @@ typedef struct hlm_gpu_buffers {
     int dense_layout;      /* an hlm_device_job.dense_tiled value; hlm_setup_gpu_buffers chooses 2: tile-major
                             * [ceil(ns/64)][nq][neq][64] (the reference's device layout is [ns][neq][nq],
                             * rk45_kernel.cu:145, and is likewise re-ordered on the way to the host) */
+    int dense_ncomp;       /* output selection the buffers were sized for (hlm_set_output_states): 0 = all neq
+                            * components, K > 0 = dense rows hold the K components dense_comp[0..K) only */
+    int dense_comp[HLM_MAX_NEQ];
 } hlm_gpu_buffers;
 
 /* setup_gpu_buffers<M>: allocate the device buffers, copy h_y0 ([ns][M::N_EQ]) and h_query_times.
@@ -235,6 +247,12 @@ typedef struct hlm_device_job {
      * flagged early next to hillslopes that run 30 days).  Used for launches without dense output and
      * without resume state; ignored otherwise. */
     int lane_refill;
+    /* Output selection (ABI 3; see hlm_set_output_states): dense_ncomp = K > 0 makes every dense row K doubles
+     * wide, holding components dense_comp[0..K) (ascending, distinct, < N_EQ) -- d_dense is [ns][W][K],
+     * [tiles][W][64][K] or [tiles][W][K][64] by dense_tiled; hlm_rk45_integrate_streamed then fills
+     * h_dense [ns][nq][K].  0 = all N_EQ components. */
+    int dense_ncomp;
+    int dense_comp[HLM_MAX_NEQ];
 } hlm_device_job;
 
 size_t hlm_resume_bytes_model(int uid, int num_systems); /* (N_EQ + 2) doubles + 5 int32 per system */

@@ -1,3 +1,4 @@
+import json
 import os
 import sys
 
@@ -128,17 +129,141 @@ def parity_or_shown_ill_conditioned(got, ref, alts, names=("y_final", "dense"), 
     return within, (~within) & shown, dev, spread
 
 
-def assert_parity_with_exemptions(got, ref, alts, max_exempt, names=("y_final", "dense"), what="", got_alts=()):
+# ---- second tier of the yardstick ----------------------------------------------------------------------
+# The eight fixed perturbations are eight SAMPLES of how far a hillslope's result moves under changes far below
+# the solver tolerance.  On a hillslope that sits on a discrete event the moved distance is heavy-tailed: fuzz
+# seed 1015 / hillslope 914 (round 2's one "unexplained" case: GPU 1.11 x the bound, fixed-sample spread 0.43) is
+# the snow store (component 0, value ~ the rain rate 1e-4, bound 1.1e-9) three minutes after the hourly forcing
+# sample boundary at t = 180 min: a step that straddles the boundary charges the overlap at the old rain rate
+# (rk45_kernel.cu:85-116 samples the forcing at the step START), so the value depends on where the step
+# sequence happens to put that step; of 48 random perturbations of rtol / h0 with |e| <= 1e-10 -- the same range
+# as the fixed eight -- 23 move the ORACLE's own rows by >= 0.5 and 9 by >= 1.11 of the bound there.  So a
+# hillslope the first tier leaves unexplained gets more samples of the same kind, on that hillslope alone
+# (the oracle integrates hillslopes independently), before it is called a failure.
+EXTENDED_YARDSTICK_SAMPLES = 48
+
+
+def _subset_case(idx, y0, kw):
+    """The oracle inputs restricted to the hillslopes ``idx`` (per-stream forcing block: columns)."""
+    y0 = np.asarray(y0)
+    ns = y0.shape[0]
+    sub = dict(kw)
+    if sub.get("sp") is not None:
+        sub["sp"] = np.ascontiguousarray(np.asarray(sub["sp"])[idx])
+    if sub.get("forc") is not None:
+        f = np.asarray(sub["forc"], dtype=np.float32).reshape(-1, ns)
+        sub["forc"] = np.ascontiguousarray(f[:, idx])
+    return np.ascontiguousarray(y0[idx]), sub
+
+
+def extended_yardstick(oracle, uid, y0, t0, tf, idx, names=("y_final", "dense"), params=DEFAULT_PARAMS,
+                       n=EXTENDED_YARDSTICK_SAMPLES, seed=914, **kw):
+    """(spread, flips) of the hillslopes ``idx`` under ``n`` random perturbations of rtol and the first step,
+    relative size 1e-12 .. 1e-10 (a third rtol only, a third h0 only, a third both), against the unperturbed
+    oracle run of the same hillslopes.  Deterministic (seeded)."""
+    idx = np.asarray(idx, dtype=np.int64)
+    y0s, sub = _subset_case(idx, y0, kw)
+    base = oracle.run(uid, y0s, t0, tf, params=params, **sub)
+    rng = np.random.default_rng(seed)
+    spread = np.zeros(len(idx))
+    flips = np.zeros(len(idx), dtype=bool)
+    for k in range(n):
+        er = rng.uniform(-1, 1) * 10.0 ** rng.uniform(-12, -10)
+        eh = rng.uniform(-1, 1) * 10.0 ** rng.uniform(-12, -10)
+        if k % 3 == 0:
+            eh = 0.0
+        if k % 3 == 1:
+            er = 0.0
+        a = oracle.run(uid, y0s, t0, tf, params=perturbed_params(params, er, eh), **sub)
+        spread = np.maximum(spread, scaled_deviation(a, base, names))
+        flips |= a["stiff"] != base["stiff"]
+    return spread, flips
+
+
+# An exemption is not a blank cheque: a hillslope shown ill-conditioned by a moved VALUE (not by a flipped flag,
+# after which one side holds zero rows) must still be near the oracle on the scale of what the yardstick moved --
+# a wrong row or a wrong layout index is off by ~1e6 bounds and is never excused (round-2 advisor finding).
+EXEMPT_DEV_OVER_SPREAD = 10.0   # observed on MI355X over every exempt hillslope of the suite: <= 4
+
+
+def _zero_row_pattern_differs(a, b):
+    """Per hillslope: does ``a`` hold an all-zero dense row where ``b`` holds values, or the other way round?
+    (A flagged hillslope's rows from its flag time on are zero, rk45_kernel.cu:167-170: two runs that flag the
+    same hillslope at DIFFERENT times have equal flags and rows that differ by the whole state.)"""
+    if a.get("dense") is None or b.get("dense") is None:
+        return np.zeros(a["stiff"].shape[0], dtype=bool)
+    za, zb = np.all(a["dense"] == 0.0, axis=2), np.all(b["dense"] == 0.0, axis=2)
+    return np.any(za != zb, axis=1)
+
+
+def assert_parity_with_exemptions(got, ref, alts, max_exempt, names=("y_final", "dense"), what="", got_alts=(),
+                                  extended=None, max_exempt_extended=0):
+    """Every hillslope within the bound with the oracle's flag, or individually shown ill-conditioned; at most
+    ``max_exempt`` of the latter (committed per test).  ``extended`` = dict(oracle=, uid=, y0=, t0=, tf=, kw=) runs
+    the second tier (extended_yardstick) on the hillslopes the first tier leaves unexplained; at most
+    ``max_exempt_extended`` may need it.  Returns (first-tier exemptions, worst deviation among the rest)."""
     within, exempt, dev, spread = parity_or_shown_ill_conditioned(got, ref, alts, names, got_alts)
+    flips = np.any([a["stiff"] != ref["stiff"] for a in alts], axis=0) | (got["stiff"] != ref["stiff"])
+    for g in got_alts:
+        flips |= g["stiff"] != got["stiff"]
+    # the flag came at another time: counts as a flipped event where the yardstick moves the flag time too
+    moved_flag_time = np.zeros_like(flips)
+    if "dense" in names:
+        shown_time = np.any([_zero_row_pattern_differs(a, ref) for a in alts], axis=0)
+        for g in got_alts:
+            shown_time |= _zero_row_pattern_differs(g, got)
+        moved_flag_time = _zero_row_pattern_differs(got, ref) & shown_time
+    flips |= moved_flag_time
     bad = ~(within | exempt)
+    n_ext = 0
+    if bad.any() and extended is not None:
+        idx = np.flatnonzero(bad)
+        s2, f2 = extended_yardstick(extended["oracle"], extended["uid"], extended["y0"], extended["t0"], extended["tf"],
+                                    idx, names=names, **extended.get("kw", {}))
+        shown2 = f2 | (s2 >= 0.5) | (s2 >= dev[idx])
+        spread = spread.copy()
+        spread[idx] = np.maximum(spread[idx], s2)
+        flips[idx] |= f2
+        exempt = exempt.copy()
+        exempt[idx[shown2]] = True
+        n_ext = int(shown2.sum())
+        bad = ~(within | exempt)
     if os.environ.get("HLM_PARITY_DIAG"):  # development aid: per-hillslope numbers of every call
         os.makedirs(os.environ["HLM_PARITY_DIAG"], exist_ok=True)
         tag = "".join(c if c.isalnum() else "_" for c in what)[:60]
         np.savez(os.path.join(os.environ["HLM_PARITY_DIAG"], f"parity_{tag}.npz"), within=within, exempt=exempt, dev=dev,
-                 spread=spread, stiff_got=got["stiff"], stiff_ref=ref["stiff"], stiff_alts=np.array([a["stiff"] for a in alts]))
+                 spread=spread, flips=flips, stiff_got=got["stiff"], stiff_ref=ref["stiff"], stiff_alts=np.array([a["stiff"] for a in alts]))
     detail = [(int(i), float(dev[i]), float(spread[i]), int(got["stiff"][i]), int(ref["stiff"][i])) for i in np.flatnonzero(bad)[:10]]
     assert not bad.any(), (f"{what}: {bad.sum()} hillslopes outside the parity bound and NOT shown ill-conditioned "
                            f"(index, dev, yardstick spread, flag got/ref): {detail}")
-    n = int(exempt.sum())
+    far = exempt & ~flips & (dev > EXEMPT_DEV_OVER_SPREAD * np.maximum(spread, 0.5))
+    assert not far.any(), (f"{what}: exempt hillslopes whose deviation is out of proportion to what the yardstick moved "
+                           f"(index, dev, spread): {[(int(i), float(dev[i]), float(spread[i])) for i in np.flatnonzero(far)[:10]]}")
+    n = int(exempt.sum()) - n_ext
     assert n <= max_exempt, f"{what}: {n} hillslopes needed the ill-conditioning exemption (committed: {max_exempt})"
+    assert n_ext <= max_exempt_extended, (f"{what}: {n_ext} hillslopes needed the second yardstick tier "
+                                          f"(committed: {max_exempt_extended})")
+    _check_committed_exempt_set(what, exempt)
     return n, float(dev[within].max()) if within.any() else 0.0
+
+
+# The exempt hillslopes of every test are pinned BY INDEX (tests/golden/parity_exempt_sets.json, written by a run
+# with HLM_PARITY_RECORD=<file> on the GPU box): a later build may need fewer exemptions, never different ones.
+_EXEMPT_SETS = None
+
+
+def _check_committed_exempt_set(what, exempt):
+    global _EXEMPT_SETS
+    idx = [int(i) for i in np.flatnonzero(exempt)]
+    rec = os.environ.get("HLM_PARITY_RECORD")
+    if rec:
+        cur = json.load(open(rec)) if os.path.exists(rec) else {}
+        cur[what] = idx
+        json.dump(cur, open(rec, "w"), indent=0, sort_keys=True)
+        return
+    if _EXEMPT_SETS is None:
+        path = os.path.join(ROOT, "tests", "golden", "parity_exempt_sets.json")
+        _EXEMPT_SETS = json.load(open(path)) if os.path.exists(path) else {}
+    if what in _EXEMPT_SETS:
+        extra = sorted(set(idx) - set(_EXEMPT_SETS[what]))
+        assert not extra, f"{what}: exempt hillslopes outside the committed index set: {extra[:20]}"

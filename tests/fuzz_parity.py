@@ -23,14 +23,16 @@ import tiger_hlm_gpu_amd as H  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 from tiger_hlm_gpu_amd import synth  # noqa: E402
 from tiger_hlm_gpu_amd.engine import ShardEngine  # noqa: E402
-from conftest import (DEFAULT_PARAMS, YARDSTICK_PERTURBATIONS, parity_or_shown_ill_conditioned,  # noqa: E402
+from conftest import (DEFAULT_PARAMS, YARDSTICK_PERTURBATIONS, extended_yardstick, parity_or_shown_ill_conditioned,  # noqa: E402
                       perturbed_params, yardstick_runs)
 
 
 RADAU = False  # argv[4] == "radau": cold cells (negative ET stub flags hillslopes) + the Radau-IIA pass on both sides
 
 
-def one(seed, ns, days):
+def make_case(seed, ns, days, radau=False):
+    """The inputs of one fuzz seed (pure function of its arguments; also used by
+    tests/test_fuzz_gpu.py and tests/fuzz_diag_one.py)."""
     rng = np.random.default_rng(seed)
     sp = synth.model204_params(0, ns, seed=seed)
     sp["Hu"] = 10.0 ** rng.uniform(np.log10(3.05), 2.4, ns) * rng.choice([1.0, 1.0, 0.02], ns)  # some saturate quickly
@@ -49,11 +51,31 @@ def one(seed, ns, days):
     run_len = int(rng.choice([1, 7, 64, 512]))
     cells = synth.cell_of_system(0, ns, ncell=64, run_len=run_len)
     pr, t2m, dt, nT = synth.forcing_tables(days=days, ncell=64, seed=seed, wet_prob=float(rng.uniform(0.05, 0.5)),
-                                           intensity=float(10.0 ** rng.uniform(-4.5, -3.0)), tmin=-5.0 if RADAU else 0.5, tmax=20.0)
+                                           intensity=float(10.0 ** rng.uniform(-4.5, -3.0)), tmin=-5.0 if radau else 0.5, tmax=20.0)
     q = synth.minute_queries(0.0, days * 1440.0, float(rng.choice([17.0, 60.0, 240.0])))
     per_cell = bool(rng.random() < 0.5)
     block = synth.expand_per_stream(pr, t2m, cells)
-    kw = dict(query=q, sp=sp, forc=block, forc_dt_h=dt, forc_nT=nT, attempt_cap=2_000_000, radau=RADAU)
+    return dict(sp=sp, y0=y0, cells=cells, pr=pr, t2m=t2m, dt=dt, nT=nT, q=q, per_cell=per_cell, run_len=run_len,
+                block=block, tf=days * 1440.0)
+
+
+def gpu_run(case, math_mode, params=DEFAULT_PARAMS, radau=False, query=None):
+    """One GPU integration of a fuzz case through the engine (the C ABI underneath)."""
+    q = case["q"] if query is None else query
+    eng = ShardEngine(H.Model204, case["y0"], 0.0, case["tf"], sp=case["sp"], query=q, math_mode=math_mode,
+                      attempt_cap=2_000_000, params=H.Parameters(*params))
+    if case["per_cell"]:
+        eng.set_forcings_per_cell((case["pr"], case["t2m"]), case["cells"], case["dt"], case["nT"])
+    else:
+        eng.expand_forcings_on_device((case["pr"], case["t2m"]), case["cells"], case["dt"], case["nT"])
+    eng.integrate(radau=radau)
+    return eng.results()
+
+
+def one(seed, ns, days):
+    c = make_case(seed, ns, days, RADAU)
+    sp, y0, q, per_cell, run_len = c["sp"], c["y0"], c["q"], c["per_cell"], c["run_len"]
+    kw = dict(query=q, sp=sp, forc=c["block"], forc_dt_h=c["dt"], forc_nT=c["nT"], attempt_cap=2_000_000, radau=RADAU)
     ref = O.run(O.UID_204, y0, 0.0, days * 1440.0, **kw)
     # the yardstick of tests/conftest.py: the oracle's FMA build + the oracle with rtol / h0 changed by a
     # relative 1e-12 .. 1e-10, and (below) the GPU itself under the first four of those perturbations
@@ -61,22 +83,26 @@ def one(seed, ns, days):
     problems = []
     for mm in (0, 1):
         def gpu(params):
-            eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, math_mode=mm, attempt_cap=2_000_000, params=H.Parameters(*params))
-            if per_cell:
-                eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
-            else:
-                eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
-            eng.integrate(radau=RADAU)
-            return eng.results()
+            return gpu_run(c, mm, params, RADAU)
         got = gpu(DEFAULT_PARAMS)
         got_alts = [gpu(perturbed_params(DEFAULT_PARAMS, er, eh)) for er, eh in YARDSTICK_PERTURBATIONS[:4]]
         within, exempt, dev, spread = parity_or_shown_ill_conditioned(got, ref, alts, got_alts=got_alts)
         bad = ~(within | exempt)
+        second_tier = 0
+        if bad.any() and not RADAU:  # more samples of the same perturbation range, on those hillslopes alone
+            idx = np.flatnonzero(bad)
+            s2, f2 = extended_yardstick(O, O.UID_204, y0, 0.0, days * 1440.0, idx, **{k: v for k, v in kw.items() if k != "radau"})
+            shown = f2 | (s2 >= 0.5) | (s2 >= dev[idx])
+            spread[idx] = np.maximum(spread[idx], s2)
+            exempt[idx[shown]] = True
+            second_tier = int(shown.sum())
+            bad = ~(within | exempt)
         same = got["stiff"] == ref["stiff"]
         dn = np.abs(got["n_attempt"][same].astype(np.int64) - ref["n_attempt"][same].astype(np.int64))
         info = dict(seed=seed, math=mm, per_cell=per_cell, run_len=run_len, flagged=int((ref["stiff"] != 0).sum()),
                     wet_end=int((ref["y_final"][:, 2] != 0).sum()), flag_mismatch=int((~same).sum()),
                     worst_within=round(float(dev[within].max()), 4) if within.any() else 0.0, exempt=int(exempt.sum()),
+                    second_tier=second_tier,
                     unexplained=int(bad.sum()), unexplained_detail=[(int(i), round(float(dev[i]), 2), round(float(spread[i]), 3))
                                                                      for i in np.flatnonzero(bad)[:6]],
                     max_dn=int(dn.max()) if dn.size else 0, finite=bool(np.isfinite(got["y_final"]).all()))

@@ -49,9 +49,9 @@ def test_torchrun_form():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT,
                        env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert p.returncode == 0, p.stderr[-2000:]
-    # (gloo's C++ layer prints its own "[Gloo] Rank ..." lines on stdout here; RCCL does not)
-    js = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
-    assert len(js) == 1 and json.loads(js[0])["shards"] == [1000, 1000]
+    # exactly one line on stdout: what gloo's C++ layer ("[Gloo] Rank ...") and RCCL (its version banner) print
+    # below Python goes to the ranks' stderr (bench._claim_stdout)
+    assert _one_json_line(p.stdout)["shards"] == [1000, 1000]
 
 
 def test_failing_ranks_give_a_nonzero_exit_and_no_line():
@@ -63,3 +63,31 @@ def test_failing_ranks_give_a_nonzero_exit_and_no_line():
                        stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT)
     assert p.returncode != 0
     assert p.stdout.strip() == ""
+
+
+def test_a_rank_that_dies_before_init_ends_the_launch_with_a_nonzero_exit():
+    """Rank 1 exits before init_process_group while rank 0 is already waiting in it: the launcher must come
+    back non-zero in bounded time (torchrun ends the surviving rank; failing that, the rank's own
+    --init-timeout and the launcher's --launch-timeout do), and print no result line."""
+    import time
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH, "--rehearse", "--backend", "gloo", "--gpus", "2", "--ns-per-gpu", "512",
+                        "--steps", "1", "--warmup", "0", "--init-timeout", "20", "--launch-timeout", "120"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT,
+                       env=dict(os.environ, HLM_BENCH_TEST_FAIL_INIT_RANK="1"))
+    assert p.returncode != 0
+    assert p.stdout.strip() == "", p.stdout
+    assert "HLM_BENCH_TEST_FAIL_INIT_RANK" in p.stderr
+    assert time.time() - t0 < 150
+
+
+def test_launch_timeout_kills_the_ranks_and_returns_124():
+    """Ranks that never finish (here: both wait in init for a third rendezvous member that does not exist is
+    not constructible with torchrun, so rank 0 simply sleeps) are killed as a process group after --launch-timeout."""
+    p = subprocess.run([sys.executable, BENCH, "--rehearse", "--backend", "gloo", "--gpus", "2", "--ns-per-gpu", "512",
+                        "--steps", "1", "--warmup", "0", "--launch-timeout", "8"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300, cwd=ROOT,
+                       env=dict(os.environ, HLM_BENCH_TEST_HANG_RANK="0"))
+    assert p.returncode == 124, (p.returncode, p.stderr[-1000:])
+    assert p.stdout.strip() == ""
+    assert "--launch-timeout" in p.stderr

@@ -260,14 +260,17 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     typename Model::Forc FV = Model::prep_forcing(P, F);
 
     // dense layouts as in hlm_rk45_dense_kernel.h: 0 / 3 [sys][q][c], 1 [tile][q][lane][c], 2 [tile][q][c][lane]
+    // output selection (hlm_device_job.dense_ncomp): rows of K components, component c at position pos(c) or absent
     const bool tiled = A.dense_tiled == 1 || A.dense_tiled == 2;
-    const size_t q_stride = tiled ? (size_t)WAVE * NEQ : (size_t)NEQ;
+    const int K = A.dense_k > 0 ? A.dense_k : NEQ;
+    auto pos = [&](int c) -> int { return A.dense_k > 0 ? A.dense_pos[c] : c; };  // wave-uniform
+    const size_t q_stride = tiled ? (size_t)WAVE * (size_t)K : (size_t)K;
     const size_t c_stride = A.dense_tiled == 2 ? (size_t)WAVE : (size_t)1;
     double* dense_row = nullptr;
     if (A.nq > 0)
-        dense_row = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * NEQ
+        dense_row = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * (size_t)K
                            : A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride +
-                                 (size_t)(sys % WAVE) * (A.dense_tiled == 2 ? (size_t)1 : (size_t)NEQ);
+                                 (size_t)(sys % WAVE) * (A.dense_tiled == 2 ? (size_t)1 : (size_t)K);
 
     double t = A.t0, h = A.h0;
     const double tf = A.tf;
@@ -276,7 +279,8 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     // queries at or before t0 are never produced: zero rows
     while (next_q < A.nq && A.query[next_q] <= t) {
 #pragma unroll
-        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
+        for (int c = 0; c < NEQ; ++c)
+            if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
         ++next_q;
     }
 
@@ -445,13 +449,15 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 double* o = dense_row + (size_t)next_q * q_stride;
 #pragma unroll
                 for (int c = 0; c < NEQ; ++c) {
+                    const int pc = pos(c);
+                    if (pc < 0) continue;  // component not selected
                     double acc = y[c], thp = th;
 #pragma unroll
                     for (int m = 0; m < 3; ++m) {
                         acc += (PD[0][m] * Z[0][c] + PD[1][m] * Z[1][c] + PD[2][m] * Z[2][c]) * thp;
                         thp *= th;
                     }
-                    o[(size_t)c * c_stride] = acc;
+                    o[(size_t)pc * c_stride] = acc;
                 }
                 ++next_q;
             }
@@ -476,7 +482,8 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = failed ? 0.0 : y[i];
     for (; next_q < A.nq; ++next_q) {  // rows never reached (later than tf, or after the cap): zero
 #pragma unroll
-        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
+        for (int c = 0; c < NEQ; ++c)
+            if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
     }
 }
 

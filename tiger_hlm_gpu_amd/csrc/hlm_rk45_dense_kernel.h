@@ -37,7 +37,12 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 #define HLM_DENSE_RING_ROWS 4
 #endif
 
-template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R>
+// SEL: output selection (hlm_device_job.dense_ncomp; the reference's output.states, data/config.yaml:44-52): a row
+// holds the A.dense_k selected components only, [tile][q][k][lane].  Every lane still evaluates the whole
+// interpolant (the row arithmetic is a tenth of an iteration) and puts component c into ring column
+// A.dense_pos[c] -- an unselected one into the spare last column, so that no register array is indexed at run
+// time; the flush reads and stores columns 0 .. dense_k-1.  SEL = false is the kernel without any of this.
+template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R, bool SEL = false>
 __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
 {
     using namespace dp;
@@ -75,8 +80,13 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     // element (q, c) of this lane = row0[(q - qb) * 64 N_EQ + c * 64].
     const int qb = A.q_begin, qe = A.q_end;
     const int q_hi = A.nq < qe ? A.nq : qe;
-    constexpr size_t Q_STRIDE = (size_t)WAVE * NEQ;
+    [[maybe_unused]] const int K = SEL ? A.dense_k : NEQ;  // components per row
+    const size_t Q_STRIDE = SEL ? (size_t)WAVE * (size_t)A.dense_k : (size_t)WAVE * NEQ;
     double* const row0 = A.dense + (size_t)blk * (size_t)(qe - qb) * Q_STRIDE + (size_t)lane;
+    // ring column of component c (SEL: its position in the row, or the spare last column -- dense_k < N_EQ)
+    [[maybe_unused]] int col[NEQ];
+#pragma unroll
+    for (int c = 0; c < NEQ; ++c) col[c] = SEL ? (A.dense_pos[c] < 0 ? NEQ - 1 : A.dense_pos[c]) * WAVE : c * WAVE;
 
     // live: still integrating in this launch.  Not live = reached tf, flagged, capped, paused at
     // t_stop ("stuck": it continues in the next launch), or finished in an earlier launch.
@@ -242,7 +252,9 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 }
                 const lds_double_ptr slot = ring + (next_q & (R - 1)) * (NEQ * WAVE);
 #pragma unroll
-                for (int c = 0; c < NEQ; ++c) slot[c * WAVE] = row[c];
+                for (int c = 0; c < NEQ; ++c) {
+                    if constexpr (SEL) slot[col[c]] = row[c]; else slot[c * WAVE] = row[c];
+                }
                 ++next_q;
                 tq_next = tq_after;
                 want = (ZEROS && owes_zeros) || (pending && tq_next <= t1) || (ZEROS && tq_next <= t);
@@ -287,11 +299,13 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             const lds_double_ptr slot = ring + (q_flush & (R - 1)) * (NEQ * WAVE);
             double v[NEQ];
 #pragma unroll
-            for (int c = 0; c < NEQ; ++c) v[c] = slot[c * WAVE];
+            for (int c = 0; c < NEQ; ++c)
+                if (!SEL || c < K) v[c] = slot[c * WAVE];
             if (has_row && (!RESUMABLE || q_flush >= my_start_q)) {  // (a first launch owns every row of its window)
                 double* o = row0 + (size_t)(q_flush - qb) * Q_STRIDE;
 #pragma unroll
-                for (int c = 0; c < NEQ; ++c) o[c * WAVE] = v[c];
+                for (int c = 0; c < NEQ; ++c)
+                    if (!SEL || c < K) o[c * WAVE] = v[c];
             }
             ++q_flush;
             flushed = true;

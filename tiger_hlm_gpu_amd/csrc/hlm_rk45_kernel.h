@@ -70,6 +70,10 @@ struct Rk45Args {
     // (hlm_rk45_integrate_compacting).  NULL: the identity.
     const int32_t* index;
     const int32_t* index_count;
+    // Output selection (SEL kernel variants only; hlm_device_job.dense_ncomp): a dense row holds dense_k
+    // components; dense_pos[c] = position of state component c in the row, or -1 when it is not written.
+    int dense_k;
+    int dense_pos[HLM_MAX_NEQ];
 };
 
 // y + sum c_j * k_j accumulated left to right with one FMA per term, the order the
@@ -390,12 +394,16 @@ constexpr int DENSE_QWIN = 256;
 // RESUMABLE: query windows / t_stop / forcing time chunks / checkpoints.  The plain variant
 // (one uninterrupted launch, all forcings resident) carries none of that state: keeping it
 // out of the default kernel is worth 3.5 % (199 -> 192 ms on the C3 pass).
-template <class Model, int MATH, bool DENSE, bool FIXED, bool RESUMABLE>
+// SEL (dense launches only): output selection, hlm_device_job.dense_ncomp -- a dense row holds the A.dense_k
+// components c with A.dense_pos[c] >= 0, at that position (the reference's output.states, data/config.yaml:44-52).
+template <class Model, int MATH, bool DENSE, bool FIXED, bool RESUMABLE, bool SEL = false>
 __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
     rk45_multi_kernel(const Rk45Args A)
 {
     using namespace dp;
+    static_assert(DENSE || !SEL, "output selection concerns the dense rows");
     constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
+    [[maybe_unused]] const int K = SEL ? A.dense_k : NEQ;  // components per dense row
     // XCD-aware block -> hillslope-chunk map: workgroups are dealt round-robin over the
     // 8 XCDs, so give each XCD one contiguous range of hillslopes (neighbouring
     // hillslopes share forcing rows -> they hit in that XCD's L2).  Bijective for any
@@ -460,11 +468,11 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         // contiguous 2560-byte row block per query (full cache lines, no write
         // amplification); dense_tile_to_host() transposes it on its way to host memory.
         if (A.dense_tiled) {
-            q_stride = (size_t)WAVE * NEQ;
-            dense_row = A.dense + ((size_t)(sys / WAVE) * (size_t)(qe - qb) - (size_t)qb) * q_stride + (size_t)(sys % WAVE) * NEQ;
+            q_stride = (size_t)WAVE * (SEL ? K : NEQ);
+            dense_row = A.dense + ((size_t)(sys / WAVE) * (size_t)(qe - qb) - (size_t)qb) * q_stride + (size_t)(sys % WAVE) * (SEL ? K : NEQ);
         } else {
-            q_stride = NEQ;
-            dense_row = A.dense + ((size_t)sys * (size_t)(qe - qb) - (size_t)qb) * NEQ;
+            q_stride = SEL ? K : NEQ;
+            dense_row = A.dense + ((size_t)sys * (size_t)(qe - qb) - (size_t)qb) * (SEL ? K : NEQ);
         }
     }
     // Integrator state carried between launches (query windows, time chunks of streamed
@@ -483,7 +491,8 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
                 if (qb != 0 || qe != A.nq) {
                     for (int q = qb; q < qe; ++q) {
 #pragma unroll
-                        for (int c = 0; c < NEQ; ++c) dense_row[(size_t)q * q_stride + c] = 0.0;
+                        for (int c = 0; c < NEQ; ++c)
+                            if (!SEL || c < K) dense_row[(size_t)q * q_stride + c] = 0.0;
                     }
                 }
             }
@@ -504,7 +513,8 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         while (next_q < A.nq && A.query[next_q] <= t) {
             if (next_q >= qe) { status = SYS_PAUSED; break; }
 #pragma unroll
-            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
+            for (int c = 0; c < NEQ; ++c)
+                if (!SEL || c < K) dense_row[(size_t)next_q * q_stride + c] = 0.0;
             ++next_q;
         }
         tq_next = next_q < A.nq ? A.query[next_q] : __builtin_inf();
@@ -600,8 +610,9 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
                     double* o = dense_row + (size_t)next_q * q_stride;
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) {
+                        if (SEL && A.dense_pos[i] < 0) continue;  // (wave-uniform) component not selected
                         const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
-                        o[i] = __builtin_fma(h, poly, y[i]);  // rk45_step_dense.cuh:235-243
+                        o[SEL ? A.dense_pos[i] : i] = __builtin_fma(h, poly, y[i]);  // rk45_step_dense.cuh:235-243
                     }
                     ++next_q;
                     tq_next = next_q < A.nq ? query_at(next_q) : __builtin_inf();
@@ -654,7 +665,8 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         const int q_stop = A.nq < qe ? A.nq : qe;
         for (; next_q < q_stop; ++next_q) {
 #pragma unroll
-            for (int c = 0; c < NEQ; ++c) dense_row[(size_t)next_q * q_stride + c] = 0.0;
+            for (int c = 0; c < NEQ; ++c)
+                if (!SEL || c < K) dense_row[(size_t)next_q * q_stride + c] = 0.0;
         }
     }
 }

@@ -52,14 +52,39 @@ def result_blob_bytes(count, n_eq=5):
     return int(count) * 8 * n_eq + 3 * c8 * 4
 
 
-def gather_blobs(blob, total, group=None, root=0, n_eq=5):
+# Backends whose process groups implement gather() (torch.distributed: ProcessGroupNCCL -- RCCL on ROCm --
+# as grouped send/recv, ProcessGroupGloo, ProcessGroupMPI).  Anything else (ucc, a custom backend) takes
+# the all_gather route.  HLM_GATHER_COLLECTIVE=gather|all_gather overrides (tests, bring-up of a backend).
+_BACKENDS_WITH_GATHER = ("nccl", "gloo", "mpi")
+
+
+def gather_collective(group=None):
+    """Which collective carries the end-of-run gather on this process group: "gather" or "all_gather".
+    Decided from the backend's NAME (and the override) -- a pure function of things every rank agrees on,
+    evaluated before any communication.  A collective that then fails raises on the rank that saw it:
+    nothing is caught and nothing is retried on another route (a rank that switched collectives alone
+    would leave the others waiting in the first one)."""
+    import os
+    forced = os.environ.get("HLM_GATHER_COLLECTIVE", "")
+    if forced:
+        if forced not in ("gather", "all_gather"):
+            raise ValueError("HLM_GATHER_COLLECTIVE must be 'gather' or 'all_gather', not %r" % forced)
+        return forced
+    return "gather" if str(dist.get_backend(group)).lower() in _BACKENDS_WITH_GATHER else "all_gather"
+
+
+def gather_blobs(blob, total, group=None, root=0, n_eq=5, single_rank_collective=False):
     """The end-of-run gather as ONE collective: every rank's result blob (uint8, 52 B per
     hillslope) to ``root``.  Returns the list of per-rank blobs (each cut to its own length) on
     root, None elsewhere.  Shards of unequal size (``total`` not divisible by the world size) are
-    padded to the longest blob for the collective."""
-    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+    padded to the longest blob for the collective.  The collective is gather_collective(group).
+    A one-rank group returns the blob itself unless ``single_rank_collective`` asks for the real
+    collective (bench.py under a one-rank torchrun: RCCL's communicator and its gather run once)."""
+    if not dist.is_initialized():
         return [blob]
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if world == 1 and not single_rank_collective:
+        return [blob]
     if blob.is_cuda and dist.get_backend(group) == "gloo":
         blob = blob.cpu()
     sizes = [result_blob_bytes(shard_bounds(total, world, r)[1], n_eq) for r in range(world)]
@@ -69,22 +94,13 @@ def gather_blobs(blob, total, group=None, root=0, n_eq=5):
     if blob.numel() != smax:
         pad = torch.zeros(smax, dtype=blob.dtype, device=blob.device)
         pad[: blob.numel()] = blob
-    global _GATHER_VIA_ALL_GATHER
-    if not _GATHER_VIA_ALL_GATHER:
-        try:
-            if rank == root:
-                bufs = [torch.empty_like(pad) for _ in range(world)]
-                dist.gather(pad, gather_list=bufs, dst=root, group=group)
-                return [b[:n] for b, n in zip(bufs, sizes)]
-            dist.gather(pad, gather_list=None, dst=root, group=group)
-            return None
-        except (RuntimeError, NotImplementedError):
-            # a backend without gather (every rank takes the same branch: the call fails before any
-            # communication): the same bytes reach the root through an all-gather from now on
-            _GATHER_VIA_ALL_GATHER = True
+    if gather_collective(group) == "gather":
+        if rank == root:
+            bufs = [torch.empty_like(pad) for _ in range(world)]
+            dist.gather(pad, gather_list=bufs, dst=root, group=group)
+            return [b[:n] for b, n in zip(bufs, sizes)]
+        dist.gather(pad, gather_list=None, dst=root, group=group)
+        return None
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad, group=group)
     return [b[:n] for b, n in zip(bufs, sizes)] if rank == root else None
-
-
-_GATHER_VIA_ALL_GATHER = False
