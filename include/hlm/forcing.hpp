@@ -1,9 +1,9 @@
 // hlm/forcing.hpp -- lookup CSV reader and host-side assembly of the forcing block.
 // LookupMapper: drop-in for reference src/I_O/forcing_loader.cpp:14-64 (header skipped,
 // "stream,lat_index,lon_index", unknown id -> {-1,-1}).  ForcingBlock: the flattened
-// float[sum_j nT_j][ld] array + dt/nT metadata that main.cpp:527-549 builds; NetCDF input is
-// a later row (no libnetcdf in this image), so the sources here are
-// in-memory per-cell tables or constant values.
+// float[sum_j nT_j][ld] array + dt/nT metadata that main.cpp:527-549 builds, from in-memory per-cell
+// tables or constant values.  The NetCDF (time, lat, lon) reader that fills such tables is
+// hlm/netcdf4_io.hpp (on the HDF5 C library).
 #pragma once
 
 #include <cstdint>

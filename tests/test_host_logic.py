@@ -18,22 +18,42 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 39
+    assert len(names) == 40
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
     # and the python binding covers exactly the header
     assert sorted(hlm._lib.SIGNATURES) == names
-    assert hlm._lib.lib().hlm_abi_version() == 2
+    assert hlm._lib.lib().hlm_abi_version() == 3
 
 
-def test_struct_layouts_match_header(hlm):
+def test_struct_layouts_match_header(hlm, tmp_path):
+    """The ctypes mirrors of the C ABI's structs against what a C compiler makes of include/hlm_hip.h: size of
+    every struct and offset of every field (a field added to the header and forgotten in _lib.py would shift
+    everything behind it)."""
+    import subprocess
     assert hlm.SP_DTYPE.itemsize == 136  # parameters_loader.hpp:19-37
     assert [n for n in hlm.SP_DTYPE.names][:4] == ["stream", "next_stream", "c1", "infil"]
-    assert C.sizeof(hlm._lib.GpuBuffers) == 7 * 8 + 4 * 4  # 7 pointers, 3 ints + tail padding
-    assert C.sizeof(hlm._lib.StreamStats) == 40
-    j = hlm._lib.DeviceJob
-    assert j.forc_dt_hours.offset % 8 == 0 and j.params.size == 48
+    structs = {"hlm_gpu_buffers": hlm._lib.GpuBuffers, "hlm_device_job": hlm._lib.DeviceJob,
+               "hlm_stream_stats": hlm._lib.StreamStats}
+    lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "hlm_hip.h"', "int main(void) {",
+             '  printf("abi %d\\n", HLM_ABI_VERSION);']
+    for cname, ct in structs.items():
+        lines.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in ct._fields_:
+            lines.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout.splitlines())
+    assert int(got["abi"]) == hlm._lib.lib().hlm_abi_version() == 3
+    for cname, ct in structs.items():
+        assert int(got[cname]) == C.sizeof(ct), cname
+        for fname, _ in ct._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
+    assert len(hlm._lib.DeviceJob._fields_) == 35 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
 
 
 def test_registry_roundtrip_and_validation_without_gpu(hlm):

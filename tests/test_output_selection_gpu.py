@@ -1,0 +1,199 @@
+"""Device-side output selection (ABI 3): hlm_device_job.dense_ncomp / hlm_set_output_states -- the reference's
+``output.states`` (data/config.yaml:44-52, parsed by I_O/config_loader.cpp:19-84; the writers take the variable
+list, I_O/output_series.cpp:18-72).  The dense rows the kernels store, the transposing kernel moves and PCIe
+carries hold the K selected components only.  Checked on the GPU, through the C ABI:
+  * against the oracle's rows restricted to the subset (parity bound |d| <= 1e-9 + 1e-6 |y|),
+  * bit for bit against the columns of the unselected run (selection changes no step),
+in the three device layouts, streamed in query windows, after the Radau pass, through the host API and the driver."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_parity
+
+pytestmark = pytest.mark.gpu
+
+SUBSETS = [(1,), (0, 2), (1, 3, 4), (0, 1, 2, 3), (4,)]
+
+
+@pytest.fixture(scope="module")
+def gpu(hlm):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return hlm
+
+
+def _case(H, ns=300, days=2, wet=True, tmin=0.5):
+    from tiger_hlm_gpu_amd import synth
+    sp = synth.model204_params(0, ns)
+    y0 = synth.model204_y0(ns, wet_surface=wet)
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=tmin)
+    q = np.concatenate([[-5.0, 0.0], synth.minute_queries(1.0, days * 1440.0 + 30.0, 7.0)])  # before t0 .. past tf
+    return sp, y0, cells, pr, t2m, dt, nT, q
+
+
+def _engine(H, case, days, **kw):
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    sp, y0, cells, pr, t2m, dt, nT, q = case
+    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, **kw)
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    return eng
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_selected_rows_in_every_device_layout_vs_oracle_and_vs_the_full_run(gpu, oracle, layout, math_mode):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    days = 2
+    case = _case(H, ns=300, days=days)  # 300 = 4 full tiles + a ragged one
+    sp, y0, cells, pr, t2m, dt, nT, q = case
+    ref = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, query=q, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells),
+                     forc_dt_h=dt, forc_nT=nT)
+    full_eng = _engine(H, case, days, dense_tiled=layout, math_mode=math_mode)
+    full_eng.integrate()
+    full = full_eng.results()
+    for sel in SUBSETS:
+        eng = _engine(H, case, days, dense_tiled=layout, math_mode=math_mode, dense_states=sel)
+        assert eng.dense.shape[-1] == len(sel)
+        eng.integrate()
+        got = eng.results()
+        assert got["dense"].shape == (300, len(q), len(sel))
+        assert np.array_equal(got["dense"], full["dense"][:, :, list(sel)]), (layout, sel)  # same steps, same rows
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(got[k], full[k]), (k, sel)
+        assert_parity(got["dense"], ref["dense"][:, :, list(sel)], f"selection {sel}, layout {layout}")
+    # listing every component is the plain kernel
+    eng = _engine(H, case, days, dense_tiled=layout, math_mode=math_mode, dense_states=(0, 1, 2, 3, 4))
+    eng.integrate()
+    assert np.array_equal(eng.results()["dense"], full["dense"])
+
+
+@pytest.mark.parametrize("path", ["copy-engine", "transfer-kernel", "transfer-kernel-tile-row", "pageable"])
+@pytest.mark.parametrize("window", [1, 37, 1000])
+def test_selected_rows_streamed_in_windows_equal_one_shot(gpu, window, path):
+    H = gpu
+    days = 2
+    case = _case(H, ns=300, days=days)
+    q = case[-1]
+    full = _engine(H, case, days)
+    full.integrate()
+    one = full.results()
+    for sel in ((2,), (0, 3), (0, 1, 3, 4)):
+        eng = _engine(H, case, days, dense_states=sel)
+        H._lib.lib().hlm_set_stream_path({"transfer-kernel": 2, "transfer-kernel-tile-row": 1}.get(path, 0))
+        try:
+            host_out = np.full((300, len(q), len(sel)), np.nan) if path == "pageable" else None
+            host, stats = eng.integrate_streamed(window, host_out=host_out)
+        finally:
+            H._lib.lib().hlm_set_stream_path(0)
+        assert stats["dense_bytes"] == 300 * len(q) * 8 * len(sel)   # K/5 of the bytes cross PCIe
+        assert np.array_equal(host, one["dense"][:, :, list(sel)]), (sel, window, path)
+        two = eng.results()
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(one[k], two[k]), k
+
+
+@pytest.mark.parametrize("layout", [0, 2])
+def test_selection_with_flagged_hillslopes_and_the_radau_pass(gpu, layout):
+    """Cold cells: flagged hillslopes have zero rows (RK45 pass) or the implicit pass's rows (Radau) -- in both
+    cases the selected columns of the full run."""
+    H = gpu
+    days = 8
+    case = _case(H, ns=256, days=days, wet=False, tmin=-5.0)
+    for radau in (False, True):
+        full = _engine(H, case, days, dense_tiled=layout)
+        full.integrate(radau=radau)
+        one = full.results()
+        assert 0 < (one["stiff"] == 1).sum() < 256
+        for sel in ((1,), (0, 2, 4)):
+            eng = _engine(H, case, days, dense_tiled=layout, dense_states=sel)
+            eng.integrate(radau=radau)
+            got = eng.results()
+            assert np.array_equal(got["dense"], one["dense"][:, :, list(sel)]), (radau, sel)
+            assert np.array_equal(got["stiff"], one["stiff"]) and np.array_equal(got["y_final"], one["y_final"])
+
+
+def test_selection_errors(gpu):
+    H = gpu
+    case = _case(H, ns=64, days=1)
+    for bad in ((5,), (2, 1), (1, 1), (-1,), (0, 1, 2, 3, 4, 5)):
+        eng = _engine(H, case, 1, dense_states=bad)
+        with pytest.raises(H.HlmError) as e:
+            eng.integrate()
+        assert e.value.code == 1, bad
+    with pytest.raises(H.HlmError):
+        H.api.set_output_states((3, 2))
+
+
+def test_host_api_output_states(gpu):
+    """hlm_set_output_states -> setup_gpu_buffers sizes the device rows for K components, the kernels store only
+    those, retrieve_and_free / run_rk45 deliver h_dense[(s*nq + q)*K + k] (toy model too: N_EQ = 3)."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    api = H.api
+    ns, days = 130, 1
+    sp, y0, cells, pr, t2m, dt, nT, q = _case(H, ns=ns, days=days)
+    d_sp = api.upload_spatial_params(sp)
+    f = api.set_forcings(np.concatenate([pr, t2m], axis=0), dt, nT, pr.shape[1], col=cells)
+    try:
+        api.set_output_states(None)
+        full_final, full_dense = api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, q, d_sp)
+        full_dense = full_dense.reshape(ns, len(q), 5)
+        api.set_output_states((1, 4))
+        final, dense = api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, q, d_sp, dense_width=2)
+        assert np.array_equal(final, full_final)
+        assert np.array_equal(dense.reshape(ns, len(q), 2), full_dense[:, :, [1, 4]])
+        # the three-phase form, into pinned memory (the transposing kernel writes it directly)
+        import torch
+        pinned = torch.empty(ns * len(q) * 2, dtype=torch.float64).pin_memory()
+        bufs = api.setup_gpu_buffers(H.Model204, y0, q)
+        assert bufs.dense_ncomp == 2 and list(bufs.dense_comp)[:2] == [1, 4]
+        api.launch_rk45_kernel(H.Model204, bufs, 0.0, days * 1440.0, d_sp)
+        _, d2 = api.retrieve_and_free(H.Model204, bufs, dense_out=pinned)
+        assert np.array_equal(d2.reshape(ns, len(q), 2), full_dense[:, :, [1, 4]])
+        api.set_output_states((0, 1, 2, 3))      # 4 of 5
+        _, d4 = api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, q, d_sp, dense_width=4)
+        assert np.array_equal(d4.reshape(ns, len(q), 4), full_dense[:, :, :4])
+        api.set_output_states((4,))              # not a state of the 3-state toy model
+        with pytest.raises(H.HlmError):
+            api.run_rk45(H.ToyModel3, np.ones((8, 3)), 0.0, 10.0, np.arange(1.0, 10.0), None, dense_width=1)
+    finally:
+        api.set_output_states(None)
+        f.free()
+        d_sp.free()
+
+
+def test_cpp_driver_states_selected_on_the_device(gpu, golden, tmp_path):
+    """rk45_solver --out-format nc --states 1,3: the selection is made on the device (dense_row_width 2 in the
+    result line) and the NetCDF files equal those of the host-side subset of a csv+nc run (--out-format both)."""
+    exe = os.path.join(ROOT, "tools", "rk45_solver")
+    h5dump = os.path.join(os.environ.get("HDF5_DIR", "/opt/conda"), "bin", "h5dump")
+    if not os.path.exists(exe) or not os.path.exists(h5dump):
+        pytest.skip("driver or h5dump not available")
+    base = [exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "2880", "--query-stride", "30", "--initial-step", "1e-6",
+            "--states", "1,3"]
+    outs = {}
+    for fmt in ("nc", "both"):
+        d = tmp_path / fmt
+        d.mkdir()
+        p = subprocess.run(base + ["--out-format", fmt, "--out-final", str(d / "final.csv"), "--out-dense", str(d / "dense.csv")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert line["device_output_selection"] is (fmt == "nc") and line["dense_row_width"] == (2 if fmt == "nc" else 5)
+        assert set(line["phases"]) == {"params_csv_s", "forcing_read_s", "h2d_s", "integrate_s", "d2h_s", "write_s"}
+        vals = []
+        for name in ("final", "dense"):
+            for ds in ("/outputs", "/variable"):
+                b = str(d / f"{name}{ds.replace('/', '_')}.bin")
+                subprocess.run([h5dump, "-d", ds, "-b", "LE", "-o", b, str(d / f"{name}.nc")], check=True, capture_output=True)
+                vals.append(open(b, "rb").read())
+        outs[fmt] = vals
+    assert outs["nc"] == outs["both"]
+    dense = np.frombuffer(outs["nc"][2], dtype=np.float64)
+    assert dense.size == 10 * 97 * 2 and np.frombuffer(outs["nc"][3], dtype=np.int32).tolist() == [1, 3]

@@ -13,6 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HLM_HIP_LIB") or os.path.join(_HERE, "lib", "libhlm_hip.so")
 
 HLM_NEQ = 5
+HLM_MAX_NEQ = 8
 HLM_MAX_FORCINGS = 16
 UID_DUMMY = 0
 UID_204 = 204
@@ -37,6 +38,7 @@ class GpuBuffers(C.Structure):
         ("d_y0_all", C.c_void_p), ("d_y_final_all", C.c_void_p), ("d_query_times", C.c_void_p),
         ("d_dense_all", C.c_void_p), ("d_stiff", C.c_void_p), ("d_n_attempt", C.c_void_p),
         ("d_n_accept", C.c_void_p), ("num_systems", C.c_int), ("num_queries", C.c_int), ("neq", C.c_int), ("dense_layout", C.c_int),
+        ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
     ]
 
 
@@ -57,6 +59,7 @@ class DeviceJob(C.Structure):
         ("dense_tiled", C.c_int), ("use_t_stop", C.c_int), ("t_stop", C.c_double),
         ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
         ("lane_refill", C.c_int),
+        ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
     ]
 
 
@@ -84,6 +87,7 @@ SIGNATURES = {
     "hlm_set_math_mode": (C.c_int, [C.c_int]),
     "hlm_set_radau_fallback": (C.c_int, [C.c_int]),
     "hlm_set_lane_refill": (C.c_int, [C.c_int]),
+    "hlm_set_output_states": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
                                    C.c_int64, C.c_void_p]),
     "hlm_set_forcings_host": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,

@@ -115,6 +115,15 @@ def set_radau_fallback(enabled):
     check(lib().hlm_set_radau_fallback(int(bool(enabled))))
 
 
+def set_output_states(comps=None):
+    """Output selection of the host API (hlm_set_output_states; the reference's ``output.states``,
+    data/config.yaml:44-52): the dense rows of setup_gpu_buffers / run_rk45 carry only the state components
+    ``comps`` (ascending, distinct).  None or () = all components."""
+    comps = [] if comps is None else [int(c) for c in comps]
+    arr = (C.c_int * max(len(comps), 1))(*comps)
+    check(lib().hlm_set_output_states(len(comps), arr))
+
+
 class Forcings:
     """Device-resident forcing block + metadata (the reference's c_forc_dt / c_forc_nT /
     d_forc_data / nForc symbols, forcing_data.cu:5-10)."""
@@ -205,12 +214,13 @@ def retrieve_and_free(model, bufs, with_info=False, dense_out=None):
     """``dense_out``: optional float64 array / pinned torch tensor of ns*nq*N_EQ elements to receive the dense
     rows (pinned, device-mapped memory is written by the transposing kernel directly)."""
     ns, nq, neq = bufs.num_systems, bufs.num_queries, model.N_EQ
+    width = bufs.dense_ncomp if bufs.dense_ncomp > 0 else neq  # doubles per dense row (output selection)
     final = np.empty(ns * neq)
     if dense_out is None:
-        dense = np.empty(ns * nq * neq)
+        dense = np.empty(ns * nq * width)
     else:
         dense = dense_out.numpy().reshape(-1) if hasattr(dense_out, "numpy") else np.asarray(dense_out).reshape(-1)
-        assert dense.dtype == np.float64 and dense.size == ns * nq * neq and dense.flags.c_contiguous
+        assert dense.dtype == np.float64 and dense.size == ns * nq * width and dense.flags.c_contiguous
     stiff = np.empty(ns, dtype=np.int32)
     na = np.empty(ns, dtype=np.uint32)
     nacc = np.empty(ns, dtype=np.uint32)
@@ -221,15 +231,16 @@ def retrieve_and_free(model, bufs, with_info=False, dense_out=None):
     return final, dense
 
 
-def run_rk45(model, h_y0, t0, tf, h_query_times, d_sp, with_info=False):
+def run_rk45(model, h_y0, t0, tf, h_query_times, d_sp, with_info=False, dense_width=None):
     """std::pair<FinalType, DenseType> run_rk45<Model>(h_y0, t0, tf, h_query_times, d_sp):
-    first = y_final[s*N_EQ+i]; second = dense[(s*nq+q)*N_EQ+c]."""
+    first = y_final[s*N_EQ+i]; second = dense[(s*nq+q)*N_EQ+c].  With a registered output selection
+    (set_output_states) pass its length as ``dense_width``: second = dense[(s*nq+q)*K+k]."""
     y0 = np.ascontiguousarray(h_y0, dtype=np.float64).reshape(-1)
     q = np.ascontiguousarray(h_query_times if h_query_times is not None else [], dtype=np.float64).reshape(-1)
     neq = model.N_EQ
     ns, nq = y0.size // neq, q.size
     final = np.empty(ns * neq)
-    dense = np.empty(ns * nq * neq)
+    dense = np.empty(ns * nq * (neq if dense_width is None else int(dense_width)))
     stiff = np.empty(ns, dtype=np.int32)
     na = np.empty(ns, dtype=np.uint32)
     nacc = np.empty(ns, dtype=np.uint32)
@@ -245,7 +256,8 @@ def run_rk45(model, h_y0, t0, tf, h_query_times, d_sp, with_info=False):
 # ---- device-resident path (torch tensors as HBM buffers) ------------------------------------------
 def make_device_job(model, *, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_hours=(), forc_nT=(),
                     forc_ld=0, forc_col=None, params=None, fixed_step=0.0, attempt_cap=0,
-                    math_mode=_lib.MATH_FAST, y_final, dense=None, stiff, n_attempt=None, n_accept=None):
+                    math_mode=_lib.MATH_FAST, y_final, dense=None, stiff, n_attempt=None, n_accept=None,
+                    dense_states=None):
     """Fill an hlm_device_job from torch CUDA tensors (or raw int device pointers)."""
     def dp(t):
         if t is None:
@@ -271,6 +283,10 @@ def make_device_job(model, *, y0, t0, tf, query=None, sp=None, forc=None, forc_d
     j.fixed_step, j.attempt_cap, j.math_mode = float(fixed_step), int(attempt_cap), int(math_mode)
     j.d_y_final, j.d_dense, j.d_stiff = dp(y_final), dp(dense), dp(stiff)
     j.d_n_attempt, j.d_n_accept = dp(n_attempt), dp(n_accept)
+    if dense_states is not None:  # output selection: rows of len(dense_states) components (hlm_device_job.dense_ncomp)
+        j.dense_ncomp = len(dense_states)
+        for k, c in enumerate(dense_states):
+            j.dense_comp[k] = int(c)
     return j
 
 

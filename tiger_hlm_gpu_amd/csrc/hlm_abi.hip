@@ -80,6 +80,9 @@ int g_math = HLM_MATH_FAST;
 bool g_math_explicit = false;
 int g_refill = 0;  // hlm_set_lane_refill(): host-API launches without dense output use the refill kernel
 int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
+// hlm_set_output_states(): the dense rows of the host API carry only these state components (0 = all)
+int g_out_ncomp = 0;
+int g_out_comp[HLM_MAX_NEQ] = {};
 
 struct ForcingState {
     const float* d_forc = nullptr;
@@ -142,6 +145,43 @@ KernelFn pick_kernel(int math, bool dense, bool fixed, bool resumable)
     if (math == HLM_MATH_FAST)
         return resumable ? pick_kernel2<Model, MATH_FAST, true>(dense, fixed) : pick_kernel2<Model, MATH_FAST, false>(dense, fixed);
     return resumable ? pick_kernel2<Model, MATH_STRICT, true>(dense, fixed) : pick_kernel2<Model, MATH_STRICT, false>(dense, fixed);
+}
+
+// Output selection (hlm_device_job.dense_ncomp): the SEL kernel variants, resumable form only (it also serves a
+// plain one-launch job: no resume buffer, t_stop = +inf)
+template <class Model>
+KernelFn pick_selecting(int math, bool fixed, bool ring)
+{
+    using namespace hlm;
+    constexpr int R = HLM_DENSE_RING_ROWS;
+    if (ring) {
+        if (math == HLM_MATH_FAST) return fixed ? rk45_dense_ring_kernel<Model, MATH_FAST, true, true, R, true> : rk45_dense_ring_kernel<Model, MATH_FAST, false, true, R, true>;
+        return fixed ? rk45_dense_ring_kernel<Model, MATH_STRICT, true, true, R, true> : rk45_dense_ring_kernel<Model, MATH_STRICT, false, true, R, true>;
+    }
+    if (math == HLM_MATH_FAST) return fixed ? rk45_multi_kernel<Model, MATH_FAST, true, true, true, true> : rk45_multi_kernel<Model, MATH_FAST, true, false, true, true>;
+    return fixed ? rk45_multi_kernel<Model, MATH_STRICT, true, true, true, true> : rk45_multi_kernel<Model, MATH_STRICT, true, false, true, true>;
+}
+KernelFn pick_selecting(int uid, int math, bool fixed, bool ring)
+{
+    return with_model<KernelFn>(uid, [&](auto m) { return pick_selecting<decltype(m)>(math, fixed, ring); });
+}
+
+// doubles per dense row of a job: the selected components, or all N_EQ
+int job_row_width(const hlm_device_job* j) { return j->dense_ncomp > 0 ? j->dense_ncomp : model_neq(j->uid); }
+// a selection that really leaves components out (listing all of them is the plain kernel)
+bool job_selects(const hlm_device_job* j) { return j->dense_ncomp > 0 && j->dense_ncomp < model_neq(j->uid); }
+
+int validate_selection(int uid, int n, const int* comps)
+{
+    const int neq = model_neq(uid);
+    if (n < 0 || n > neq) return fail(HLM_ERR_INVALID_ARGUMENT, "output selection: %d components, model %d has %d", n, uid, neq);
+    for (int k = 0; k < n; ++k) {
+        if (comps[k] < 0 || comps[k] >= neq)
+            return fail(HLM_ERR_INVALID_ARGUMENT, "output selection: %d is not a state of model %d (N_EQ = %d)", comps[k], uid, neq);
+        if (k > 0 && comps[k] <= comps[k - 1])
+            return fail(HLM_ERR_INVALID_ARGUMENT, "output selection must be ascending and distinct (position %d: %d after %d)", k, comps[k], comps[k - 1]);
+    }
+    return HLM_SUCCESS;
 }
 
 // the dense kernels with wave-synchronous stores (hlm_rk45_dense_kernel.h), layout [tile][q][comp][lane]
@@ -240,6 +280,7 @@ int validate_job(const hlm_device_job* j)
     }
     if (j->resume_in && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "resume_in without d_resume");
     if (j->dense_tiled < 0 || j->dense_tiled > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0, 1 or 2");
+    if (const int rcs = validate_selection(j->uid, j->dense_ncomp, j->dense_comp); rcs != HLM_SUCCESS) return rcs;
     if (j->lane_refill != 0 && j->lane_refill != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane_refill must be 0 or 1");
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
@@ -298,6 +339,11 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     a.stiff = j->d_stiff;
     a.n_attempt = j->d_n_attempt;
     a.n_accept = j->d_n_accept;
+    if (job_selects(j)) {
+        a.dense_k = j->dense_ncomp;
+        for (int c = 0; c < HLM_MAX_NEQ; ++c) a.dense_pos[c] = -1;
+        for (int k = 0; k < j->dense_ncomp; ++k) a.dense_pos[j->dense_comp[k]] = k;
+    }
     return a;
 }
 
@@ -334,7 +380,8 @@ int launch(const hlm_device_job* j, hipStream_t stream)
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
     if (!dense && j->lane_refill && !job_is_resumable(j)) return launch_refill(j, stream);
-    KernelFn fn = dense && j->dense_tiled == hlm::DENSE_TILE_COMP
+    KernelFn fn = dense && job_selects(j) ? pick_selecting(j->uid, j->math_mode, fixed, j->dense_tiled == hlm::DENSE_TILE_COMP)
+                  : dense && j->dense_tiled == hlm::DENSE_TILE_COMP
                       ? pick_dense_ring(j->uid, j->math_mode, fixed, job_is_resumable(j))
                       : pick(j->uid, j->math_mode, dense, fixed, job_is_resumable(j));
     if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
@@ -356,9 +403,17 @@ void launch_tile_to_host(int layout, int neq, dim3 grid, hipStream_t stream, con
         else
             hipLaunchKernelGGL((hlm::dense_tile_to_host<false, N>), grid, dim3(256), 0, stream, src, dst, ns, nq, q_begin, W);
     };
-    if (neq == 3) go(std::integral_constant<int, 3>{});
-    else go(std::integral_constant<int, 5>{});
-    static_assert(hlm::ToyDev::N_EQ == 3 && hlm::Model204Dev::N_EQ == 5 && hlm::DummyDev::N_EQ == 5, "one instance per registered N_EQ");
+    switch (neq) {  // neq = doubles per row: a model's N_EQ, or the width of an output selection
+        case 1: go(std::integral_constant<int, 1>{}); break;
+        case 2: go(std::integral_constant<int, 2>{}); break;
+        case 3: go(std::integral_constant<int, 3>{}); break;
+        case 4: go(std::integral_constant<int, 4>{}); break;
+        case 5: go(std::integral_constant<int, 5>{}); break;
+        case 6: go(std::integral_constant<int, 6>{}); break;
+        case 7: go(std::integral_constant<int, 7>{}); break;
+        default: go(std::integral_constant<int, 8>{}); break;
+    }
+    static_assert(HLM_MAX_NEQ == 8, "one instance per possible row width");
 }
 
 // Radau-IIA pass over the systems the RK45 launch of the same job flagged (stream-ordered after it)
@@ -622,6 +677,19 @@ int hlm_set_lane_refill(int enabled)
     return HLM_SUCCESS;
 }
 
+int hlm_set_output_states(int n, const int* comps)
+{
+    if (n < 0 || n > HLM_MAX_NEQ || (n > 0 && !comps)) return fail(HLM_ERR_INVALID_ARGUMENT, "output states: n = %d (0..%d) with a list", n, HLM_MAX_NEQ);
+    for (int k = 0; k < n; ++k) {
+        if (comps[k] < 0 || comps[k] >= HLM_MAX_NEQ) return fail(HLM_ERR_INVALID_ARGUMENT, "output states: component %d", comps[k]);
+        if (k > 0 && comps[k] <= comps[k - 1]) return fail(HLM_ERR_INVALID_ARGUMENT, "output states must be ascending and distinct");
+    }
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_out_ncomp = n;
+    for (int k = 0; k < HLM_MAX_NEQ; ++k) g_out_comp[k] = k < n ? comps[k] : 0;
+    return HLM_SUCCESS;
+}
+
 int hlm_set_radau_fallback(int enabled)
 {
     if (enabled != 0 && enabled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "radau fallback flag %d (want 0 or 1)", enabled);
@@ -677,7 +745,7 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
     if (!h_dense) return fail(HLM_ERR_INVALID_ARGUMENT, "h_dense is NULL");
     const int W = window_queries < nq ? window_queries : nq;
     const int nwin = (nq + W - 1) / W;
-    const int neq = model_neq(job->uid);
+    const int neq = job_row_width(job);                // doubles per row: N_EQ, or the selected components only
     const size_t row = (size_t)neq * sizeof(double);  // 40 B per (system, query) for the 5-state models
 
     // Path 0 (default): linear device windows [ns][W][5] + hipMemcpy2DAsync on the copy engine.
@@ -748,7 +816,7 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
             launch_tile_to_host(g_stream_layout, neq, grid, copy, buf[b], h_dense_dev, ns, nq, qb, Wk);
             ok(hipGetLastError());
         } else {
-            // device [ns][qe-qb][5] -> host rows of nq*40 B, columns qb..qe
+            // device [ns][qe-qb][K] -> host rows of nq*8K B, columns qb..qe
             ok(hipMemcpy2DAsync(reinterpret_cast<char*>(h_dense) + (size_t)qb * row, (size_t)nq * row, buf[b],
                                 (size_t)(qe - qb) * row, (size_t)(qe - qb) * row, (size_t)ns,
                                 hipMemcpyDeviceToHost, copy));
@@ -1027,7 +1095,17 @@ int hlm_setup_gpu_buffers_model(int uid, const double* h_y0, int ns, const doubl
     // dense rows live tile-major in HBM ([ceil(ns/64)][nq][5][64], whole cache lines per store:
     // hlm_rk45_dense_kernel.h); hlm_retrieve_and_free delivers the host order
     out->dense_layout = hlm::DENSE_TILE_COMP;
-    const size_t b_dense = sizeof(double) * (size_t)((ns + hlm::WAVE - 1) / hlm::WAVE) * hlm::WAVE * (size_t)neq * (size_t)nq;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);  // the registered output selection (hlm_set_output_states)
+        out->dense_ncomp = g_out_ncomp;
+        std::memcpy(out->dense_comp, g_out_comp, sizeof(g_out_comp));
+    }
+    if (const int rcs = validate_selection(uid, out->dense_ncomp, out->dense_comp); rcs != HLM_SUCCESS) {
+        std::memset(out, 0, sizeof(*out));
+        return rcs;
+    }
+    const int width = out->dense_ncomp > 0 ? out->dense_ncomp : neq;
+    const size_t b_dense = sizeof(double) * (size_t)((ns + hlm::WAVE - 1) / hlm::WAVE) * hlm::WAVE * (size_t)width * (size_t)nq;
     hipError_t e = hipSuccess;
     auto alloc = [&](void** p, size_t bytes) {
         if (e == hipSuccess && bytes) e = hipMalloc(p, bytes);
@@ -1089,6 +1167,8 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     j.d_y_final = b->d_y_final_all;
     j.d_dense = b->d_dense_all;
     j.dense_tiled = b->dense_layout;
+    j.dense_ncomp = b->dense_ncomp;
+    std::memcpy(j.dense_comp, b->dense_comp, sizeof(j.dense_comp));
     j.d_stiff = b->d_stiff;
     j.d_n_attempt = b->d_n_attempt;
     j.d_n_accept = b->d_n_accept;
@@ -1158,7 +1238,7 @@ int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense, 
     };
     const int neq = b->neq ? b->neq : HLM_NEQ;
     d2h(h_final, b->d_y_final_all, sizeof(double) * ns * (size_t)neq);
-    if (e == hipSuccess) e = dense_to_host_order(b->d_dense_all, b->dense_layout, neq, ns, nq, h_dense);
+    if (e == hipSuccess) e = dense_to_host_order(b->d_dense_all, b->dense_layout, b->dense_ncomp > 0 ? b->dense_ncomp : neq, ns, nq, h_dense);
     d2h(h_stiff, b->d_stiff, sizeof(int32_t) * ns);
     d2h(h_n_attempt, b->d_n_attempt, sizeof(uint32_t) * ns);
     d2h(h_n_accept, b->d_n_accept, sizeof(uint32_t) * ns);

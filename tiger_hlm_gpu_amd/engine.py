@@ -15,7 +15,7 @@ from .models import Parameters, SP_DTYPE
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
                  math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
-                 dense_tiled=2, lane_refill=False):
+                 dense_tiled=2, lane_refill=False, dense_states=None):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -50,8 +50,12 @@ class ShardEngine:
         # [tile][q][c][lane], the kernel with wave-synchronous stores; 0 host order and 1 [tile][q][lane][c],
         # the free-running kernel.  results() / dense_host_order() deliver [ns][nq][5] whatever the layout.
         self.dense_tiled = int(dense_tiled)
+        # output selection (hlm_device_job.dense_ncomp; the reference's output.states): the dense rows hold only
+        # these state components -- K/N_EQ of the HBM and PCIe bytes; None = all
+        self.dense_states = None if dense_states is None else tuple(int(c) for c in dense_states)
+        self.dense_width = model.N_EQ if self.dense_states is None else len(self.dense_states)
         rows = -(-self.ns // 64) * 64 if self.dense_tiled else self.ns
-        self.dense = (torch.empty((rows, self.nq, model.N_EQ), dtype=torch.float64, device=dev)
+        self.dense = (torch.empty((rows, self.nq, self.dense_width), dtype=torch.float64, device=dev)
                       if self.nq and alloc_dense else None)
         self.stiff = self.result_blob[o:o + ns8 * 4].view(torch.int32)[:self.ns]
         self.n_attempt = self.result_blob[o + ns8 * 4:o + 2 * ns8 * 4].view(torch.int32)[:self.ns]  # uint32 bits
@@ -90,7 +94,8 @@ class ShardEngine:
             forc=self.forc, forc_dt_hours=self.forc_dt, forc_nT=self.forc_nT, forc_ld=self.forc_ld,
             forc_col=self.forc_col, params=self.params, fixed_step=self.fixed_step,
             attempt_cap=self.attempt_cap, math_mode=self.math_mode, y_final=self.y_final,
-            dense=self.dense, stiff=self.stiff, n_attempt=self.n_attempt, n_accept=self.n_accept)
+            dense=self.dense, stiff=self.stiff, n_attempt=self.n_attempt, n_accept=self.n_accept,
+            dense_states=self.dense_states)
         j.dense_tiled = self.dense_tiled if self.dense is not None else 0
         j.lane_refill = self.lane_refill
         return j
@@ -224,7 +229,7 @@ class ShardEngine:
         ``dense`` buffer is not used (it may not even fit in HBM)."""
         assert self.nq > 0
         if host_out is None:
-            host_out = torch.empty((self.ns, self.nq, self.model.N_EQ), dtype=torch.float64, pin_memory=True)
+            host_out = torch.empty((self.ns, self.nq, self.dense_width), dtype=torch.float64, pin_memory=True)
         arr = host_out.numpy() if torch.is_tensor(host_out) else host_out
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         keep, self.dense = self.dense, None
@@ -252,7 +257,7 @@ class ShardEngine:
         if self.dense is None or self.dense_tiled == 0:
             return self.dense
         tiles = self.dense.shape[0] // 64
-        n_eq = self.model.N_EQ
+        n_eq = self.dense_width
         if self.dense_tiled == 1:
             d = self.dense.view(tiles, self.nq, 64, n_eq).permute(0, 2, 1, 3)  # [tile][q][lane][c]
         else:

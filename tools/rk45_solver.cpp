@@ -52,7 +52,8 @@ struct Options {
     double safety = -1.0, min_scale = -1.0, max_scale = -1.0;  // < 0: the model's Parameters defaults
     std::string config;           // YAML run configuration (schema of the reference's data/config.yaml)
     std::string init_file;        // "hot" start: CSV, one row of N_EQ states per hillslope (parameter-file order)
-    std::vector<int> states;      // subset of states written to the NetCDF outputs (empty = all)
+    std::vector<int> states;      // subset of states written to the NetCDF outputs (empty = all); with --out-format nc
+                                  // the selection is made ON THE DEVICE (dense rows of K components: hlm_set_output_states)
     bool scipy_h0 = false;
     std::string math;  // "fast" | "strict"; empty = the library default (FAST where its atol range allows)
     std::string out_final = "final.csv", out_dense = "dense.csv";
@@ -78,7 +79,7 @@ struct Options {
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
-                 "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L]\n"
+                 "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L] [--states I,J,..]\n"
                  "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
     std::exit(msg ? 2 : 0);
 }
@@ -161,6 +162,16 @@ Options parse(int argc, char** argv)
         else if (a == "--stream-forcings") o.stream_forcings = std::atof(val());
         else if (a == "--out-format") o.out_format = val();
         else if (a == "--nc-compression") o.nc_compression = std::atoi(val());
+        else if (a == "--states") {  // config output.states from the command line: "1,3"
+            o.states.clear();
+            for (const char* p = val(); *p;) {
+                char* end = nullptr;
+                const long v = std::strtol(p, &end, 10);
+                if (end == p) usage("--states expects a comma-separated list of state indices");
+                o.states.push_back((int)v);
+                p = *end == ',' ? end + 1 : end;
+            }
+        }
         else if (a == "--device") o.device = std::atoi(val());
         else if (a == "--gpus") o.gpus = std::atoi(val());
         else if (a == "--oversubscribe") o.oversubscribe = true;
@@ -195,6 +206,12 @@ int run(const Options& o, hlm_io::CsvStyle style)
     constexpr int N_EQ = Model::N_EQ;
     const bool is204 = Model::UID == HLM_UID_204;
     const bool is_toy = Model::UID == HLM_UID_TOY3;
+    // wall time of every host phase around the integration (the reference's only timer sits around its NetCDF
+    // writer, main.cpp:809-823); printed in the result line as "phases"
+    using clk = std::chrono::steady_clock;
+    auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
+    double t_params = 0, t_forcing_read = 0, t_write = 0;
+    clk::time_point tp = clk::now();
 
     // ---- streams ---------------------------------------------------------------------------
     std::vector<SpatialParams> spatial;
@@ -212,6 +229,8 @@ int run(const Options& o, hlm_io::CsvStyle style)
 
     const double t0 = o.t0;
     const double tf = o.tf > 0 ? o.tf : (is204 ? 2 * 24.0 * 60.0 : 5.0);  // main.cpp:610-611 / README
+    t_params = since(tp);
+    tp = clk::now();
 
     // ---- forcings on the host: a table [sum nT][ncol] + one column index per stream ---------------
     // NetCDF (time, lat, lon) forcings go through the lookup table (main.cpp:495-549).  The
@@ -272,6 +291,8 @@ int run(const Options& o, hlm_io::CsvStyle style)
         fb.add_constant((float)o.rain, n_hours ? n_hours : 1, 1.0);
         fb.add_constant((float)o.temp, n_days ? n_days : 1, 24.0);
     }
+
+    t_forcing_read = since(tp);
 
     // ---- solver parameters (main.cpp:615-641) ---------------------------------------------------------
     typename Model::Parameters hp;
@@ -349,7 +370,18 @@ int run(const Options& o, hlm_io::CsvStyle style)
     const int G = std::max(1, o.gpus);
     if (G > ndev && !o.oversubscribe)
         throw std::runtime_error("--gpus " + std::to_string(G) + " but only " + std::to_string(ndev) + " device(s) visible");
-    std::vector<double> h_y_final((size_t)ns * N_EQ), h_dense((size_t)ns * nq * N_EQ);
+    // config output.states: with NetCDF-only output the selection is made on the device -- the dense rows the
+    // kernels store, the transposing kernel moves and PCIe carries hold the K listed components only.  The CSV
+    // layouts (main.cpp:734-773) have every component, so csv / both keep whole rows and subset on the host.
+    for (size_t k = 0; k < o.states.size(); ++k) {
+        if (o.states[k] < 0 || o.states[k] >= N_EQ) throw std::runtime_error("output.states: " + std::to_string(o.states[k]) + " is not a state of this model");
+        if (k > 0 && o.states[k] <= o.states[k - 1]) throw std::runtime_error("output.states must be ascending and distinct");
+    }
+    const bool device_select = !o.states.empty() && (int)o.states.size() < N_EQ && o.out_format == "nc";
+    const int width = device_select ? (int)o.states.size() : N_EQ;  // doubles per dense row as it leaves the device
+    rk45_api::set_output_states(device_select ? o.states : std::vector<int>{});
+    std::vector<double> h_y_final((size_t)ns * N_EQ), h_dense((size_t)ns * nq * width);
+    std::vector<double> t_h2d(G, 0.0), t_integrate(G, 0.0), t_d2h(G, 0.0);
     std::vector<int32_t> stiff(ns, 0);
     std::vector<uint32_t> n_attempt(ns, 0);
     std::vector<std::string> errors(G);
@@ -365,6 +397,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
             const int dev = G > 1 ? (o.device + r) % std::max(ndev, 1) : o.device;
             std::lock_guard<std::mutex> turn(device_turn[(size_t)std::min(std::max(dev, 0), std::max(ndev, 1) - 1)]);
             rk45_api::detail::check(hlm_set_device(dev), "hlm_set_device");
+            clk::time_point ts = clk::now();
             SpatialParams* d_sp = rk45_api::device_upload(spatial.data() + start, (size_t)count);
             float* d_forc = nullptr;
             int32_t* d_col = nullptr;
@@ -393,10 +426,25 @@ int run(const Options& o, hlm_io::CsvStyle style)
                 rk45_api::detail::check(hlm_clear_forcings(), "hlm_clear_forcings");
             }
             const std::vector<double> y0_shard(h_y0.begin() + (size_t)start * N_EQ, h_y0.begin() + (size_t)(start + count) * N_EQ);
-            auto [yf, dn] = rk45_api::run_rk45<Model>(y0_shard, t0, tf, h_query_times, d_sp);
+            // run_rk45<Model> (rk45_api.hpp:273-313) spelt out in its three phases so that each can be timed
+            auto [d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, ns_b, nq_b] =
+                rk45_api::setup_gpu_buffers<Model>(y0_shard, h_query_times);
+            t_h2d[r] = since(ts);
+            ts = clk::now();
+            try {
+                rk45_api::launch_rk45_kernel<Model>(d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, ns_b, nq_b, t0, tf, d_sp);
+            } catch (...) {
+                hlm_gpu_buffers b = rk45_api::detail::adopt(d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, ns_b, nq_b, true);
+                hlm_retrieve_and_free(&b, nullptr, nullptr, nullptr, nullptr, nullptr);
+                throw;
+            }
+            t_integrate[r] = since(ts);
+            ts = clk::now();
+            auto [yf, dn] = rk45_api::retrieve_and_free<Model>(d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, ns_b, nq_b, t0, tf, d_sp);
+            t_d2h[r] = since(ts);
             const rk45_api::RunInfo info = rk45_api::last_run_info();
             std::copy(yf.begin(), yf.end(), h_y_final.begin() + (size_t)start * N_EQ);
-            std::copy(dn.begin(), dn.end(), h_dense.begin() + (size_t)start * nq * N_EQ);
+            std::copy(dn.begin(), dn.end(), h_dense.begin() + (size_t)start * nq * width);
             std::copy(info.stiff.begin(), info.stiff.end(), stiff.begin() + start);
             if (!info.n_attempt.empty()) std::copy(info.n_attempt.begin(), info.n_attempt.end(), n_attempt.begin() + start);
             rk45_api::device_free(d_sp);
@@ -419,6 +467,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
     for (int r = 0; r < G; ++r)
         if (!errors[r].empty()) throw std::runtime_error("shard " + std::to_string(r) + ": " + errors[r]);
 
+    tp = clk::now();
     if (o.out_format == "csv" || o.out_format == "both") {
         hlm_io::write_final_csv(o.out_final, h_y_final, ns, N_EQ, style);
         hlm_io::write_dense_csv(o.out_dense, h_dense, h_query_times, ns, N_EQ, style);
@@ -435,23 +484,29 @@ int run(const Options& o, hlm_io::CsvStyle style)
             write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
                                (int)nq, ns, N_EQ, o.nc_compression);
         } else {
-            // config output.states: only these columns; the "variable" coordinate keeps their model indices
+            // config output.states: only these columns; the "variable" coordinate keeps their model indices.
+            // Final states always come back whole (they are the next run's initial state); the dense rows
+            // arrive already reduced when the device made the selection (device_select above).
             const int K = (int)o.states.size();
-            for (int v : o.states)
-                if (v < 0 || v >= N_EQ) throw std::runtime_error("output.states: " + std::to_string(v) + " is not a state of this model");
-            std::vector<double> yf((size_t)ns * K), dn((size_t)ns * nq * K);
+            std::vector<double> yf((size_t)ns * K), dn_host;
             for (size_t r = 0; r < (size_t)ns; ++r)
                 for (int k = 0; k < K; ++k) yf[r * K + k] = h_y_final[r * N_EQ + o.states[k]];
-            for (size_t r = 0; r < (size_t)ns * nq; ++r)
-                for (int k = 0; k < K; ++k) dn[r * K + k] = h_dense[r * N_EQ + o.states[k]];
+            if (width != K) {
+                dn_host.resize((size_t)ns * nq * K);
+                for (size_t r = 0; r < (size_t)ns * nq; ++r)
+                    for (int k = 0; k < K; ++k) dn_host[r * K + k] = h_dense[r * N_EQ + o.states[k]];
+            }
+            const double* dn = width != K ? dn_host.data() : h_dense.data();
             write_final_netcdf(nc_name(o.out_final), yf.data(), linkid_vals.data(), o.states.data(), ns, K, o.nc_compression);
-            write_dense_netcdf(nc_name(o.out_dense), dn.data(), h_query_times.data(), linkid_vals.data(), o.states.data(), (int)nq, ns, K,
+            write_dense_netcdf(nc_name(o.out_dense), dn, h_query_times.data(), linkid_vals.data(), o.states.data(), (int)nq, ns, K,
                                o.nc_compression);
         }
 #else
         usage("--out-format nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
 #endif
     }
+
+    t_write = since(tp);
 
     unsigned long long attempts = 0;
     int flagged = 0, unsolved = 0;  // flagged by RK45; of those, not finished by the Radau fallback either
@@ -463,9 +518,13 @@ int run(const Options& o, hlm_io::CsvStyle style)
     if (!o.quiet)
         std::printf("{\"model\": %d, \"num_systems\": %d, \"num_queries\": %zu, \"t0\": %g, \"tf\": %g, "
                     "\"initial_step\": %g, \"gpus\": %d, \"attempted_steps\": %llu, \"flagged\": %d, \"radau\": %s, \"unsolved\": %d, "
-                    "\"run_rk45_seconds\": %.6f, \"final\": \"%s\", \"dense\": \"%s\"}\n",
+                    "\"run_rk45_seconds\": %.6f, \"dense_row_width\": %d, \"device_output_selection\": %s, "
+                    "\"phases\": {\"params_csv_s\": %.6f, \"forcing_read_s\": %.6f, \"h2d_s\": %.6f, \"integrate_s\": %.6f, "
+                    "\"d2h_s\": %.6f, \"write_s\": %.6f}, \"final\": \"%s\", \"dense\": \"%s\"}\n",
                     (int)Model::UID, ns, nq, t0, tf, hp.initialStep, G, attempts, flagged, o.radau ? "true" : "false", unsolved, secs,
-                    o.out_final.c_str(), o.out_dense.c_str());
+                    width, device_select ? "true" : "false", t_params, t_forcing_read,
+                    *std::max_element(t_h2d.begin(), t_h2d.end()), *std::max_element(t_integrate.begin(), t_integrate.end()),
+                    *std::max_element(t_d2h.begin(), t_d2h.end()), t_write, o.out_final.c_str(), o.out_dense.c_str());
     return 0;
 }
 
