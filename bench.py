@@ -95,9 +95,11 @@ def parse():
     ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
     ap.add_argument("--no-variants", action="store_true", help="skip the wet-surface variant pass")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-output (config 5 style) section")
-    ap.add_argument("--dense-ns", type=int, default=65536)
-    ap.add_argument("--dense-days", type=int, default=2)
-    ap.add_argument("--dense-window", type=int, default=720, help="queries per streamed window")
+    ap.add_argument("--dense-ns", type=int, default=1_000_000, help="hillslopes of the streamed dense-output measurement")
+    ap.add_argument("--dense-days", type=int, default=1)
+    ap.add_argument("--dense-window", type=int, default=96, help="queries per streamed window (1 M x 96 x 40 B = 3.84 GB per buffer)")
+    ap.add_argument("--c5-ns", type=int, default=500_000, help="hillslopes of the config-5 share run in HBM windows (0 skips it)")
+    ap.add_argument("--c5-days", type=int, default=30)
     ap.add_argument("--dense-hbm-ns", type=int, default=1_000_000,
                     help="hillslopes of the in-HBM dense kernel measurement (1 day at 1-minute stride; 0 skips it)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -205,56 +207,95 @@ def timed_passes(eng, total, world, warmup, steps):
     return wall, kernel_ms, gather_ms
 
 
+def _host_bytes_available():
+    """Host memory this process may still take (MemAvailable, capped by the cgroup limit where there is one)."""
+    avail = None
+    try:
+        for ln in open("/proc/meminfo"):
+            if ln.startswith("MemAvailable:"):
+                avail = int(ln.split()[1]) * 1024
+    except Exception:
+        pass
+    try:
+        lim = open("/sys/fs/cgroup/memory.max").read().strip()
+        cur = int(open("/sys/fs/cgroup/memory.current").read().strip())
+        if lim != "max":
+            avail = min(avail, int(lim) - cur) if avail is not None else int(lim) - cur
+    except Exception:
+        pass
+    return avail
+
+
 def dense_section(args):
-    """BASELINE config 5 shape on one GPU: 1-minute query stride, dense output streamed to
-    pinned host memory in query windows with the D2H of window k overlapped with the
-    integration of window k+1.  dense-output MB/s = ns*nq*5*8 B / wall time until the bytes
-    are in host memory in [sys][q][comp] order."""
+    """BASELINE config 5 shape on one GPU (dense output at 1-minute query stride), three measurements:
+    streamed   -- the windowed pipeline to HOST memory (hlm_rk45_integrate_streamed_sink: two device windows, two
+                  pinned staging buffers, D2H of window k overlapped with the integration of window k+1):
+                  dense-output MB/s = bytes / wall time until they are in host memory in [sys][q][comp] order
+                  (BASELINE.md section 3), with all five state components and with one selected on the device;
+    in_hbm_kernel -- the dense kernel by itself, rows kept in HBM: the HBM-bound kernel of the path;
+    c5_share   -- one GPU's share of config 5 (500 000 hillslopes x 30 days x 43 201 queries = 864 GB of rows) through
+                  the same kernel in 1-day query windows reusing one HBM buffer: sustained rate over the whole span."""
+    dev = f"cuda:{torch.cuda.current_device()}"
+    math = H.MATH_FAST if args.math == "fast" else H.MATH_STRICT
+    out = {}
+
+    # ---- streamed to the host -------------------------------------------------------------------------------
     ns, days = args.dense_ns, args.dense_days
-    sp = synth.model204_params(0, ns)
-    y0 = synth.model204_y0(ns)
-    cells = synth.cell_of_system(0, ns)
-    pr, t2m, dt, nT = synth.forcing_tables(days=days)
     tf = days * 1440.0
-    q = synth.minute_queries(0.0, tf, 1.0)
-    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, alloc_dense=False,
-                      math_mode=H.MATH_FAST if args.math == "fast" else H.MATH_STRICT,
-                      device=f"cuda:{torch.cuda.current_device()}")
-    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
-    host = torch.empty((ns, len(q), 5), dtype=torch.float64, pin_memory=True)
-    eng.integrate_streamed(args.dense_window, host_out=host)          # warm-up (also faults the pages in)
-    torch.cuda.synchronize()
-    _, st = eng.integrate_streamed(args.dense_window, host_out=host)
-    attempts = eng.total_attempts()
-    algo_bytes = st["dense_bytes"] + ns * B_SYS + 4.0 * sum(eng.forc_nT) * ns
-    hbm = algo_bytes / (st["kernel_ms"] * 1e-3) / 1e9
-    out = {"workload": f"Model 204, {ns} hillslopes, {days} days, query every 1 min (nq={len(q)}), "
-                       f"{st['windows']} windows of {args.dense_window} queries, math={args.math}",
-           "dense_output_MBps": st["dense_bytes"] / (st["wall_ms"] * 1e-3) / 1e6,
-           "dense_bytes": st["dense_bytes"], "wall_ms": st["wall_ms"], "kernel_ms_sum": st["kernel_ms"],
-           "d2h_ms_sum": st["copy_ms"], "steps_per_s_kernel_only": attempts / (st["kernel_ms"] * 1e-3),
-           "roofline_hbm_kernel": {"bound": "hbm", "achieved": hbm, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                   "frac": hbm / PEAK_HBM_GBS, "algorithmic_bytes": algo_bytes},
-           "pcie_GBps": st["dense_bytes"] / (st["copy_ms"] * 1e-3) / 1e9}
-    del eng, host
-    torch.cuda.empty_cache()
-    # The dense kernel by itself, output kept in HBM: 1 M hillslopes x 1 day at 1-minute stride (57.6 GB of
+    q = synth.minute_queries(0.0, tf, 1.0)[1:]            # t = 1 .. tf: `days` x 1440 rows per hillslope
+    W = args.dense_window
+    need = 2 * ns * W * 40                                # two pinned staging buffers
+    avail = _host_bytes_available()
+    if avail is not None and need > 0.5 * avail:          # a small or shared host: fewer hillslopes, same shape
+        ns = max(65536, int(0.5 * avail / (2 * W * 40)) // 65536 * 65536)
+    sp, y0, cells = synth.model204_params(0, ns), synth.model204_y0(ns), synth.cell_of_system(0, ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days)
+
+    def streamed(states):
+        eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, alloc_dense=False, math_mode=math, device=dev, dense_states=states)
+        eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+        eng.integrate_streamed_sink(W)                    # warm-up (also faults the staging pages in)
+        torch.cuda.synchronize()
+        st = eng.integrate_streamed_sink(W)
+        att = eng.total_attempts()
+        del eng
+        torch.cuda.empty_cache()
+        return st, att
+    st, attempts = streamed(None)
+    st1, _ = streamed((1,))
+    out["streamed"] = {
+        "workload": f"Model 204, {ns} hillslopes, {days} day(s), query every 1 min (nq={len(q)}), {st['windows']} windows of {W} queries "
+                    f"through two pinned host staging buffers (sink = discard), math={args.math}",
+        "dense_output_MBps": st["dense_bytes"] / (st["wall_ms"] * 1e-3) / 1e6,
+        "dense_bytes": st["dense_bytes"], "wall_ms": st["wall_ms"], "kernel_ms_sum": st["kernel_ms"], "d2h_ms_sum": st["copy_ms"],
+        "pcie_GBps": st["dense_bytes"] / (st["copy_ms"] * 1e-3) / 1e9,
+        "copy_engine_busy_fraction_of_wall": st["copy_ms"] / st["wall_ms"],
+        "kernel_fraction_of_wall": st["kernel_ms"] / st["wall_ms"],
+        "steps_per_s_wall": attempts / (st["wall_ms"] * 1e-3),
+        "one_state_selected_on_device": {"states": [1], "dense_bytes": st1["dense_bytes"], "wall_ms": st1["wall_ms"],
+                                         "kernel_ms_sum": st1["kernel_ms"], "d2h_ms_sum": st1["copy_ms"],
+                                         "wall_speedup_vs_all_states": st["wall_ms"] / st1["wall_ms"]}}
+    out["dense_output_MBps"] = out["streamed"]["dense_output_MBps"]
+    del sp, y0, cells
+
+    # ---- the dense kernel by itself, output kept in HBM: 1 M hillslopes x 1 day at 1-minute stride (57.6 GB of
     # rows) in the tile layout [tile][q][comp][lane] with wave-synchronous stores (hlm_rk45_dense_kernel.h).
-    # This is the HBM-bound kernel of the path: its roofline is the 8 TB/s spec peak; a pure fill of the
-    # same 57.6 GB reaches 4.8 TB/s on this GPU (tools/hbm_write_probe.py).
+    # This is the HBM-bound kernel of the path: its roofline is the 8 TB/s spec peak.
     ns2, days2 = args.dense_hbm_ns, 1
     if ns2 > 0:
+        free_b, _ = torch.cuda.mem_get_info()
+        if 40.0 * ns2 * 1440 > 0.8 * free_b:              # a smaller or shared card: as many whole 64 K blocks as fit
+            ns2 = max(65536, int(0.8 * free_b / (40.0 * 1440)) // 65536 * 65536)
         tf2 = days2 * 1440.0
         q2 = synth.minute_queries(0.0, tf2, 1.0)
         pr2, t2, dt2, nT2 = synth.forcing_tables(days=days2)
         e2 = ShardEngine(H.Model204, synth.model204_y0(ns2), 0.0, tf2, sp=synth.model204_params(0, ns2), query=q2,
-                         math_mode=H.MATH_FAST if args.math == "fast" else H.MATH_STRICT,
-                         device=f"cuda:{torch.cuda.current_device()}", dense_tiled=2)
+                         math_mode=math, device=dev, dense_tiled=2)
         e2.expand_forcings_on_device((pr2, t2), synth.cell_of_system(0, ns2), dt2, nT2)
         e2.integrate()
         torch.cuda.synchronize()
         ms = []
-        for _ in range(3):
+        for _ in range(5):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             a.record()
             e2.integrate()
@@ -267,6 +308,7 @@ def dense_section(args):
             "workload": f"Model 204, {ns2} hillslopes, {days2} day, query every 1 min (nq={len(q2)}): {40.0 * ns2 * len(q2) / 1e9:.1f} GB "
                         "of rows kept in HBM, tile layout, wave-synchronous stores",
             "kernel_ms": k, "kernel_ms_each": ms, "attempts_per_hillslope": e2.total_attempts() / ns2,
+            "steps_per_s": e2.total_attempts() / (k * 1e-3),
             "roofline": {"bound": "hbm", "achieved": ab / (k * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": ab / (k * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": ab,
                          "kernel": "hlm::rk45_dense_ring_kernel<Model204Dev>",
@@ -274,7 +316,107 @@ def dense_section(args):
                                  "on an MI355X of this pool (tools/hbm_write_probe.py, profiles/r02_hbm_write_probe.txt)"}}
         del e2
         torch.cuda.empty_cache()
+
+    # ---- one GPU's share of BASELINE config 5: 4 M hillslopes / 8 GPUs, 30 days, queries 0, 1, ..., 43 200 --------
+    ns3, days3 = args.c5_ns, args.c5_days
+    if ns3 > 0:
+        tf3 = days3 * 1440.0
+        q3 = synth.minute_queries(0.0, tf3, 1.0)          # 0 .. tf: days x 1440 + 1 queries
+        W3 = 1440
+        free_b, _ = torch.cuda.mem_get_info()
+        if 40.0 * ns3 * W3 > 0.8 * free_b:
+            ns3 = max(65536, int(0.8 * free_b / (40.0 * W3)) // 65536 * 65536)
+        pr3, t3, dt3, nT3 = synth.forcing_tables(days=days3)
+        e3 = ShardEngine(H.Model204, synth.model204_y0(ns3), 0.0, tf3, sp=synth.model204_params(0, ns3), query=q3,
+                         math_mode=math, device=dev, dense_tiled=2, alloc_dense=False)
+        e3.expand_forcings_on_device((pr3, t3), synth.cell_of_system(0, ns3), dt3, nT3)
+        tiles = -(-ns3 // 64)
+        window = torch.empty(tiles * 64 * W3 * 5, dtype=torch.float64, device=dev)   # ONE window buffer, reused
+        resume = torch.zeros(H.api.resume_bytes(ns3, H.Model204), dtype=torch.uint8, device=dev)
+        stream = torch.cuda.current_stream()
+        nwin = -(-len(q3) // W3)
+
+        def span():
+            evs = []
+            for kwin in range(nwin):
+                j = e3.job()
+                j.d_dense, j.dense_tiled = window.data_ptr(), 2
+                j.query_begin, j.query_end = kwin * W3, min((kwin + 1) * W3, len(q3))
+                j.d_resume, j.resume_in = resume.data_ptr(), int(kwin > 0)
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record()
+                H.api.integrate_device(j, stream)
+                b.record()
+                evs.append((a, b))
+            torch.cuda.synchronize()
+            return [a.elapsed_time(b) for a, b in evs]
+        span()                                            # warm-up
+        t0 = time.perf_counter()
+        kms = span()
+        wall3 = time.perf_counter() - t0
+        att3 = e3.total_attempts()
+        rows_b = 40.0 * ns3 * len(q3)
+        ab3 = rows_b + ns3 * B_SYS + 4.0 * sum(e3.forc_nT) * ns3
+        ksum = float(np.sum(kms))
+        out["c5_share"] = {
+            "workload": f"one GPU's share of BASELINE config 5: Model 204, {ns3} hillslopes, {days3} days, queries 0..{int(tf3)} min "
+                        f"(nq={len(q3)}): {rows_b / 1e9:.0f} GB of rows in {nwin} query windows of {W3} reusing one "
+                        f"{40.0 * ns3 * W3 / 1e9:.1f} GB HBM buffer (rows not copied out), resume record between windows",
+            "windows": nwin, "kernel_ms_sum": ksum, "wall_ms": wall3 * 1e3, "kernel_ms_each": kms,
+            "sustained_TBps": ab3 / (ksum * 1e-3) / 1e12, "frac_of_hbm_spec": ab3 / (ksum * 1e-3) / 1e9 / PEAK_HBM_GBS,
+            "steps_per_s": att3 / (ksum * 1e-3), "attempts_per_hillslope": att3 / ns3,
+            "flagged_fraction": float((e3.stiff != 0).sum().item()) / ns3,
+            "pcie_seconds_for_these_rows_at_the_streamed_rate": rows_b / (out["streamed"]["pcie_GBps"] * 1e9),
+            "note": "delivered to the host this span is PCIe-bound: the copy engine would need the seconds above, the kernels "
+                    "the kernel_ms_sum; with one state selected on the device a fifth of that"}
+        del e3, window, resume
+        torch.cuda.empty_cache()
     return out
+
+
+def driver_e2e_section(args):
+    """The C++ driver end to end on the headline workload: tools/rk45_solver reads a params CSV (1 M rows), a lookup
+    CSV and (time, lat, lon) NetCDF forcings, uploads, integrates 30 days (run_rk45<Model204> in its three phases),
+    copies back and writes final.nc -- with its own phase timers (the reference's only timer sits around its NetCDF
+    writer, main.cpp:809-823).  Inputs are written here first (not timed).  A separate process on the same GPU."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe, mk = os.path.join(ROOT, "tools", "rk45_solver"), os.path.join(ROOT, "tools", "hlm_forcing_nc")
+    if not (os.path.exists(exe) and os.path.exists(mk)):
+        return {"error": "tools/rk45_solver or tools/hlm_forcing_nc not built (needs the HDF5 C library)"}
+    ns, days = args.ns_per_gpu, args.days
+    tmp = tempfile.mkdtemp(prefix="hlm_e2e_", dir="/tmp")
+    try:
+        sp = synth.model204_params(0, ns)
+        cells = synth.cell_of_system(0, ns)
+        pr, t2m, dt, nT = synth.forcing_tables(days=days)
+        pcsv, lcsv = os.path.join(tmp, "params.csv"), os.path.join(tmp, "lookup.csv")
+        synth.write_params_csv(pcsv, sp)
+        synth.write_lookup_csv(lcsv, sp["stream"], cells, nlon=32)
+        for name, tab in (("pr", pr), ("t2m", t2m)):
+            raw = os.path.join(tmp, name + ".f32")
+            np.ascontiguousarray(tab, dtype="<f4").tofile(raw)   # [T][1024] = [T][32][32]
+            subprocess.run([mk, os.path.join(tmp, name + ".nc"), name, str(tab.shape[0]), "32", "32", raw], check=True)
+        cmd = [exe, "--model", "204", "--params", pcsv, "--tf", str(days * 1440.0), "--nq", "0", "--initial-step", "0.01",
+               "--forcing-nc", os.path.join(tmp, "pr.nc") + ":pr:1", "--forcing-nc", os.path.join(tmp, "t2m.nc") + ":t2m:24",
+               "--lookup", lcsv, "--math", args.math, "--out-format", "nc", "--out-final", os.path.join(tmp, "final.csv"),
+               "--out-dense", os.path.join(tmp, "dense.csv"), "--device", str(torch.cuda.current_device())]
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            return {"error": "rk45_solver exit %d: %s" % (p.returncode, p.stderr[-400:])}
+        line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+        ph = line["phases"]
+        return {"workload": f"tools/rk45_solver: Model 204, {ns} hillslopes, {days} days, params CSV ({os.path.getsize(pcsv) / 1e6:.0f} MB) + lookup CSV "
+                            f"+ NetCDF pr / t2m on a 32x32 grid (per-cell table), final.nc ({os.path.getsize(os.path.join(tmp, 'final.nc')) / 1e6:.0f} MB), math={args.math}",
+                "process_wall_s": wall, "phases_s": ph, "attempted_steps": line["attempted_steps"], "flagged": line["flagged"],
+                "steps_per_s_integrate_phase": line["attempted_steps"] / ph["integrate_s"],
+                "steps_per_s_whole_process": line["attempted_steps"] / wall,
+                "dominant_host_phase": max((k for k in ph if k != "integrate_s"), key=lambda k: ph[k])}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def c2_dummy_section(args):
@@ -717,6 +859,11 @@ def main():
         out["dense_output"] = _optional(dense_section, args)
     if rank == 0 and world == 1 and not args.no_variants:
         out["c2_dummy"] = _optional(c2_dummy_section, args)
+
+    if rank == 0 and world == 1 and not args.no_variants:
+        out["driver_e2e"] = _optional(driver_e2e_section, args)
+        if "phases_s" in out["driver_e2e"]:   # the driver's integrate phase against this run's kernel time
+            out["driver_e2e"]["integrate_over_kernel"] = out["driver_e2e"]["phases_s"]["integrate_s"] / (k_ms * 1e-3)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = _optional(cpu_baseline, args)

@@ -296,6 +296,17 @@ typedef struct hlm_stream_stats {
 } hlm_stream_stats;
 int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, double* h_dense,
                                 void* hip_stream, hlm_stream_stats* stats);
+/* The same pipeline for dense output that does not fit in host memory either (BASELINE config 5 on its real
+ * size: 500 000 hillslopes x 43 201 queries = 864 GB per GPU): every window lands in one of two PINNED host
+ * staging buffers the library owns, and `sink` is called on the calling thread as soon as its bytes are there,
+ * h_rows = [ns][query_end - query_begin][K] (K = N_EQ or the job's output selection), valid until the sink
+ * returns -- while the next window integrates and the one after is copied.  A consumer writes the rows to its
+ * file (the reference: write_dense_netcdf, I_O/output_series.cpp:18-72, one call for the whole array).
+ * sink == NULL discards the rows (measurement of the pipeline itself).  A non-zero return of the sink ends the
+ * run with HLM_ERR_STATE.  stats->dense_bytes counts the bytes delivered. */
+typedef int (*hlm_window_sink)(void* user, int query_begin, int query_end, const double* h_rows);
+int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queries, hlm_window_sink sink, void* user,
+                                     void* hip_stream, hlm_stream_stats* stats);
 /* Forcing series streamed through HBM in time chunks (BASELINE config 3: "NetCDF precip+t2m
  * forcings streamed").  h_tables[j]: HOST float [job->forc_nT[j]][job->forc_ld] of forcing j
  * (pinned memory makes the uploads asynchronous); job->d_forc is ignored.  The window [t0, tf]

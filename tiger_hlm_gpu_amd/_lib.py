@@ -69,6 +69,9 @@ class StreamStats(C.Structure):
                 ("windows", C.c_int), ("dense_bytes", C.c_uint64)]
 
 
+# hlm_window_sink: int (*)(void* user, int query_begin, int query_end, const double* h_rows)
+WINDOW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double))
+
 # name -> (restype, argtypes); every symbol include/hlm_hip.h declares
 SIGNATURES = {
     "hlm_abi_version": (C.c_int, []),
@@ -107,6 +110,8 @@ SIGNATURES = {
     "hlm_resume_bytes_model": (C.c_size_t, [C.c_int, C.c_int]),
     "hlm_rk45_integrate_streamed": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p,
                                               C.POINTER(StreamStats)]),
+    "hlm_rk45_integrate_streamed_sink": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                                   C.POINTER(StreamStats)]),
     "hlm_rk45_integrate_forcing_streamed": (C.c_int, [C.POINTER(DeviceJob), C.POINTER(C.c_void_p), C.c_double,
                                                       C.c_void_p, C.POINTER(C.c_int)]),
     "hlm_rk45_integrate_compacting": (C.c_int, [C.POINTER(DeviceJob), C.c_double, C.c_void_p, C.POINTER(C.c_int)]),

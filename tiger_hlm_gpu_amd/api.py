@@ -316,6 +316,37 @@ def integrate_streamed(job, window_queries, h_dense, stream=None):
             "dense_bytes": st.dense_bytes}
 
 
+def integrate_streamed_sink(job, window_queries, sink=None, stream=None):
+    """Dense output streamed window by window through pinned staging buffers of the library into ``sink``
+    (hlm_rk45_integrate_streamed_sink): ``sink(query_begin, query_end, rows)`` is called with a numpy VIEW
+    [ns, query_end - query_begin, K] of the staging buffer, valid until it returns (copy what is kept); it may
+    return a non-zero int to stop the run.  sink=None discards the rows.  Returns the stats dict."""
+    s = None if stream is None else (stream if isinstance(stream, int) else stream.cuda_stream)
+    ns = job.num_systems
+    width = job.dense_ncomp if job.dense_ncomp > 0 else model_info(job.uid)[0]
+    err = []
+
+    def trampoline(_user, qb, qe, ptr):
+        try:
+            rows = np.ctypeslib.as_array(ptr, shape=(ns, qe - qb, width))
+            r = sink(qb, qe, rows)
+            return int(r) if r else 0
+        except BaseException as ex:  # never let an exception cross the C frame
+            err.append(ex)
+            return -1
+    cb = _lib.WINDOW_SINK(trampoline) if sink is not None else None
+    st = _lib.StreamStats()
+    try:
+        check(lib().hlm_rk45_integrate_streamed_sink(C.byref(job), int(window_queries), C.cast(cb, C.c_void_p) if cb else None,
+                                                     None, s, C.byref(st)))
+    except HlmError:
+        if err:
+            raise err[0]
+        raise
+    return {"wall_ms": st.wall_ms, "kernel_ms": st.kernel_ms, "copy_ms": st.copy_ms, "windows": st.windows,
+            "dense_bytes": st.dense_bytes}
+
+
 def resume_bytes(ns, model=None):
     """Bytes of the integrator-state record of ``ns`` systems ((N_EQ + 2) doubles + 5 int32 each)."""
     if model is None:

@@ -851,6 +851,105 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
     return rc;
 }
 
+int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queries, hlm_window_sink sink, void* user,
+                                     void* hip_stream, hlm_stream_stats* stats)
+{
+    if (!job) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
+    hlm_device_job probe = *job;  // d_dense / window fields of the caller's job are ignored
+    probe.d_dense = reinterpret_cast<double*>(sizeof(double));
+    probe.query_begin = probe.query_end = probe.resume_in = 0;
+    probe.d_resume = nullptr;
+    int rc = validate_job(&probe);
+    if (rc != HLM_SUCCESS) return rc;
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    const int ns = job->num_systems, nq = job->num_queries;
+    if (nq <= 0 || ns <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "streamed dense output needs num_systems, num_queries > 0");
+    if (window_queries <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "window_queries must be > 0");
+    const int W = window_queries < nq ? window_queries : nq;
+    const int nwin = (nq + W - 1) / W;
+    const size_t row = (size_t)job_row_width(job) * sizeof(double);
+    const size_t win_bytes = (size_t)ns * (size_t)W * row;
+
+    hipStream_t compute = static_cast<hipStream_t>(hip_stream), copy = nullptr;
+    double* buf[2] = {nullptr, nullptr};   // device windows [ns][W][K] (host order: one contiguous copy each)
+    double* hbuf[2] = {nullptr, nullptr};  // pinned host staging
+    void* resume = nullptr;
+    hipEvent_t done_k[2] = {nullptr, nullptr}, done_c[2] = {nullptr, nullptr};
+    std::vector<hipEvent_t> ev((size_t)nwin * 4, nullptr);
+    hipError_t e = hipSuccess;
+    auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
+    ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+        if (b == 0 || nwin > 1) {
+            ok(hipMalloc((void**)&buf[b], win_bytes));
+            ok(hipHostMalloc((void**)&hbuf[b], win_bytes, hipHostMallocDefault));
+        }
+        ok(hipEventCreateWithFlags(&done_k[b], hipEventDisableTiming));
+        ok(hipEventCreateWithFlags(&done_c[b], hipEventDisableTiming));
+    }
+    ok(hipMalloc(&resume, hlm_resume_bytes_model(job->uid, ns)));
+    for (auto& x : ev) ok(hipEventCreate(&x));
+    if (e == hipSuccess) ok(hipStreamSynchronize(compute));  // setup done: the clock starts here
+    const auto host_t0 = std::chrono::steady_clock::now();
+    uint64_t delivered = 0;
+    int sink_rc = 0;
+    auto deliver = [&](int k) {  // window k is in hbuf[k & 1] once its copy has finished
+        const int qb = k * W, qe = (qb + W < nq) ? qb + W : nq;
+        if (!ok(hipEventSynchronize(done_c[k & 1]))) return;
+        if (sink) sink_rc = sink(user, qb, qe, hbuf[k & 1]);
+        delivered += (uint64_t)ns * (uint64_t)(qe - qb) * row;
+    };
+    for (int k = 0; k < nwin && e == hipSuccess && rc == HLM_SUCCESS && sink_rc == 0; ++k) {
+        const int b = k & 1, qb = k * W, qe = (qb + W < nq) ? qb + W : nq;
+        hlm_device_job j = *job;
+        j.d_dense = buf[b];
+        j.dense_tiled = 0;
+        j.query_begin = qb;
+        j.query_end = qe;
+        j.d_resume = resume;
+        j.resume_in = k > 0;
+        if (k >= 2) ok(hipStreamWaitEvent(compute, done_c[b], 0));  // device window b has been copied out
+        ok(hipEventRecord(ev[4 * k + 0], compute));
+        if (e == hipSuccess) rc = launch(&j, compute);
+        ok(hipEventRecord(ev[4 * k + 1], compute));
+        ok(hipEventRecord(done_k[b], compute));
+        ok(hipStreamWaitEvent(copy, done_k[b], 0));
+        ok(hipEventRecord(ev[4 * k + 2], copy));
+        // (hbuf[b] is free: the sink of window k - 2 returned during iteration k - 1)
+        ok(hipMemcpyAsync(hbuf[b], buf[b], (size_t)ns * (size_t)(qe - qb) * row, hipMemcpyDeviceToHost, copy));
+        ok(hipEventRecord(ev[4 * k + 3], copy));
+        ok(hipEventRecord(done_c[b], copy));
+        if (k >= 1 && e == hipSuccess && rc == HLM_SUCCESS) deliver(k - 1);
+    }
+    if (e == hipSuccess && rc == HLM_SUCCESS && sink_rc == 0) deliver(nwin - 1);
+    (void)hipStreamSynchronize(compute);
+    (void)hipStreamSynchronize(copy);
+    const auto host_t1 = std::chrono::steady_clock::now();
+    if (e == hipSuccess && rc == HLM_SUCCESS && stats) {
+        float ms = 0.f;
+        stats->windows = nwin;
+        stats->dense_bytes = delivered;
+        for (int k = 0; k < nwin; ++k) {
+            if (hipEventElapsedTime(&ms, ev[4 * k + 0], ev[4 * k + 1]) == hipSuccess) stats->kernel_ms += ms;
+            if (hipEventElapsedTime(&ms, ev[4 * k + 2], ev[4 * k + 3]) == hipSuccess) stats->copy_ms += ms;
+        }
+        (void)hipGetLastError();
+        stats->wall_ms = std::chrono::duration<double, std::milli>(host_t1 - host_t0).count();
+    }
+    for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+    for (int b = 0; b < 2; ++b) {
+        if (buf[b]) (void)hipFree(buf[b]);
+        if (hbuf[b]) (void)hipHostFree(hbuf[b]);
+        if (done_k[b]) (void)hipEventDestroy(done_k[b]);
+        if (done_c[b]) (void)hipEventDestroy(done_c[b]);
+    }
+    if (resume) (void)hipFree(resume);
+    if (copy) (void)hipStreamDestroy(copy);
+    if (e != hipSuccess) return fail(HLM_ERR_HIP, "integrate_streamed_sink: %s", hipGetErrorString(e));
+    if (sink_rc != 0) return fail(HLM_ERR_STATE, "integrate_streamed_sink: the sink returned %d", sink_rc);
+    return rc;
+}
+
 int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* const* h_tables,
                                         double chunk_minutes, void* hip_stream, int* chunks)
 {
@@ -1072,6 +1171,20 @@ int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* scratch_
     if (max_threads) *max_threads = at.maxThreadsPerBlock;
     return HLM_SUCCESS;
 }
+
+#ifdef HLM_PHASE_TIMING
+// experiment builds only (not in include/hlm_hip.h): read (and optionally clear) the phase-cycle sums
+int hlm_debug_phase_cycles(unsigned long long out[8], int reset)
+{
+    HLM_HIP_TRY(hipDeviceSynchronize());
+    if (out) HLM_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(hlm::g_phase_cycles), 8 * sizeof(unsigned long long)));
+    if (reset) {
+        const unsigned long long zero[8] = {};
+        HLM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hlm::g_phase_cycles), zero, sizeof(zero)));
+    }
+    return HLM_SUCCESS;
+}
+#endif
 
 // ---- three-phase host API ----------------------------------------------------------------
 int hlm_setup_gpu_buffers(const double* h_y0, int ns, const double* h_q, int nq, hlm_gpu_buffers* out)

@@ -42,6 +42,16 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 // interpolant (the row arithmetic is a tenth of an iteration) and puts component c into ring column
 // A.dense_pos[c] -- an unselected one into the spare last column, so that no register array is indexed at run
 // time; the flush reads and stores columns 0 .. dense_k-1.  SEL = false is the kernel without any of this.
+#ifdef HLM_PHASE_TIMING
+// Experiment builds only (tools/dense_phase_probe.py): shader-clock cycles every wave spends in the phases of the
+// loop below, summed over all waves: [0] attempt, [1] rows + commit, [2] forcing refresh, [3] flush, [4] iterations,
+// [5] waves.  Read back with hlm_debug_phase_cycles().
+__device__ unsigned long long g_phase_cycles[8];
+#define HLM_STAMP(v) const unsigned long long v = __builtin_readcyclecounter()
+#else
+#define HLM_STAMP(v)
+#endif
+
 template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R, bool SEL = false>
 __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
 {
@@ -160,7 +170,16 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     // stores of the previous flush to be acknowledged by memory -- the stores must drain behind the
     // next attempt's arithmetic instead.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt / lgkmcnt untouched
+#ifdef HLM_PHASE_TIMING
+    unsigned long long ph_a = 0, ph_b = 0, ph_f = 0, ph_c = 0, ph_n = 0;
+#endif
     while (wave_on) {
+        HLM_STAMP(st0);
+#if defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 1
+        __builtin_amdgcn_s_setprio(0);
+#elif defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 2
+        __builtin_amdgcn_s_setprio(1);
+#endif
         int progress = 0;
         // ---- (A) one attempt ------------------------------------------------------------------
         const bool can_step = mode == M_LIVE && t < t_end && n_attempt < A.cap;
@@ -214,6 +233,12 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             }
         }
         const bool owes_zeros = mode == M_ZEROS;
+        HLM_STAMP(st1);
+#if defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 1
+        __builtin_amdgcn_s_setprio(1);
+#elif defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
 
         // ---- (B) rows -------------------------------------------------------------------------
         // slide the query-time window (the lanes' cursors are within R rows of the flush cursor)
@@ -274,6 +299,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             progress = 1;
         }
 
+        HLM_STAMP(st2);
         // ---- (B') the forcing samples of the next attempt ----------------------------------------
         // Fetched here, BEFORE this iteration's row stores are issued: the wait for the load then
         // only covers the stores of the previous flush, which have had a whole iteration to drain
@@ -283,6 +309,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             if (held.refresh(A, P, t, FV)) have_k0 = false;
         }
 
+        HLM_STAMP(st3);
         // ---- (C) flush: row q_flush goes to HBM once every lane is through with it ----------------
         // (Reading all ready rows from the ring before the first store -- one LDS latency per batch --
         // was measured: no gain, 40 more live registers, spills.)
@@ -311,7 +338,19 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             flushed = true;
         }
         wave_on = flushed || __builtin_amdgcn_ballot_w64(progress != 0) != 0ull;
+#ifdef HLM_PHASE_TIMING
+        {
+            HLM_STAMP(st4);
+            ph_a += st1 - st0; ph_b += st2 - st1; ph_f += st3 - st2; ph_c += st4 - st3; ++ph_n;
+        }
+#endif
     }
+#ifdef HLM_PHASE_TIMING
+    if (lane == (int)__builtin_ctzll(__builtin_amdgcn_ballot_w64(true))) {
+        atomicAdd(&g_phase_cycles[0], ph_a); atomicAdd(&g_phase_cycles[1], ph_b); atomicAdd(&g_phase_cycles[2], ph_f);
+        atomicAdd(&g_phase_cycles[3], ph_c); atomicAdd(&g_phase_cycles[4], ph_n); atomicAdd(&g_phase_cycles[5], 1ull);
+    }
+#endif
 
     if (mode == M_PENDING) {
         // the launch's query window ends inside this step: it is given back -- (y, t, h) are still the

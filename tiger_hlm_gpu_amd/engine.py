@@ -240,6 +240,18 @@ class ShardEngine:
         stats = api.integrate_streamed(job, window_queries, arr, s)
         return arr, stats
 
+    def integrate_streamed_sink(self, window_queries, sink=None, stream=None):
+        """BASELINE config 5 at sizes that fit no host array: the dense rows pass window by window through the
+        library's pinned staging buffers into ``sink(query_begin, query_end, rows[ns, W, K])`` (None = discard)."""
+        assert self.nq > 0
+        s = stream if stream is not None else torch.cuda.current_stream(self.device)
+        keep, self.dense = self.dense, None
+        try:
+            job = self.job()
+        finally:
+            self.dense = keep
+        return api.integrate_streamed_sink(job, window_queries, sink, s)
+
     def total_attempts(self):
         return int(self.n_attempt.to(torch.int64).bitwise_and(0xFFFFFFFF).sum().item())
 

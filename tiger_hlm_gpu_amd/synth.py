@@ -118,3 +118,28 @@ def minute_queries(t0, tf, stride=1.0):
     """for (t = t0; t <= tf; t += stride), main.cpp:653-656."""
     n = int(np.floor((tf - t0) / stride + 1e-9)) + 1
     return t0 + stride * np.arange(n, dtype=np.float64)
+
+
+def write_params_csv(path, sp):
+    """The parameter CSV (data/small_test.csv header; parameters_loader.cpp:35-49) whose load gives back ``sp``
+    bit for bit: the loader multiplies i2 / i3 by c = 0.001/60 and res_ss / res_gw by 1440 (:92-101), so the raw
+    columns are written as those quotients (exact for the generator's 4, 1.6, 2 and 55) and everything else with
+    17 significant digits."""
+    cols = ["stream", "next_stream", "drainage_area_km2", "length_km", "area_sqkm", "centroid_lon", "centroid_lat", "hu",
+            "i2", "i3", "sw", "ss", "n", "slope", "res_ss", "res_gw", "melt", "t_thres"]
+    n = sp.shape[0]
+    raw = {
+        "drainage_area_km2": sp["A_h"], "length_km": sp["L"], "area_sqkm": sp["A_h"], "centroid_lon": np.zeros(n),
+        "centroid_lat": sp["lat"], "hu": sp["Hu"], "i2": np.round(sp["infil"] / C_1, 12), "i3": np.round(sp["perco"] / C_1, 12),
+        "sw": sp["sw"], "ss": sp["ss"], "n": sp["n_mann"], "slope": sp["slope"], "res_ss": np.round(sp["alpha3"] / 1440.0, 12),
+        "res_gw": np.round(sp["alpha4"] / 1440.0, 12), "melt": sp["melt_f"], "t_thres": sp["temp_thr"]}
+    import pandas as pd
+    df = pd.DataFrame({"stream": sp["stream"], "next_stream": sp["next_stream"], **{c: raw[c] for c in cols[2:]}})[cols]
+    df.to_csv(path, index=False, float_format="%.17g")
+
+
+def write_lookup_csv(path, streams, cells, nlon=32):
+    """stream,lat_index,lon_index (data/small_example_pr_lookup.csv; forcing_loader.cpp:14-64): cell = lat * nlon + lon."""
+    import pandas as pd
+    cells = np.asarray(cells, dtype=np.int64)
+    pd.DataFrame({"stream": np.asarray(streams, dtype=np.int64), "lat_index": cells // nlon, "lon_index": cells % nlon}).to_csv(path, index=False)

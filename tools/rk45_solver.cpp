@@ -470,7 +470,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
     tp = clk::now();
     if (o.out_format == "csv" || o.out_format == "both") {
         hlm_io::write_final_csv(o.out_final, h_y_final, ns, N_EQ, style);
-        hlm_io::write_dense_csv(o.out_dense, h_dense, h_query_times, ns, N_EQ, style);
+        if (nq > 0) hlm_io::write_dense_csv(o.out_dense, h_dense, h_query_times, ns, N_EQ, style);  // (--nq 0: no dense file)
     }
     if (o.out_format == "nc" || o.out_format == "both") {
 #ifdef HLM_WITH_HDF5
@@ -481,8 +481,9 @@ int run(const Options& o, hlm_io::CsvStyle style)
         auto nc_name = [](std::string p) { const size_t d = p.rfind('.'); return (d == std::string::npos ? p : p.substr(0, d)) + ".nc"; };
         if (o.states.empty()) {
             write_final_netcdf(nc_name(o.out_final), h_y_final.data(), linkid_vals.data(), state_vals.data(), ns, N_EQ, o.nc_compression);
-            write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
-                               (int)nq, ns, N_EQ, o.nc_compression);
+            if (nq > 0)
+                write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
+                                   (int)nq, ns, N_EQ, o.nc_compression);
         } else {
             // config output.states: only these columns; the "variable" coordinate keeps their model indices.
             // Final states always come back whole (they are the next run's initial state); the dense rows
@@ -498,8 +499,9 @@ int run(const Options& o, hlm_io::CsvStyle style)
             }
             const double* dn = width != K ? dn_host.data() : h_dense.data();
             write_final_netcdf(nc_name(o.out_final), yf.data(), linkid_vals.data(), o.states.data(), ns, K, o.nc_compression);
-            write_dense_netcdf(nc_name(o.out_dense), dn, h_query_times.data(), linkid_vals.data(), o.states.data(), (int)nq, ns, K,
-                               o.nc_compression);
+            if (nq > 0)
+                write_dense_netcdf(nc_name(o.out_dense), dn, h_query_times.data(), linkid_vals.data(), o.states.data(), (int)nq, ns, K,
+                                   o.nc_compression);
         }
 #else
         usage("--out-format nc: this binary was built without HDF5 (HLM_WITH_HDF5)");
