@@ -42,6 +42,31 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 // interpolant (the row arithmetic is a tenth of an iteration) and puts component c into ring column
 // A.dense_pos[c] -- an unselected one into the spare last column, so that no register array is indexed at run
 // time; the flush reads and stores columns 0 .. dense_k-1.  SEL = false is the kernel without any of this.
+// Flush of the ring (phase C of the loop below).  1: the number of complete rows is found first, with R independent
+// ballots, and the rows are then moved in a software pipeline -- the LDS reads of row r + 1 are issued before the
+// stores of row r, into a second set of registers (the attempt's temporaries are dead here: they cost nothing).
+// 0: one row per trip, each trip = ballots -> branch -> LDS reads -> wait -> stores: every row paid a full LDS round
+// trip and two VALU -> SALU -> branch chains (measured with the phase counters below: 490 cycles per flushed row).
+#ifndef HLM_FLUSH_PIPELINED
+#define HLM_FLUSH_PIPELINED 1
+#endif
+
+// rows r .. n-1 of a flush: `cur` holds row r (already read from the ring)
+template <int r, int R, int N, class Load, class Store>
+__device__ __forceinline__ void flush_pipeline(int n, int q0, const double (&cur)[N], Load& load, Store& store)
+{
+    if constexpr (r + 1 < R) {
+        if (r + 1 < n) {  // (wave-uniform)
+            double nxt[N];
+            load(q0 + r + 1, nxt);
+            store(q0 + r, cur);
+            flush_pipeline<r + 1, R, N>(n, q0, nxt, load, store);
+            return;
+        }
+    }
+    store(q0 + r, cur);
+}
+
 #ifdef HLM_PHASE_TIMING
 // Experiment builds only (tools/dense_phase_probe.py): shader-clock cycles every wave spends in the phases of the
 // loop below, summed over all waves: [0] attempt, [1] rows + commit, [2] forcing refresh, [3] flush, [4] iterations,
@@ -310,11 +335,57 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         }
 
         HLM_STAMP(st3);
-        // ---- (C) flush: row q_flush goes to HBM once every lane is through with it ----------------
-        // (Reading all ready rows from the ring before the first store -- one LDS latency per batch --
-        // was measured: no gain, 40 more live registers, spills.)
+        // ---- (C) flush: rows go to HBM once every lane is through with them -----------------------------
         bool flushed = false;
-        const unsigned long long paused = __builtin_amdgcn_ballot_w64(mode == M_STUCK);  // they produce nothing more in this launch
+        [[maybe_unused]] const unsigned long long paused = __builtin_amdgcn_ballot_w64(mode == M_STUCK);  // they produce nothing more in this launch
+#if HLM_FLUSH_PIPELINED
+        {
+            // Row q_flush + r - 1 (r = 1 .. R; a lane is never more than R rows ahead of the cursor) is complete when no
+            // lane that still produces rows in this launch lacks it -- and somebody has it: when only paused lanes are
+            // left, their rows belong to the next launch.
+            // Both conditions are monotone in r (who lacks row r lacks row r + 1), so the complete rows are counted
+            // without any chain between the R ballots.  A launch that is not RESUMABLE has no paused lanes.
+            const int ahead = next_q - q_flush;
+            int nready = 0;
+            if constexpr (RESUMABLE) {
+                const unsigned long long active = __builtin_amdgcn_ballot_w64(true);
+#pragma unroll
+                for (int r = 1; r <= R; ++r) {
+                    const unsigned long long lacks = __builtin_amdgcn_ballot_w64(ahead < r);
+                    nready += ((lacks & ~paused) == 0ull && lacks != active) ? 1 : 0;
+                }
+            } else {
+#pragma unroll
+                for (int r = 1; r <= R; ++r) nready += __builtin_amdgcn_ballot_w64(ahead < r) == 0ull ? 1 : 0;
+            }
+            const int room = q_hi - q_flush;
+            nready = nready < room ? nready : (room > 0 ? room : 0);
+            if (nready > 0) {
+                // every lane reads its column of a slot (one wait per row) and stores it: per component 64 lanes x 8 B =
+                // 512 contiguous bytes
+                auto load = [&](int q, double (&v)[NEQ]) {
+                    const lds_double_ptr slot = ring + (q & (R - 1)) * (NEQ * WAVE);
+#pragma unroll
+                    for (int c = 0; c < NEQ; ++c)
+                        if (!SEL || c < K) v[c] = slot[c * WAVE];
+                };
+                auto store = [&](int q, const double (&v)[NEQ]) {
+                    // (a first launch owns every row of its window; a paused lane only the rows it produced)
+                    if (!RESUMABLE || (next_q > q && q >= my_start_q)) {
+                        double* o = row0 + (size_t)(q - qb) * Q_STRIDE;
+#pragma unroll
+                        for (int c = 0; c < NEQ; ++c)
+                            if (!SEL || c < K) o[c * WAVE] = v[c];
+                    }
+                };
+                double first[NEQ];
+                load(q_flush, first);
+                flush_pipeline<0, R, NEQ>(nready, q_flush, first, load, store);
+                q_flush += nready;
+                flushed = true;
+            }
+        }
+#else
         while (q_flush < q_hi) {
             const bool has_row = next_q > q_flush;
             const unsigned long long have = __builtin_amdgcn_ballot_w64(has_row);
@@ -337,6 +408,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             ++q_flush;
             flushed = true;
         }
+#endif
         wave_on = flushed || __builtin_amdgcn_ballot_w64(progress != 0) != 0ull;
 #ifdef HLM_PHASE_TIMING
         {
