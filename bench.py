@@ -825,7 +825,7 @@ def main():
         def _cold():
             e, _ = build_engine(args, rank, world, wet=False, tmin=-5.0)
             res = {"workload": f"C3 as SURVEY 8d writes it: Model 204, {e.ns} hillslopes, {args.days} days, T in [-5, 15], math={args.math}"}
-            for tag, radau in (("rk45", False), ("rk45_plus_radau", True)):
+            for tag, radau in (("rk45", False), ("rk45_plus_radau", True), ("rk45_plus_radau_continue", "continue")):
                 e.integrate(radau=radau)
                 torch.cuda.synchronize()
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -837,6 +837,8 @@ def main():
                 res[tag] = {"ms": ms, "attempts": att, "steps_per_s": att / (ms * 1e-3)}
                 if not radau:
                     res["flagged_fraction"] = float((e.stiff == 1).sum().item()) / e.ns
+                else:
+                    res[tag]["unsolved_after"] = int((e.stiff == 2).sum().item())
             # the same RK45 pass in one-day launches with the survivors compacted between them (bit-identical)
             e.integrate_compacting(1440.0)
             torch.cuda.synchronize()
@@ -847,8 +849,10 @@ def main():
             torch.cuda.synchronize()
             res["rk45_compacting"] = {"ms": a.elapsed_time(b), "launches": nl, "interval_minutes": 1440.0,
                                       "steps_per_s": res["rk45"]["attempts"] / (a.elapsed_time(b) * 1e-3)}
-            res["rk45_plus_radau"]["implicit_attempts"] = res["rk45_plus_radau"]["attempts"] - res["rk45"]["attempts"]
-            res["rk45_plus_radau"]["unsolved_after"] = int((e.stiff == 2).sum().item())
+            for tag in ("rk45_plus_radau", "rk45_plus_radau_continue"):
+                res[tag]["implicit_attempts"] = res[tag]["attempts"] - res["rk45"]["attempts"]
+            res["rk45_plus_radau_continue"]["note"] = ("build option: every flagged hillslope continues from the state RK45 reached "
+                                                       "(the reference's kernel, and rk45_plus_radau, restart it at t0)")
             res["lane_utilisation_rk45_source"] = ("not measured in this run: 40.6 of 64 lanes active per VALU instruction in "
                                                    "profiles/r02_cold_pmc.json (rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, round 2)")
             return res

@@ -132,6 +132,9 @@ inline void set_output_states(const std::vector<int>& comps)
 // Radau-IIA fallback for the systems RK45 flags (the pass rk45_api.hpp:189-247 of the reference
 // attempts inside retrieve_and_free); off by default = the reference's observable behaviour.
 inline void set_radau_fallback(bool on) { detail::check(hlm_set_radau_fallback(on ? 1 : 0), "set_radau_fallback"); }
+// mode 2: the pass continues every flagged system from the state it had reached instead of restarting it at t0
+// (radau_kernel.cu:44-52 restarts); 0 / 1 as set_radau_fallback(false / true)
+inline void set_radau_mode(int mode) { detail::check(hlm_set_radau_fallback(mode), "set_radau_mode"); }
 
 // ---- 1) allocate device buffers & copy inputs ------------------------------------------------
 template <class Model>

@@ -104,8 +104,10 @@ int hlm_set_math_mode(int mode);
 /* 1: the host API's launches without dense output use lane refill (hlm_device_job.lane_refill). */
 int hlm_set_lane_refill(int enabled);
 /* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
- * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free); 0 (default): flagged systems
- * keep stiff = 1 and zero rows, the reference's observable behaviour. */
+ * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free), every flagged system restarting at t0 as
+ * radau_kernel.cu:44-52 does; 2: the same pass CONTINUING from the state each flagged system had reached
+ * (hlm_device_job.d_flag_state); 0 (default): flagged systems keep stiff = 1 and zero rows, the reference's
+ * observable behaviour. */
 int hlm_set_radau_fallback(int enabled);
 /* Output selection of the host API: the reference's run configuration lists the state variables to write
  * (data/config.yaml:44-52 "output.states", parsed by I_O/config_loader.cpp:19-84; the writers take the variable
@@ -253,6 +255,12 @@ typedef struct hlm_device_job {
      * h_dense [ns][nq][K].  0 = all N_EQ components. */
     int dense_ncomp;
     int dense_comp[HLM_MAX_NEQ];
+    /* Radau pass in "continue" mode (build option; the reference's kernel restarts at t0, radau_kernel.cu:44-52):
+     * nullable DEVICE buffer of num_systems x (N_EQ + 1) doubles.  When set, a hillslope the RK45 launch flags
+     * stiff leaves the state it had reached there ({y[N_EQ], t}), and hlm_radau_fallback_device(job) continues
+     * every flagged hillslope from that state -- the rows RK45 wrote up to there stay, nothing before the flag is
+     * integrated twice -- taking the hillslopes flagged earliest (most left to do) first.  NULL: restart at t0. */
+    double* d_flag_state;
 } hlm_device_job;
 
 size_t hlm_resume_bytes_model(int uid, int num_systems); /* (N_EQ + 2) doubles + 5 int32 per system */

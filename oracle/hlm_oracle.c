@@ -340,6 +340,8 @@ static void integrate_one(const hlm_oracle_job* J, int sys)
     if (J->n_attempt) J->n_attempt[sys] = n_attempt;
     if (J->n_accept) J->n_accept[sys] = n_accept;
     if (J->t_reached) J->t_reached[sys] = t;
+    if (J->y_reached)
+        for (int i = 0; i < n; ++i) J->y_reached[(size_t)sys * n + i] = y[i];
     if (capped && t < J->tf) { J->stiff[sys] = HLM_ORACLE_CAPPED; return; }
     if (stiff && t < J->tf) { J->stiff[sys] = HLM_ORACLE_STIFF; return; } /* :167-170 */
     for (int i = 0; i < n; ++i) J->y_final[(size_t)sys * n + i] = y[i]; /* :173-175 */

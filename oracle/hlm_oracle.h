@@ -80,7 +80,13 @@ typedef struct {
     int32_t* stiff;          /* [ns] */
     uint32_t* n_attempt;     /* [ns] nullable */
     uint32_t* n_accept;      /* [ns] nullable */
-    double* t_reached;       /* [ns] nullable: time at which the loop stopped (diagnostic) */
+    double* t_reached;       /* [ns] nullable: time at which the loop stopped */
+    double* y_reached;       /* [ns][N_EQ] nullable: the state at t_reached (what a flagged system had reached) */
+    /* hlm_oracle_radau_run only.  0: every flagged system restarts from (t0, y0), as the reference's kernel does
+     * (radau_kernel.cu:44-52).  1 (build option, needs t_reached and y_reached of the RK45 run): it CONTINUES
+     * from the state at which RK45 gave up -- the rows RK45 wrote up to there stay, the implicit method takes
+     * over from (t_reached, y_reached) with the first step initialStep. */
+    int radau_continue;
 } hlm_oracle_job;
 
 /* The whole integration, rk45_kernel.cu:17-176.  Returns 0, or -1 on bad arguments. */

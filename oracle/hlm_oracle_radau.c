@@ -142,10 +142,16 @@ static void radau_one(const hlm_oracle_job* J, int sys)
     double* dense = J->nq ? J->dense_raw + (size_t)sys * hlm_oracle_neq(J->uid) * nq : NULL;
     const int n = hlm_oracle_neq(J->uid);
     double y[NEQ];
-    for (int i = 0; i < n; ++i) y[i] = J->y0[(size_t)sys * n + i];
-    if (dense) memset(dense, 0, sizeof(double) * n * nq);
-
     double t = J->t0, h = P->initialStep;
+    if (J->radau_continue) {
+        /* continue from where RK45 gave up: its rows up to there (queries <= t_reached) stay as they are, the
+         * later ones are still zero */
+        t = J->t_reached[sys];
+        for (int i = 0; i < n; ++i) y[i] = J->y_reached[(size_t)sys * n + i];
+    } else {
+        for (int i = 0; i < n; ++i) y[i] = J->y0[(size_t)sys * n + i];
+        if (dense) memset(dense, 0, sizeof(double) * n * nq);
+    }
     int next_q = 0, capped = 0;
     uint32_t n_attempt = 0, n_accept = 0;
     while (next_q < J->nq && J->query[next_q] <= t) ++next_q; /* never produced: stay 0 */
@@ -300,6 +306,7 @@ int hlm_oracle_radau_run(const hlm_oracle_job* J)
 {
     if (!J || J->ns < 0 || !J->stiff || !J->y_final || !J->y0) return -1;
     if (J->nq > 0 && (!J->query || !J->dense_raw)) return -1;
+    if (J->radau_continue && (!J->t_reached || !J->y_reached)) return -1;
     int sys;
 #ifdef _OPENMP
 #pragma omp parallel for schedule(dynamic, 1)

@@ -49,6 +49,7 @@ class _Job(C.Structure):
         ("attempt_cap", C.c_uint32), ("nthreads", C.c_int),
         ("y_final", C.c_void_p), ("dense_raw", C.c_void_p), ("stiff", C.c_void_p),
         ("n_attempt", C.c_void_p), ("n_accept", C.c_void_p), ("t_reached", C.c_void_p),
+        ("y_reached", C.c_void_p), ("radau_continue", C.c_int),
     ]
 
 
@@ -151,11 +152,13 @@ def rk45_dense(y, k, h, theta):
 
 def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT=None,
         params=DEFAULT_PARAMS, forc_stub_f64=None, fixed_step=0.0, attempt_cap=0, nthreads=0,
-        reorder=True, radau=False, radau_only=False, fma=False):
+        reorder=True, radau=False, radau_only=False, fma=False, radau_continue=False):
     """Integrate; returns dict(y_final[ns,5], dense[ns,nq,5] (or raw [ns,5,nq]), stiff, n_attempt, n_accept).
 
     radau=True re-integrates the systems RK45 flagged with the Radau-IIA fallback
     (hlm_oracle_radau_run); radau_only=True skips RK45 and sends every system through it.
+    radau_continue=True (with radau): the flagged systems continue from the state RK45 reached instead of
+    restarting at t0 (hlm_oracle_job.radau_continue).
     fma=True runs the FMA-contracted build instead: NOT a reference, only the yardstick for how far
     two valid roundings of the same computation separate on this input."""
     n = neq(uid)
@@ -191,6 +194,9 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     treach = np.zeros(ns)
     j.y_final, j.dense_raw, j.stiff, j.n_attempt, j.n_accept = _p(yf), _p(raw), _p(stiff), _p(na), _p(nacc)
     j.t_reached = _p(treach)
+    yreach = np.zeros((ns, n))
+    j.y_reached = _p(yreach)
+    j.radau_continue = 1 if (radau_continue and not radau_only) else 0
     if radau_only:
         stiff[:] = 1
         yf[:] = 0.0
@@ -206,4 +212,5 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     if nq and reorder:
         dense = np.empty((ns, nq, n))
         lib().hlm_oracle_reorder_dense_n(_p(raw), _p(dense), ns, nq, n)
-    return {"y_final": yf, "dense": dense, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "t_reached": treach}
+    return {"y_final": yf, "dense": dense, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "t_reached": treach,
+            "y_reached": yreach}

@@ -53,7 +53,7 @@ def test_struct_layouts_match_header(hlm, tmp_path):
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
-    assert len(hlm._lib.DeviceJob._fields_) == 35 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
+    assert len(hlm._lib.DeviceJob._fields_) == 36 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
 
 
 def test_registry_roundtrip_and_validation_without_gpu(hlm):
@@ -326,3 +326,27 @@ def test_model_info_and_toy_model_host_side(hlm, oracle):
         a = hlm.ToyModel3.rhs(0.0, y, sp[i], (0.03,))
         b = oracle.rhs(oracle.UID_TOY3, np.array(y), sp[i:i + 1], (0.03,))
         assert np.allclose(a, b, rtol=1e-15, atol=0)
+
+
+def test_piece_count_of_chunked_launches_is_bounded(hlm):
+    """hlm_rk45_integrate_compacting / _forcing_streamed cut [t0, tf] into pieces t0 + k * step: a step below the
+    ulp of t (which repeated addition would never get past) or one that asks for millions of launches is an
+    argument error, raised before anything touches a device (round-2 advisor finding)."""
+    L = hlm._lib.lib()
+    j = hlm._lib.DeviceJob()
+    j.uid, j.num_systems, j.num_queries, j.t0, j.tf = hlm.UID_DUMMY, 64, 0, 0.0, 43200.0
+    j.d_y0 = j.d_y_final = j.d_stiff = 4096  # never dereferenced: the call fails before any launch
+    for k, v in enumerate((0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0)):
+        j.params[k] = v
+    j.math_mode = hlm.MATH_FAST
+    n = C.c_int(-1)
+    for step in (1e-30, 1e-3):
+        rc = L.hlm_rk45_integrate_compacting(C.byref(j), step, None, C.byref(n))
+        assert rc == 1 and b"pieces" in L.hlm_last_error(), (step, rc, L.hlm_last_error())
+    j.uid, j.nforc, j.forc_ld = hlm.UID_204, 1, 64
+    j.d_sp = 4096
+    j.forc_dt_hours[0], j.forc_nT[0] = 1.0, 720
+    tab = np.zeros((720, 64), dtype=np.float32)
+    ptrs = (C.c_void_p * 1)(tab.ctypes.data)
+    rc = L.hlm_rk45_integrate_forcing_streamed(C.byref(j), ptrs, 1e-30, None, None)
+    assert rc == 1 and b"pieces" in L.hlm_last_error()

@@ -1609,6 +1609,53 @@ def test_radau_fallback_matches_oracle(gpu, oracle, per_cell):
         assert np.array_equal(again[k], got[k]), k
 
 
+@pytest.mark.parametrize("layout", [0, 2])
+def test_radau_continue_from_the_flag_state_matches_oracle(gpu, oracle, layout):
+    """Radau "continue" mode (hlm_device_job.d_flag_state; build option -- the reference's kernel restarts at t0,
+    radau_kernel.cu:44-52): the RK45 launch leaves the state of every hillslope it flags, the implicit pass takes
+    over from there, earliest flags first.  Against the oracle's restatement of the same mode: rows before the
+    flag are RK45's (bit for bit the rows of the run without the pass), rows after it and the final state within
+    0.05 of the parity bound where both sides flagged at the same time, fewer implicit attempts than a restart."""
+    H = gpu
+    import torch
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    sp, y0, cells, pr, t2m, dt, nT, q, tf = _cold_case()
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, dense_tiled=layout)
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    eng.integrate()
+    base = eng.results()
+    eng.integrate(radau=True)
+    restart = eng.results()
+    eng.integrate(radau="continue")
+    got = eng.results()
+    ns = len(y0)
+    fs = eng._flag_state.cpu().numpy().reshape(ns, 6)
+    kw = dict(query=q, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    plain = oracle.run(oracle.UID_204, y0, 0.0, tf, **kw)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, tf, radau=True, radau_continue=True, **kw)
+    fl = base["stiff"] == 1
+    assert 20 < fl.sum() < ns and np.array_equal(got["stiff"], base["stiff"])
+    for k in ("y_final", "dense", "n_attempt", "n_accept"):
+        assert np.array_equal(got[k][~fl], base[k][~fl]), k          # hillslopes RK45 finished: untouched
+    assert np.all(np.isfinite(got["y_final"])) and np.all(np.isfinite(got["dense"]))
+    assert np.all(np.abs(got["y_final"][fl]).sum(axis=1) > 0)
+    assert (got["n_attempt"][fl] < restart["n_attempt"][fl]).all()  # nothing before the flag is integrated twice
+    for s in np.flatnonzero(fl):
+        before = q <= fs[s, 5]
+        assert np.array_equal(got["dense"][s][before], base["dense"][s][before])   # RK45's rows stay
+    same = fl & (ref["stiff"] == 1) & (np.abs(fs[:, 5] - plain["t_reached"]) <= 1e-9 * np.maximum(1.0, plain["t_reached"]))
+    assert same.sum() >= 0.9 * fl.sum()
+    assert _scaled_err(fs[same, :5], plain["y_reached"][same]).max() <= 0.05
+    assert _scaled_err(got["y_final"][same], ref["y_final"][same]).max() <= 0.05
+    assert _scaled_err(got["dense"][same], ref["dense"][same]).max() <= 0.05
+    assert q[-1] == tf and _scaled_err(got["dense"][fl][:, -1], got["y_final"][fl]).max() <= 1e-3
+    eng.integrate(radau="continue")                                   # deterministic
+    again = eng.results()
+    for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(again[k], got[k]), k
+
+
 def test_radau_only_dummy_vs_oracle_and_exact_flow(gpu, oracle):
     """Send every DummyModel system through the implicit solver (flags forced to 1): checks the
     kernel on ragged wave counts against the oracle and against the linear system's exact flow."""

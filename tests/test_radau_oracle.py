@@ -89,6 +89,42 @@ def test_radau_rescues_flagged_systems_and_matches_piecewise_scipy(oracle):
     assert _scaled(r["y_final"][s], y).max() <= 5.0  # global error over 120 restarts, kink at Hu included
 
 
+def test_radau_continue_from_the_flag_state_matches_piecewise_scipy(oracle):
+    """radau_continue (build option; the reference's kernel restarts at t0, radau_kernel.cu:44-52): a flagged
+    hillslope keeps the rows RK45 wrote up to the state it reached and the implicit method takes over from there.
+    Checked against SciPy's Radau started at that state and restarted at every forcing sample."""
+    ns, days = 128, 5
+    sp = synth.model204_params(0, ns, seed=3)
+    y0 = synth.model204_y0(ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, ncell=16, seed=5, tmin=-5.0)
+    cells = synth.cell_of_system(0, ns, ncell=16, run_len=16)
+    forc = synth.expand_per_stream(pr, t2m, cells)
+    tf = days * 1440.0
+    q = np.arange(30.0, tf + 1.0, 60.0)
+    kw = dict(sp=sp, forc=forc, forc_dt_h=dt, forc_nT=nT, query=q)
+    k = oracle.run(oracle.UID_204, y0, 0.0, tf, **kw)
+    r = oracle.run(oracle.UID_204, y0, 0.0, tf, radau=True, radau_continue=True, **kw)
+    full = oracle.run(oracle.UID_204, y0, 0.0, tf, radau=True, **kw)
+    fl = k["stiff"] == 1
+    assert 0 < fl.sum() < ns and np.array_equal(r["stiff"], k["stiff"])
+    assert np.array_equal(r["y_final"][~fl], k["y_final"][~fl]) and np.array_equal(r["dense"][~fl], k["dense"][~fl])
+    assert (r["t_reached"][fl] == tf).all() and np.all(np.isfinite(r["y_final"]))
+    assert (r["n_attempt"][fl] < full["n_attempt"][fl]).all()   # nothing before the flag is integrated twice
+    for s in np.nonzero(fl)[0][:4]:
+        t_flag = k["t_reached"][s]
+        before = q <= t_flag
+        assert np.array_equal(r["dense"][s][before], k["dense"][s][before])      # RK45's rows stay
+        assert np.all(np.abs(r["dense"][s][~before]).sum(axis=1) > 0)              # the later ones are filled
+        y, t = k["y_reached"][s].copy(), t_flag
+        while t < tf:
+            hr = min(int(t // 60.0), 24 * days - 1)
+            t1 = min((hr + 1) * 60.0, tf)
+            F = np.array([pr[hr, cells[s]], t2m[min(hr // 24, days - 1), cells[s]]], dtype=np.float32)
+            sol = solve_ivp(lambda tt, yy: oracle.rhs(oracle.UID_204, yy, sp[s:s + 1], F, tt), (t, t1), y, method="Radau", rtol=1e-9, atol=1e-12)
+            y, t = sol.y[:, -1], t1
+        assert _scaled(r["y_final"][s], y).max() <= 5.0
+
+
 def test_radau_attempt_cap_flags_and_zeroes(oracle):
     y0 = synth.dummy_y0(0, 3)
     r = oracle.run(oracle.UID_DUMMY, y0, 0.0, 5.0, query=synth.dummy_query_times(5.0, 20), radau_only=True, attempt_cap=4)

@@ -111,8 +111,11 @@ def set_lane_refill(enabled):
 
 
 def set_radau_fallback(enabled):
-    """Host API (run_rk45 / launch_rk45_kernel): re-integrate flagged systems with Radau IIA."""
-    check(lib().hlm_set_radau_fallback(int(bool(enabled))))
+    """Host API (run_rk45 / launch_rk45_kernel): re-integrate flagged systems with Radau IIA.  False / 0: off
+    (the reference's observable behaviour); True / 1: every flagged system restarts at t0 (radau_kernel.cu:44-52);
+    2 or "continue": it continues from the state it had reached when RK45 flagged it."""
+    mode = 2 if enabled == "continue" else int(enabled)
+    check(lib().hlm_set_radau_fallback(mode))
 
 
 def set_output_states(comps=None):

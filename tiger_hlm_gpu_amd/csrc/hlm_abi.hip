@@ -339,6 +339,7 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     a.stiff = j->d_stiff;
     a.n_attempt = j->d_n_attempt;
     a.n_accept = j->d_n_accept;
+    a.flag_state = j->d_flag_state;
     if (job_selects(j)) {
         a.dense_k = j->dense_ncomp;
         for (int c = 0; c < HLM_MAX_NEQ; ++c) a.dense_pos[c] = -1;
@@ -428,14 +429,32 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     // the flagged systems, compacted IN ORDER: neighbours share a forcing cell and take similar numbers of
     // implicit attempts, so the lanes of a Radau wave finish together (an atomic append scatters them)
     const int nb = (ns + hlm::COMPACT_BLOCK - 1) / hlm::COMPACT_BLOCK;
-    int* scratch = nullptr;  // [0 .. ns) indices of flagged systems | [ns .. ns+nb) block counts | [ns+nb] count
-    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + (size_t)nb + 1), stream));
+    int* scratch = nullptr;  // [0 .. ns) indices of flagged systems | [ns .. ns+nb) block counts | count | base | [ns] time bins
+    const bool by_flag_time = j->d_flag_state != nullptr;
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + (size_t)nb + 2 + (by_flag_time ? (size_t)ns : 0)), stream));
     int* const list = scratch;
     int* const block_count = scratch + ns;
     int* const count = block_count + nb;
-    hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count);
-    hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count);
-    hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count, list);
+    if (!by_flag_time) {
+        hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count);
+        hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, (int*)nullptr);
+        hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count, list);
+    } else {
+        // "continue" mode: the work left is tf - t_flag.  The list is built bin by bin of the flag time (earliest
+        // first: the longest jobs start first, and the lanes of a wave have similar amounts left), in index order
+        // within a bin -- kRadauBins stable compaction passes appending to one list, no host round trip
+        constexpr int kRadauBins = 16;
+        int* const base = count + 1;
+        int* const bin = base + 1;
+        HLM_HIP_TRY(hipMemsetAsync(count, 0, 2 * sizeof(int), stream));
+        hipLaunchKernelGGL(hlm::radau_flag_bin_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, j->d_flag_state,
+                           model_neq(j->uid), ns, j->t0, j->tf, kRadauBins, bin);
+        for (int b = 0; b < kRadauBins; ++b) {
+            hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, bin, b, ns, block_count);
+            hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, base);
+            hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, bin, b, ns, block_count, list);
+        }
+    }
     hlm::Rk45Args a = make_args(j);
     // an implicit attempt costs ~30 us of a wave: the default cap of this pass is 2^20 attempts per
     // system (half a minute), not the RK45 loop's 2^24, so a hopeless system cannot hold a wave for long
@@ -452,6 +471,26 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(scratch, stream));  // stream-ordered: after the kernels above
     HLM_HIP_TRY(launched);
+    return HLM_SUCCESS;
+}
+
+// Edges t0 = e_0 < e_1 < ... < e_n = tf of a window cut into pieces of `step` minutes, as t0 + k * step (never by
+// repeated addition: a step below the ulp of t would not advance, and the piece count is bounded up front).
+constexpr int kMaxPieces = 1 << 20;
+int chunk_edges(double t0, double tf, double step, std::vector<double>* edge, const char* what)
+{
+    edge->assign(1, t0);
+    if (!(tf > t0)) return HLM_SUCCESS;  // nothing to integrate: no pieces
+    const double n = std::ceil((tf - t0) / step);
+    if (!(n >= 1.0) || n > (double)kMaxPieces)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "%s: %g minutes per piece cuts [%g, %g] into %g pieces (at most %d)", what, step, t0, tf, n, kMaxPieces);
+    const int np = (int)n;
+    edge->reserve((size_t)np + 1);
+    for (int k = 1; k < np; ++k) {
+        const double e = t0 + (double)k * step;
+        if (e > edge->back() && e < tf) edge->push_back(e);
+    }
+    edge->push_back(tf);
     return HLM_SUCCESS;
 }
 
@@ -692,7 +731,7 @@ int hlm_set_output_states(int n, const int* comps)
 
 int hlm_set_radau_fallback(int enabled)
 {
-    if (enabled != 0 && enabled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "radau fallback flag %d (want 0 or 1)", enabled);
+    if (enabled < 0 || enabled > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "radau fallback mode %d (0 off, 1 restart at t0, 2 continue from the flag state)", enabled);
     std::lock_guard<std::mutex> lk(g_mu);
     g_radau = enabled;
     return HLM_SUCCESS;
@@ -972,8 +1011,8 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
     const size_t ld = (size_t)job->forc_ld;
 
     // chunk edges and, per chunk and forcing, the sample rows any t in [ta, tb] can ask for
-    std::vector<double> edge{job->t0};
-    while (edge.back() < job->tf) edge.push_back(std::fmin(job->tf, edge.back() + chunk_minutes));
+    std::vector<double> edge;
+    if (const int rce = chunk_edges(job->t0, job->tf, chunk_minutes, &edge, "integrate_forcing_streamed"); rce != HLM_SUCCESS) return rce;
     const int nchunk = (int)edge.size() - 1;
     if (nchunk <= 0) return launch(&probe, static_cast<hipStream_t>(hip_stream)) /* tf <= t0: nothing to integrate */;
     auto span = [&](int j, double ta, double tb, uint64_t* first, uint64_t* rows) {
@@ -1053,8 +1092,8 @@ int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_min
     const int ns = job->num_systems;
     if (ns == 0) return HLM_SUCCESS;
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    std::vector<double> edge{job->t0};
-    while (edge.back() < job->tf) edge.push_back(std::fmin(job->tf, edge.back() + interval_minutes));
+    std::vector<double> edge;
+    if (const int rce = chunk_edges(job->t0, job->tf, interval_minutes, &edge, "integrate_compacting"); rce != HLM_SUCCESS) return rce;
     const int nchunk = (int)edge.size() - 1;
     if (nchunk <= 1) {  // one interval (or tf <= t0): nothing to compact
         rc = launch(job, stream);
@@ -1080,11 +1119,12 @@ int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_min
         j.use_t_stop = edge[k + 1] < job->tf;
         j.t_stop = edge[k + 1];
         KernelFn fn = pick(j.uid, j.math_mode, false, j.fixed_step > 0.0, true);
+        if (!fn) { e = hipSuccess; rc = fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j.uid); break; }
         hlm::Rk45Args a = make_args(&j);
         if (k > 0) {
             // the systems still integrating, in their original order
             hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, (int)hlm::SYS_PAUSED, ns, block_count);
-            hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count);
+            hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, (int*)nullptr);
             hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, (int)hlm::SYS_PAUSED, ns, block_count, index);
             a.index = index;
             a.index_count = count;
@@ -1290,13 +1330,20 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
         return fail(HLM_ERR_INVALID_ARGUMENT, "the Radau fallback needs the forcing series resident in HBM "
                                               "(hlm_set_forcings), not streamed in time chunks");
     int rc;
+    double* flag_state = nullptr;  // Radau "continue" mode: where the RK45 launch leaves the state of a flagged system
+    if (radau == 2 && j.num_systems > 0) {
+        HLM_HIP_TRY(hipMalloc((void**)&flag_state, sizeof(double) * (size_t)j.num_systems * (size_t)(model_neq(uid) + 1)));
+        j.d_flag_state = flag_state;
+    }
     if (streamed)
         rc = hlm_rk45_integrate_forcing_streamed(&j, host_tables, chunk_minutes, nullptr, nullptr);
     else
         rc = hlm_rk45_integrate_device(&j, nullptr);
     if (rc == HLM_SUCCESS && radau) rc = hlm_radau_fallback_device(&j, nullptr);  // rk45_api.hpp:189-247
+    const hipError_t es = hipDeviceSynchronize();  // rk45_api.hpp:150
+    if (flag_state) (void)hipFree(flag_state);
     if (rc != HLM_SUCCESS) return rc;
-    HLM_HIP_TRY(hipDeviceSynchronize());  // rk45_api.hpp:150
+    HLM_HIP_TRY(es);
     return HLM_SUCCESS;
 }
 

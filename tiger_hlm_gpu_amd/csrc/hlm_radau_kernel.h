@@ -276,12 +276,22 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     const double tf = A.tf;
     int next_q = 0;
     uint32_t n_attempt = 0, n_accept = 0;
-    // queries at or before t0 are never produced: zero rows
-    while (next_q < A.nq && A.query[next_q] <= t) {
+    if (A.flag_state) {
+        // "continue" mode (hlm_device_job.d_flag_state): take over from the state at which RK45 gave up; the rows
+        // it wrote up to there stay, the later ones (zero so far) are this pass's
+        const double* fs = A.flag_state + (size_t)sys * (NEQ + 1);
 #pragma unroll
-        for (int c = 0; c < NEQ; ++c)
-            if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
-        ++next_q;
+        for (int i = 0; i < NEQ; ++i) y[i] = fs[i];
+        t = fs[NEQ];
+        while (next_q < A.nq && A.query[next_q] <= t) ++next_q;
+    } else {
+        // restart at t0 (radau_kernel.cu:44-52); queries at or before t0 are never produced: zero rows
+        while (next_q < A.nq && A.query[next_q] <= t) {
+#pragma unroll
+            for (int c = 0; c < NEQ; ++c)
+                if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
+            ++next_q;
+        }
     }
 
     auto sample = [&](int j, double& tb) -> double {

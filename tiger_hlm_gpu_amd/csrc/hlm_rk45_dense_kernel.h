@@ -50,6 +50,12 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 #ifndef HLM_FLUSH_PIPELINED
 #define HLM_FLUSH_PIPELINED 1
 #endif
+#ifndef HLM_DENSE_DRAIN
+#define HLM_DENSE_DRAIN 0
+#endif
+#ifndef HLM_DENSE_PRIO_LEVEL
+#define HLM_DENSE_PRIO_LEVEL 1
+#endif
 
 // rows r .. n-1 of a flush: `cur` holds row r (already read from the ring)
 template <int r, int R, int N, class Load, class Store>
@@ -198,6 +204,11 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
 #ifdef HLM_PHASE_TIMING
     unsigned long long ph_a = 0, ph_b = 0, ph_f = 0, ph_c = 0, ph_n = 0;
 #endif
+    // drain (wave-uniform): the flush of the last iteration made room in the ring while some lane still holds rows of
+    // its accepted step (a step with more than R rows) -- this iteration only moves rows (B, C), nobody attempts.
+    // Without it the lanes that are free go on integrating while the others finish their rows: those then attempt
+    // later, alone, and the wave runs the attempt code more often than its slowest lane needs.
+    [[maybe_unused]] bool drain = false;
     while (wave_on) {
         HLM_STAMP(st0);
 #if defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 1
@@ -207,8 +218,13 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
 #endif
         int progress = 0;
         // ---- (A) one attempt ------------------------------------------------------------------
+#if HLM_DENSE_DRAIN
+        const bool can_step = !drain && mode == M_LIVE && t < t_end && n_attempt < A.cap;
+        if (mode == M_LIVE && !can_step && !drain) {
+#else
         const bool can_step = mode == M_LIVE && t < t_end && n_attempt < A.cap;
         if (mode == M_LIVE && !can_step) {
+#endif
             if (t < t_end) status = HLM_SYS_CAPPED;  // attempt cap (the build's guard, see hlm_hip.h)
             mode = (status == HLM_SYS_OK && t < tf) ? M_STUCK : M_ZEROS;  // (paused at t_stop : tf reached or capped)
         }
@@ -260,7 +276,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         const bool owes_zeros = mode == M_ZEROS;
         HLM_STAMP(st1);
 #if defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 1
-        __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(HLM_DENSE_PRIO_LEVEL);
 #elif defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
@@ -410,6 +426,9 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         }
 #endif
         wave_on = flushed || __builtin_amdgcn_ballot_w64(progress != 0) != 0ull;
+#if HLM_DENSE_DRAIN
+        drain = flushed && __builtin_amdgcn_ballot_w64(mode == M_PENDING) != 0ull;
+#endif
 #ifdef HLM_PHASE_TIMING
         {
             HLM_STAMP(st4);
@@ -454,6 +473,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         A.stiff[sys] = flagged ? status : HLM_SYS_OK;
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
+        if (A.flag_state && flagged) record_flag_state<NEQ>(A.flag_state, sys, y, t);
     }
 }
 

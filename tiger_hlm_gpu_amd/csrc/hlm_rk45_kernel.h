@@ -74,6 +74,9 @@ struct Rk45Args {
     // components; dense_pos[c] = position of state component c in the row, or -1 when it is not written.
     int dense_k;
     int dense_pos[HLM_MAX_NEQ];
+    // nullable, [ns][N_EQ + 1]: a lane that is flagged stiff records the state it had reached, {y[N_EQ], t}, for a
+    // Radau pass that continues from there instead of restarting at t0 (hlm_device_job.d_flag_state)
+    double* flag_state;
 };
 
 // y + sum c_j * k_j accumulated left to right with one FMA per term, the order the
@@ -128,6 +131,16 @@ __device__ __forceinline__ size_t forcing_row(unsigned long long idx, unsigned l
 {
     const unsigned long long r = idx >= first ? idx - first : 0ull;
     return (size_t)(r < rows ? r : rows - 1ull);
+}
+
+// where a flagged lane leaves the state it had reached (Rk45Args.flag_state)
+template <int NEQ>
+__device__ __forceinline__ void record_flag_state(double* flag_state, int sys, const double (&y)[NEQ], double t)
+{
+    double* o = flag_state + (size_t)sys * (NEQ + 1);
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) o[i] = y[i];
+    o[NEQ] = t;
 }
 
 // ---- the 7 stages of one attempt ---------------------------------------------------------
@@ -660,6 +673,7 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     A.stiff[sys] = flagged ? status : HLM_SYS_OK;
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
+    if (A.flag_state && flagged) record_flag_state<NEQ>(A.flag_state, sys, y, t);
     if constexpr (DENSE) {
         // queries this lane never reaches (flagged, or later than tf): zero rows
         const int q_stop = A.nq < qe ? A.nq : qe;
@@ -697,7 +711,11 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) compact_count_kernel(const int*
 
 // exclusive scan of block_count[0 .. nb) in place (nb is ~1000 for a million systems: one block, serial
 // chunks per thread), total -> *count
-__global__ void __launch_bounds__(COMPACT_BLOCK) compact_scan_kernel(int* __restrict__ block_count, int nb, int* __restrict__ count)
+// base (nullable, in/out): the list already holds *base entries -- the offsets start there and *base becomes the new
+// total, so that several passes with different `want` append to one list (the Radau pass orders the flagged systems
+// by the time of their flag that way: radau_flag_bin_kernel)
+__global__ void __launch_bounds__(COMPACT_BLOCK) compact_scan_kernel(int* __restrict__ block_count, int nb, int* __restrict__ count,
+                                                                     int* __restrict__ base = nullptr)
 {
     __shared__ int part[COMPACT_BLOCK];
     const int per = (nb + COMPACT_BLOCK - 1) / COMPACT_BLOCK;
@@ -707,9 +725,10 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) compact_scan_kernel(int* __rest
     part[threadIdx.x] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
-        int run = 0;
+        int run = base ? *base : 0;
         for (int i = 0; i < COMPACT_BLOCK; ++i) { const int v = part[i]; part[i] = run; run += v; }
         *count = run;
+        if (base) *base = run;
     }
     __syncthreads();
     int run = part[threadIdx.x];
@@ -733,6 +752,21 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) compact_scatter_kernel(const in
     }
     __syncthreads();
     if (alive) index[wave_offset[w] + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+// bin[i] = which of the nbins equal parts of [t0, tf] system i was flagged in (earliest = 0), -1 when it was not
+// flagged: the key of the Radau pass's work order in "continue" mode (a system flagged early has most left to do)
+__global__ void __launch_bounds__(COMPACT_BLOCK) radau_flag_bin_kernel(const int* __restrict__ stiff, const double* __restrict__ flag_state,
+                                                                       int neq, int ns, double t0, double tf, int nbins, int* __restrict__ bin)
+{
+    const int i = (int)(blockIdx.x * COMPACT_BLOCK + threadIdx.x);
+    if (i >= ns) return;
+    int b = -1;
+    if (stiff[i] == HLM_SYS_STIFF) {
+        const double x = (flag_state[(size_t)i * (neq + 1) + neq] - t0) / (tf - t0) * (double)nbins;
+        b = x >= 0.0 ? (x < (double)nbins ? (int)x : nbins - 1) : 0;  // (NaN -> 0)
+    }
+    bin[i] = b;
 }
 
 // ---- self-test of the FAST-mode elementary functions (hlm_selftest_math) ---------------------

@@ -64,6 +64,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 A.stiff[sys] = flagged ? status : HLM_SYS_OK;
 #pragma unroll
                 for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
+                if (A.flag_state && flagged) record_flag_state<NEQ>(A.flag_state, sys, y, t);
                 // one draw for all lanes that finished in this iteration
                 if (lane == (int)__builtin_ctzll(fin)) base = atomicAdd(queue, (unsigned)__builtin_popcountll(fin));
             }

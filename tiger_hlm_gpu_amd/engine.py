@@ -105,9 +105,15 @@ class ShardEngine:
         ``t_stop``: pause every hillslope once its t reaches it (state kept in the engine's
         resume buffer); ``resume_in``: continue from that buffer.  A sequence of such launches
         gives the same bits as one uninterrupted pass.  ``radau``: follow the pass with the
-        Radau-IIA fallback over the hillslopes it flagged as stiff."""
+        Radau-IIA fallback over the hillslopes it flagged as stiff -- True: each restarts at t0 (the
+        reference's kernel, radau_kernel.cu:44-52); "continue": each continues from the state it had reached
+        (hlm_device_job.d_flag_state), the hillslopes flagged earliest first."""
         s = stream if stream is not None else torch.cuda.current_stream(self.device)
         j = self.job()
+        if radau == "continue":
+            if getattr(self, "_flag_state", None) is None:
+                self._flag_state = torch.zeros(self.ns * (self.model.N_EQ + 1), dtype=torch.float64, device=self.device)
+            j.d_flag_state = self._flag_state.data_ptr()
         if t_stop is not None or resume_in:
             j.d_resume, j.resume_in = self._resume_buffer().data_ptr(), int(bool(resume_in))
             if t_stop is not None:
@@ -187,9 +193,13 @@ class ShardEngine:
             last = min(max(int(np.floor(tb / dtmin[j])), 0), nT[j] - 1)
             return first, last - first + 1
 
-        edges = [self.t0]
-        while edges[-1] < self.tf:
-            edges.append(min(self.tf, edges[-1] + float(chunk_minutes)))
+        # edges as t0 + k * step (never by repeated addition), piece count bounded up front
+        npieces = int(np.ceil((self.tf - self.t0) / float(chunk_minutes))) if self.tf > self.t0 else 0
+        if npieces > (1 << 20):
+            raise ValueError(f"chunk_minutes = {chunk_minutes} cuts the window into {npieces} pieces (at most 2^20)")
+        edges = [self.t0] + [e for e in (self.t0 + k * float(chunk_minutes) for k in range(1, npieces)) if self.t0 < e < self.tf]
+        if npieces > 0:
+            edges.append(self.tf)
         max_rows = sum(max(span(j, a, b)[1] for a, b in zip(edges[:-1], edges[1:])) for j in range(len(host)))
         bufs = [torch.empty(max_rows * ld, dtype=torch.float32, device=dev) for _ in range(2)]
         compute = torch.cuda.current_stream(dev)

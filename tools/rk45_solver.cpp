@@ -67,6 +67,7 @@ struct Options {
     int device = 0;
     int gpus = 1;               // shard the hillslopes over this many GPUs (one host thread each)
     bool radau = false;         // re-integrate flagged systems with the Radau-IIA fallback
+    bool radau_continue = false; // ... continuing from the state RK45 reached instead of restarting at t0
     bool oversubscribe = false; // allow --gpus > visible devices (shards share GPUs round-robin)
     bool quiet = false;
 };
@@ -77,7 +78,7 @@ struct Options {
     std::fprintf(stderr,
                  "usage: rk45_solver [--config run.yaml] [--init-file states.csv] [--model dummy|204|toy3] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
-                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau]\n"
+                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau | --radau-continue]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
                  "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L] [--states I,J,..]\n"
                  "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
@@ -154,6 +155,7 @@ Options parse(int argc, char** argv)
         else if (a == "--atol") o.atol = std::atof(val());
         else if (a == "--math") o.math = val();
         else if (a == "--radau") o.radau = true;
+        else if (a == "--radau-continue") o.radau = o.radau_continue = true;
         else if (a == "--out-final") o.out_final = val();
         else if (a == "--out-dense") o.out_dense = val();
         else if (a == "--forcing-nc") o.forcing_nc.push_back(val());
@@ -313,7 +315,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
         if (o.math != "fast" && o.math != "strict") usage("--math must be fast or strict");
         rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
     }
-    rk45_api::set_radau_fallback(o.radau);
+    rk45_api::set_radau_mode(o.radau_continue ? 2 : (o.radau ? 1 : 0));
 
     // ---- initial state and query grid --------------------------------------------------------------------
     std::vector<double> h_y0((size_t)ns * N_EQ);
