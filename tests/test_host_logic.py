@@ -350,3 +350,55 @@ def test_piece_count_of_chunked_launches_is_bounded(hlm):
     ptrs = (C.c_void_p * 1)(tab.ctypes.data)
     rc = L.hlm_rk45_integrate_forcing_streamed(C.byref(j), ptrs, 1e-30, None, None)
     assert rc == 1 and b"pieces" in L.hlm_last_error()
+
+
+def test_cpp_params_loader_values_and_errors(hlm, golden, tmp_path):
+    """include/hlm/parameters_loader.hpp (buffer + strtod, rows parsed by several threads) against the Python mirror
+    of reference src/I_O/parameters_loader.cpp:8-107: the same rows bit for bit on the reference's sample file and
+    on a 60 000-row synthetic one (several threads, CRLF, blank lines, no final newline, '+', blanks, exponents),
+    and the reference's exceptions: runtime_error for a missing file / column / short row, invalid_argument for a
+    field that is not a number."""
+    import subprocess
+    from tiger_hlm_gpu_amd import params, synth
+    exe = tmp_path / "test_params_loader"
+    subprocess.run(["g++", "-O1", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+                    os.path.join(ROOT, "tests", "cpp", "test_params_loader.cpp")], check=True)
+
+    def run(path):
+        p = subprocess.run([str(exe), str(path)], stdout=subprocess.PIPE, text=True)
+        return p.returncode, p.stdout.splitlines()
+
+    def rows_of(lines):
+        out = []
+        for ln in lines[1:]:
+            f = ln.split()
+            out.append((int(f[0]), int(f[1])) + tuple(float.fromhex(x) for x in f[2:]))
+        return out
+
+    def expect(sp):
+        names = ("c1", "infil", "perco", "Hu", "lat", "sw", "ss", "n_mann", "slope", "L", "A_h", "alpha3", "alpha4", "melt_f", "temp_thr")
+        return [(int(r["stream"]), int(r["next_stream"])) + tuple(float(r[n]) for n in names) for r in sp]
+
+    rc, lines = run(golden["small_test_csv"])
+    assert rc == 0 and rows_of(lines) == expect(params.load_spatial_params(golden["small_test_csv"]))
+    big = tmp_path / "big.csv"
+    synth.write_params_csv(big, synth.model204_params(0, 60_000))    # ~14 MB: four parser threads
+    text = open(big).read().splitlines()
+    text[5] = text[5].replace(",4,", ", +4,", 1).replace(",55,", ",5.5e1,", 1)
+    text.insert(9, "")
+    body = "\r\n".join(text)                                          # CRLF, a blank line, no final newline
+    open(big, "w", newline="").write(body)
+    rc, lines = run(big)
+    assert rc == 0 and lines[0] == "ROWS 60000"
+    assert rows_of(lines) == expect(params.load_spatial_params(big))
+    hdr = text[0]
+    for name, content, kind in (("missing_col.csv", hdr.replace(",hu,", ",HU,") + "\n" + text[1] + "\n", "runtime_error: Missing column 'hu'"),
+                                ("short_row.csv", hdr + "\n" + ",".join(text[1].split(",")[:10]) + "\n", "runtime_error: Bad row with too few fields"),
+                                ("not_a_number.csv", hdr + "\n" + text[1].replace(",4,", ",four,", 1) + "\n", "invalid_argument"),
+                                ("empty_field_at_line_end.csv", hdr + "\n" + ",".join(text[1].split(",")[:-1]) + ", \n" + text[2] + "\n", "invalid_argument")):
+        p = tmp_path / name
+        p.write_text(content)
+        rc, lines = run(p)
+        assert rc == 3 and lines[0].startswith("EXC " + kind), (name, lines[:1])
+    rc, lines = run(tmp_path / "nowhere.csv")
+    assert rc == 3 and lines[0].startswith("EXC runtime_error: Failed to open parameter file")

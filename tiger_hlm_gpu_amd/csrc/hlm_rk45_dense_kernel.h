@@ -50,8 +50,11 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 #ifndef HLM_FLUSH_PIPELINED
 #define HLM_FLUSH_PIPELINED 1
 #endif
-#ifndef HLM_DENSE_DRAIN
-#define HLM_DENSE_DRAIN 0
+// Wave priority by phase.  1: the row and flush phases (B, C: LDS, stores, ballots -- short instructions whose
+// latencies the wave waits for) run at s_setprio 1, the attempt (A: long FP64 chains) at 0, so that a wave in its
+// rows is not queued behind its SIMD partner's arithmetic: -2 % (same-box A/B, round 3).  2: the reverse (+0.3 %).
+#ifndef HLM_DENSE_PRIO
+#define HLM_DENSE_PRIO 1
 #endif
 #ifndef HLM_DENSE_PRIO_LEVEL
 #define HLM_DENSE_PRIO_LEVEL 1
@@ -170,14 +173,15 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     double tq_next = next_q < A.nq ? A.query[next_q] : inf;
 
     bool have_k0 = false;  // see rk45_multi_kernel: k6 of an accepted step is the next k0
-    double k0[NEQ], k6[NEQ], yt[NEQ], Q1[NEQ], Q2[NEQ], Q3[NEQ];
+    // D1, (k0 as D2), D3, D4: the interpolant of a pending step (dense_coefficients; k0 is dead until the commit)
+    double k0[NEQ], k6[NEQ], yt[NEQ], D1[NEQ], D3[NEQ], D4[NEQ];
 #pragma unroll
-    for (int i = 0; i < NEQ; ++i) k0[i] = k6[i] = yt[i] = Q1[i] = Q2[i] = Q3[i] = 0.0;
+    for (int i = 0; i < NEQ; ++i) k0[i] = k6[i] = yt[i] = D1[i] = D3[i] = D4[i] = 0.0;
     typename Model::Forc FV = Model::prep_forcing(P, held.F);
     // A PENDING step: accepted, not yet committed because rows of it are still to be produced (the
     // ring is full, or the launch's query window ends inside it).  While a lane waits its registers
     // are not written (it is masked off in the attempt code), so the step lives where the attempt
-    // left it: y (old state), yt (new state), k0, k6 (the next k0), Q1..Q3 (rk45_step_dense.cuh:222-231).
+    // left it: y (old state), yt (new state), k6 (the next k0), D1, k0 (= D2), D3, D4 (the interpolant).
     // The lane's state, one integer in a VGPR (tested where it is needed; four booleans carried through the
     // loop's divergent control flow cost three scalar instructions at every join):
     //   LIVE    integrating;
@@ -204,27 +208,20 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
 #ifdef HLM_PHASE_TIMING
     unsigned long long ph_a = 0, ph_b = 0, ph_f = 0, ph_c = 0, ph_n = 0;
 #endif
-    // drain (wave-uniform): the flush of the last iteration made room in the ring while some lane still holds rows of
-    // its accepted step (a step with more than R rows) -- this iteration only moves rows (B, C), nobody attempts.
-    // Without it the lanes that are free go on integrating while the others finish their rows: those then attempt
-    // later, alone, and the wave runs the attempt code more often than its slowest lane needs.
-    [[maybe_unused]] bool drain = false;
+    // (Tried and dropped, round 3: "drain" iterations -- when the flush made room while some lane still holds rows of
+    // its accepted step, an iteration that only moves rows, so that no lane falls an attempt behind: 816 instead of
+    // 621 iterations per wave, 15.9 instead of 15.1 ms.)
     while (wave_on) {
         HLM_STAMP(st0);
-#if defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 1
+#if HLM_DENSE_PRIO == 1
         __builtin_amdgcn_s_setprio(0);
-#elif defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 2
+#elif HLM_DENSE_PRIO == 2
         __builtin_amdgcn_s_setprio(1);
 #endif
         int progress = 0;
         // ---- (A) one attempt ------------------------------------------------------------------
-#if HLM_DENSE_DRAIN
-        const bool can_step = !drain && mode == M_LIVE && t < t_end && n_attempt < A.cap;
-        if (mode == M_LIVE && !can_step && !drain) {
-#else
         const bool can_step = mode == M_LIVE && t < t_end && n_attempt < A.cap;
         if (mode == M_LIVE && !can_step) {
-#endif
             if (t < t_end) status = HLM_SYS_CAPPED;  // attempt cap (the build's guard, see hlm_hip.h)
             mode = (status == HLM_SYS_OK && t < tf) ? M_STUCK : M_ZEROS;  // (paused at t_stop : tf reached or capped)
         }
@@ -262,22 +259,14 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 t1 = t + h;
                 h_next = FIXED ? A.fixed_step : h * fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
                 mode = M_PENDING;
-                if (tq_next <= t1) {
-                    // Q_m = sum_j P[j][m] k_j once per step; Q_0 = k0 (rk45_step_dense.cuh:222-231)
-#pragma unroll
-                    for (int i = 0; i < NEQ; ++i) {
-                        Q1[i] = lc(P01 * k0[i], P21, k2[i], P31, k3[i], P41, k4[i], P51, k5[i], P61, k6[i]);
-                        Q2[i] = lc(P02 * k0[i], P22, k2[i], P32, k3[i], P42, k4[i], P52, k5[i], P62, k6[i]);
-                        Q3[i] = lc(P03 * k0[i], P23, k2[i], P33, k3[i], P43, k4[i], P53, k5[i], P63, k6[i]);
-                    }
-                }
+                if (tq_next <= t1) dense_coefficients<NEQ>(y, yt, h, k0, k2, k3, k4, k5, k6, D1, k0, D3, D4);  // once per step
             }
         }
         const bool owes_zeros = mode == M_ZEROS;
         HLM_STAMP(st1);
-#if defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 1
+#if HLM_DENSE_PRIO == 1
         __builtin_amdgcn_s_setprio(HLM_DENSE_PRIO_LEVEL);
-#elif defined(HLM_DENSE_PRIO) && HLM_DENSE_PRIO == 2
+#elif HLM_DENSE_PRIO == 2
         __builtin_amdgcn_s_setprio(0);
 #endif
 
@@ -309,12 +298,9 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 if (!ZEROS || (pending && tq_next > t)) {  // rk45_step_dense.cuh:235-243
                     double th;
                     if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
-                    const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
+                    const double th1 = 1.0 - th;
 #pragma unroll
-                    for (int i = 0; i < NEQ; ++i) {
-                        const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
-                        row[i] = __builtin_fma(h, poly, y[i]);
-                    }
+                    for (int i = 0; i < NEQ; ++i) row[i] = dense_value(th, th1, y[i], D1[i], k0[i], D3[i], D4[i]);
                 }
                 const lds_double_ptr slot = ring + (next_q & (R - 1)) * (NEQ * WAVE);
 #pragma unroll
@@ -426,9 +412,6 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         }
 #endif
         wave_on = flushed || __builtin_amdgcn_ballot_w64(progress != 0) != 0ull;
-#if HLM_DENSE_DRAIN
-        drain = flushed && __builtin_amdgcn_ballot_w64(mode == M_PENDING) != 0ull;
-#endif
 #ifdef HLM_PHASE_TIMING
         {
             HLM_STAMP(st4);

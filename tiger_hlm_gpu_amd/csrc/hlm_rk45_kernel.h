@@ -133,6 +133,43 @@ __device__ __forceinline__ size_t forcing_row(unsigned long long idx, unsigned l
     return (size_t)(r < rows ? r : rows - 1ull);
 }
 
+// ---- dense output of an accepted step ------------------------------------------------------------------------
+// The reference evaluates y(t + theta h) = y + h sum_{m=0..3} Q_m theta^(m+1) with Q = P^T k, P = SciPy's 7 x 4
+// matrix (rk45_step_dense.cuh:193-244).  That quartic is the continuous extension of the Dormand-Prince pair in
+// monomial form; Hairer's DOPRI5 writes THE SAME polynomial (checked coefficient by coefficient against P: they
+// agree to 2e-15, the rounding of the decimal constants) as
+//     y + theta (d1 + (1 - theta) (d2 + theta (d3 + (1 - theta) d4))),
+//     d1 = y_new - y,  d2 = h k0 - d1,  d3 = d1 - h k6 - d2,  d4 = h sum_j P[j][3] k_j
+// -- one six-term combination of the slopes instead of three (10 instead of 18 operations per component and
+// step), and 4 instead of 5 fused operations per component and row.  The rows differ from the monomial form's in
+// the last bits only (errors of a few ulp of |y|; the parity bound is 1e-6 |y|); they never feed back into the
+// integration, so the step sequence is untouched.  Both dense kernels use these two functions: their rows stay
+// bit-identical to each other.
+// d2 MAY BE k0 ITSELF (the ring kernel: a lane holding an accepted step has no use for k0 until the commit replaces
+// it by k6, and a second set of registers for d2 would spill): k0[i] is read before d2[i] is written.
+template <int NEQ>
+__device__ __forceinline__ void dense_coefficients(const double (&y)[NEQ], const double (&yn)[NEQ], double h, const double (&k0)[NEQ],
+                                                   const double (&k2)[NEQ], const double (&k3)[NEQ], const double (&k4)[NEQ],
+                                                   const double (&k5)[NEQ], const double (&k6)[NEQ], double (&d1)[NEQ],
+                                                   double (&d2)[NEQ], double (&d3)[NEQ], double (&d4)[NEQ])
+{
+    using namespace dp;
+    const double h0 = h * P03, h2 = h * P23, h3 = h * P33, h4 = h * P43, h5 = h * P53, h6 = h * P63;
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) {
+        const double k0i = k0[i];
+        d4[i] = lc(h0 * k0i, h2, k2[i], h3, k3[i], h4, k4[i], h5, k5[i], h6, k6[i]);
+        d1[i] = yn[i] - y[i];
+        const double d2i = __builtin_fma(h, k0i, -d1[i]);
+        d3[i] = __builtin_fma(-h, k6[i], d1[i]) - d2i;
+        d2[i] = d2i;
+    }
+}
+__device__ __forceinline__ double dense_value(double th, double th1, double y, double d1, double d2, double d3, double d4)
+{
+    return __builtin_fma(th, __builtin_fma(th1, __builtin_fma(th, __builtin_fma(th1, d4, d3), d2), d1), y);
+}
+
 // where a flagged lane leaves the state it had reached (Rk45Args.flag_state)
 template <int NEQ>
 __device__ __forceinline__ void record_flag_state(double* flag_state, int sys, const double (&y)[NEQ], double t)
@@ -604,28 +641,22 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         const double t1 = t + h;
         if constexpr (DENSE) {
             if (tq_next <= t1) {
-                // Q_m = sum_j P[j][m] k_j once per step (the reference recomputes the same
-                // values for every query, rk45_step_dense.cuh:222-231); Q_0 = k0.
-                double Q1[NEQ], Q2[NEQ], Q3[NEQ];
-#pragma unroll
-                for (int i = 0; i < NEQ; ++i) {
-                    Q1[i] = lc(P01 * k0[i], P21, k2[i], P31, k3[i], P41, k4[i], P51, k5[i], P61, k6[i]);
-                    Q2[i] = lc(P02 * k0[i], P22, k2[i], P32, k3[i], P42, k4[i], P52, k5[i], P62, k6[i]);
-                    Q3[i] = lc(P03 * k0[i], P23, k2[i], P33, k3[i], P43, k4[i], P53, k5[i], P63, k6[i]);
-                }
+                // the interpolant's coefficients once per step (the reference recomputes Q = P^T k for every
+                // query, rk45_step_dense.cuh:222-231), in Hairer's form: see dense_coefficients
+                double D1[NEQ], D2[NEQ], D3[NEQ], D4[NEQ];
+                dense_coefficients<NEQ>(y, yn, h, k0, k2, k3, k4, k5, k6, D1, D2, D3, D4);
                 bool pause = false;
                 [[maybe_unused]] const double inv_h = MATH == MATH_FAST ? fast_rcp(h) : 0.0;
                 do {
                     if (next_q >= qe) { pause = true; break; }
                     double th;  // rk45_kernel.cu:142
                     if constexpr (MATH == MATH_FAST) th = (tq_next - t) * inv_h; else th = (tq_next - t) / h;
-                    const double th2 = th * th, th3 = th2 * th, th4 = th3 * th;
+                    const double th1 = 1.0 - th;
                     double* o = dense_row + (size_t)next_q * q_stride;
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) {
                         if (SEL && A.dense_pos[i] < 0) continue;  // (wave-uniform) component not selected
-                        const double poly = lc(k0[i] * th, Q1[i], th2, Q2[i], th3, Q3[i], th4);
-                        o[SEL ? A.dense_pos[i] : i] = __builtin_fma(h, poly, y[i]);  // rk45_step_dense.cuh:235-243
+                        o[SEL ? A.dense_pos[i] : i] = dense_value(th, th1, y[i], D1[i], D2[i], D3[i], D4[i]);  // rk45_step_dense.cuh:235-243
                     }
                     ++next_q;
                     tq_next = next_q < A.nq ? query_at(next_q) : __builtin_inf();

@@ -14,7 +14,7 @@ ASAN_OPTIONS=detect_leaks=0:abort_on_error=0 UBSAN_OPTIONS=halt_on_error=1:print
   python -m pytest tests/test_oracle_golden.py tests/test_radau_oracle.py -q -x -p no:cacheprovider 2>&1 | tail -3
 [ ${PIPESTATUS[0]} -eq 0 ] && echo "PASS: oracle under ASan+UBSan" || { echo "FAIL: oracle under ASan+UBSan"; rc=1; }
 T=$(mktemp -d)
-SAN="-O1 -g -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -Wextra -Iinclude"
+SAN="-O1 -g -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -Wall -Wextra -Iinclude"
 g++ $SAN tests/cpp/test_config_yaml.cpp -o $T/yaml && $T/yaml tools/examples/run_204.yaml >/dev/null && $T/yaml dump tools/examples/run_204.yaml >/dev/null \
   && echo "PASS: config_yaml.hpp" || { echo "FAIL: config_yaml.hpp"; rc=1; }
 g++ $SAN tests/cpp/test_lookup.cpp -o $T/lookup && $T/lookup tests/golden/lookup_small_example.csv 64 64 >/dev/null \
