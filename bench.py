@@ -292,7 +292,8 @@ def dense_section(args):
         e2 = ShardEngine(H.Model204, synth.model204_y0(ns2), 0.0, tf2, sp=synth.model204_params(0, ns2), query=q2,
                          math_mode=math, device=dev, dense_tiled=2)
         e2.expand_forcings_on_device((pr2, t2), synth.cell_of_system(0, ns2), dt2, nT2)
-        e2.integrate()
+        for _ in range(2):                                # warm-up: the first launch after the allocation runs 2-3 % longer
+            e2.integrate()
         torch.cuda.synchronize()
         ms = []
         for _ in range(5):

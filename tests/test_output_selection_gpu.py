@@ -197,3 +197,60 @@ def test_cpp_driver_states_selected_on_the_device(gpu, golden, tmp_path):
     assert outs["nc"] == outs["both"]
     dense = np.frombuffer(outs["nc"][2], dtype=np.float64)
     assert dense.size == 10 * 97 * 2 and np.frombuffer(outs["nc"][3], dtype=np.int32).tolist() == [1, 3]
+
+
+@pytest.mark.parametrize("window", [1, 37, 1000])
+def test_streamed_sink_delivers_every_window_once_in_order(gpu, window):
+    """hlm_rk45_integrate_streamed_sink: the rows pass through the library's two pinned staging buffers into the
+    consumer's callback, window by window, [ns][W][K]; assembled they equal the one-shot run bit for bit (all
+    components and a device-side selection), and the integrator state at the end is the one-shot run's."""
+    H = gpu
+    days = 2
+    case = _case(H, ns=300, days=days)
+    q = case[-1]
+    full = _engine(H, case, days)
+    full.integrate()
+    one = full.results()
+    for sel in (None, (0, 3)):
+        eng = _engine(H, case, days, dense_states=sel)
+        width = 5 if sel is None else len(sel)
+        out = np.full((300, len(q), width), np.nan)
+        calls = []
+
+        def sink(qb, qe, rows):
+            assert rows.shape == (300, qe - qb, width)
+            calls.append((qb, qe))
+            out[:, qb:qe] = rows          # (a copy: the view is only valid until the sink returns)
+        st = eng.integrate_streamed_sink(window, sink)
+        W = min(window, len(q))
+        assert calls == [(k * W, min((k + 1) * W, len(q))) for k in range(-(-len(q) // W))]
+        assert st["windows"] == len(calls) and st["dense_bytes"] == 300 * len(q) * 8 * width
+        want = one["dense"] if sel is None else one["dense"][:, :, list(sel)]
+        assert np.array_equal(out, want)
+        two = eng.results()
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(one[k], two[k]), k
+    # no consumer: the rows are discarded, the statistics still count them
+    st = _engine(H, case, days).integrate_streamed_sink(64, None)
+    assert st["dense_bytes"] == 300 * len(q) * 40 and st["windows"] == -(-len(q) // 64)
+
+
+def test_streamed_sink_stops_when_the_consumer_says_so(gpu):
+    H = gpu
+    case = _case(H, ns=128, days=1)
+    eng = _engine(H, case, 1)
+    seen = []
+
+    def stop_after_two(qb, qe, rows):
+        seen.append(qb)
+        return 7 if len(seen) == 2 else 0
+    with pytest.raises(H.HlmError) as e:
+        eng.integrate_streamed_sink(16, stop_after_two)
+    assert e.value.code == 5 and "7" in str(e.value) and len(seen) == 2
+
+    def broken(qb, qe, rows):
+        raise KeyError("consumer bug")
+    with pytest.raises(KeyError):
+        eng.integrate_streamed_sink(16, broken)
+    eng.integrate()                       # the library is usable afterwards
+    assert np.isfinite(eng.results()["y_final"]).all()

@@ -56,6 +56,11 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 #ifndef HLM_DENSE_PRIO
 #define HLM_DENSE_PRIO 1
 #endif
+// 1: a ring slot is padded to the next power of two doubles (N_EQ = 5: 512 instead of 320; 18 instead of 12 KB of LDS
+// per wave, eight waves per CU still fit): the slot offset of a row is a shift.  -0.5 % (same-box A/B, round 3).
+#ifndef HLM_RING_POW2
+#define HLM_RING_POW2 1
+#endif
 #ifndef HLM_DENSE_PRIO_LEVEL
 #define HLM_DENSE_PRIO_LEVEL 1
 #endif
@@ -101,7 +106,14 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     if (sys >= A.ns) return;
 
     using lds_double_ptr = __attribute__((address_space(3))) double*;
-    __shared__ double ring_mem[R * NEQ * WAVE];  // [row % R][comp][lane]
+    // doubles per ring slot: N_EQ x 64, or (HLM_RING_POW2) the next power of two, so that a slot's offset is a shift
+#if HLM_RING_POW2
+    constexpr int SLOT = (NEQ * WAVE <= 64) ? 64 : (NEQ * WAVE <= 128) ? 128 : (NEQ * WAVE <= 256) ? 256 : (NEQ * WAVE <= 512) ? 512 : 1024;
+#else
+    constexpr int SLOT = NEQ * WAVE;
+#endif
+    static_assert(SLOT >= NEQ * WAVE, "a ring slot holds one row of the wave");
+    __shared__ double ring_mem[R * SLOT];  // [row % R][comp][lane]
     __shared__ double lds_query[DENSE_QWIN];     // sliding window of query times (see rk45_multi_kernel)
     const lds_double_ptr ring = (lds_double_ptr)ring_mem + lane;
 
@@ -302,7 +314,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) row[i] = dense_value(th, th1, y[i], D1[i], k0[i], D3[i], D4[i]);
                 }
-                const lds_double_ptr slot = ring + (next_q & (R - 1)) * (NEQ * WAVE);
+                const lds_double_ptr slot = ring + (next_q & (R - 1)) * SLOT;
 #pragma unroll
                 for (int c = 0; c < NEQ; ++c) {
                     if constexpr (SEL) slot[col[c]] = row[c]; else slot[c * WAVE] = row[c];
@@ -366,7 +378,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 // every lane reads its column of a slot (one wait per row) and stores it: per component 64 lanes x 8 B =
                 // 512 contiguous bytes
                 auto load = [&](int q, double (&v)[NEQ]) {
-                    const lds_double_ptr slot = ring + (q & (R - 1)) * (NEQ * WAVE);
+                    const lds_double_ptr slot = ring + (q & (R - 1)) * SLOT;
 #pragma unroll
                     for (int c = 0; c < NEQ; ++c)
                         if (!SEL || c < K) v[c] = slot[c * WAVE];
@@ -396,7 +408,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             if (have == 0ull) break;
             // every lane reads its column of the slot (five reads in flight, one wait) and stores it:
             // per component 64 lanes x 8 B = 512 contiguous bytes
-            const lds_double_ptr slot = ring + (q_flush & (R - 1)) * (NEQ * WAVE);
+            const lds_double_ptr slot = ring + (q_flush & (R - 1)) * SLOT;
             double v[NEQ];
 #pragma unroll
             for (int c = 0; c < NEQ; ++c)

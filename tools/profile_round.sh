@@ -6,7 +6,7 @@
 set -e
 ROOTDIR="${GRAFT_REPO_ROOT:-$PWD}"
 OUT="$ROOTDIR/gpurun_out/prof_${1:-r02}"
-ARGS="--steps 3 --warmup 1 --no-variants --no-cpu-baseline ${2:-}"
+ARGS="--steps 3 --warmup 1 --no-variants --no-dense --no-cpu-baseline ${2:-}"   # (--no-dense: the 57.6 GB dense section is profiled by itself, tools/profile_dense.sh)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOTDIR/bench.py" $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
