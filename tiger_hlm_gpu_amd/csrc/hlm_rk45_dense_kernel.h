@@ -58,6 +58,11 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 #endif
 // 1: a ring slot is padded to the next power of two doubles (N_EQ = 5: 512 instead of 320; 18 instead of 12 KB of LDS
 // per wave, eight waves per CU still fit): the slot offset of a row is a shift.  -0.5 % (same-box A/B, round 3).
+// 1: the row loop of phase B written out (a lane emits at most R rows per iteration): no back-edge, the compiler
+// if-converts the R trips into one predicated block in which the rows of a lane interleave.  -1.6 % (same-box A/B).
+#ifndef HLM_ROWS_UNROLLED
+#define HLM_ROWS_UNROLLED 1
+#endif
 #ifndef HLM_RING_POW2
 #define HLM_RING_POW2 1
 #endif
@@ -304,7 +309,15 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
         const int q_lim = q_flush + R < q_hi ? q_flush + R : q_hi;  // room in the ring, end of the launch's window
         auto produce_rows = [&](auto zeros_tag) {
             constexpr bool ZEROS = decltype(zeros_tag)::value;
+#if HLM_ROWS_UNROLLED
+            // a lane is never more than R rows ahead of the flush cursor: at most R trips, written out (no back-edge,
+            // the rows of one lane interleave in the schedule)
+#pragma unroll
+            for (int trip = 0; trip < R; ++trip) {
+                if (!(want && next_q < q_lim)) break;
+#else
             while (want && next_q < q_lim) {
+#endif
                 const double tq_after = query_at(next_q + 1);  // fetched while the row is computed (the window holds inf past the last query)
                 double row[NEQ] = {};
                 if (!ZEROS || (pending && tq_next > t)) {  // rk45_step_dense.cuh:235-243
