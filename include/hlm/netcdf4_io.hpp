@@ -229,6 +229,76 @@ done:
     if (f >= 0) H5Fclose(f);
 }
 
+// The same file written window by window: the dense output of a run whose rows do not fit in host memory
+// (BASELINE config 5: 864 GB per GPU) arrives in query windows [q_begin, q_end) -- rk45_api::run_rk45_streamed /
+// hlm_rk45_integrate_streamed_sink -- and each window is one hyperslab outputs[:, q_begin:q_end, :].  The file is
+// what write_dense_netcdf produces for the whole array (same objects, attributes and layout; contiguous unless
+// compression is asked for).  Failures are reported on stderr like the reference's writer and make ok() false.
+class DenseNetcdfWriter {
+public:
+    DenseNetcdfWriter(const std::string& filename, const double* time_vals, const int* linkid_vals, const int* state_vals,
+                      int num_queries, int num_systems, int N_EQ, int compression_level = 0)
+        : ns_((hsize_t)num_systems), nq_((hsize_t)num_queries), k_((hsize_t)N_EQ)
+    {
+        using namespace hlm_nc_detail;
+        H5Eset_auto2(H5E_DEFAULT, nullptr, nullptr);
+        const hsize_t dims[3] = {ns_, nq_, k_};
+        const int coords[3] = {0, 1, 2};
+        hid_t ds = -1, dt = -1, dv = -1;
+        f_ = H5Fcreate(filename.c_str(), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT);
+        HLM_NC_CHECK(f_ >= 0);
+        ds = make_coord(f_, "system", H5T_STD_I32LE, H5T_NATIVE_INT, linkid_vals, dims[0], 0);
+        HLM_NC_CHECK(ds >= 0);
+        dt = make_coord(f_, "time", H5T_IEEE_F64LE, H5T_NATIVE_DOUBLE, time_vals, dims[1], 1);
+        HLM_NC_CHECK(dt >= 0);
+        dv = make_coord(f_, "variable", H5T_STD_I32LE, H5T_NATIVE_INT, state_vals, dims[2], 2);
+        HLM_NC_CHECK(dv >= 0);
+        HLM_NC_CHECK(put_text_attr(ds, "long_name", "LinkID"));
+        HLM_NC_CHECK(put_text_attr(dt, "long_name", "Time"));
+        HLM_NC_CHECK(put_text_attr(dt, "units", "minutes since start of simulation"));
+        HLM_NC_CHECK(put_text_attr(dv, "long_name", "state variable"));
+        HLM_NC_CHECK(put_text_attr(dv, "units", "various units"));
+        out_ = make_outputs(f_, 3, dims, compression_level);
+        HLM_NC_CHECK(out_ >= 0);
+        HLM_NC_CHECK(H5DSattach_scale(out_, ds, 0) >= 0 && H5DSattach_scale(out_, dt, 1) >= 0 && H5DSattach_scale(out_, dv, 2) >= 0);
+        HLM_NC_CHECK(put_int_attr(out_, "_Netcdf4Coordinates", coords, 3, false));
+        ok_ = true;
+    done:
+        if (dv >= 0) H5Dclose(dv);
+        if (dt >= 0) H5Dclose(dt);
+        if (ds >= 0) H5Dclose(ds);
+    }
+    DenseNetcdfWriter(const DenseNetcdfWriter&) = delete;
+    DenseNetcdfWriter& operator=(const DenseNetcdfWriter&) = delete;
+    ~DenseNetcdfWriter() { close(); }
+
+    // rows: [num_systems][q_end - q_begin][N_EQ], the layout a window sink receives
+    bool write_window(int q_begin, int q_end, const double* rows)
+    {
+        if (!ok_ || q_begin < 0 || q_end <= q_begin || (hsize_t)q_end > nq_) return ok_ = false;
+        const hsize_t start[3] = {0, (hsize_t)q_begin, 0}, count[3] = {ns_, (hsize_t)(q_end - q_begin), k_};
+        const hid_t fs = H5Dget_space(out_), ms = H5Screate_simple(3, count, nullptr);
+        const bool good = fs >= 0 && ms >= 0 && H5Sselect_hyperslab(fs, H5S_SELECT_SET, start, nullptr, count, nullptr) >= 0 &&
+                          H5Dwrite(out_, H5T_NATIVE_DOUBLE, ms, fs, H5P_DEFAULT, rows) >= 0;
+        if (ms >= 0) H5Sclose(ms);
+        if (fs >= 0) H5Sclose(fs);
+        if (!good) std::cerr << "NetCDF error: writing the window [" << q_begin << ", " << q_end << ") failed" << std::endl;
+        return ok_ = ok_ && good;
+    }
+    void close()
+    {
+        if (out_ >= 0) H5Dclose(out_);
+        if (f_ >= 0) H5Fclose(f_);
+        out_ = f_ = -1;
+    }
+    bool ok() const { return ok_; }
+
+private:
+    hsize_t ns_, nq_, k_;
+    hid_t f_ = -1, out_ = -1;
+    bool ok_ = false;
+};
+
 // outputs[system][variable] (output_series.cpp:77-123)
 inline void write_final_netcdf(const std::string& filename, const double* h_y_final, const int* linkid_vals,
                                const int* state_vals, int num_systems, int N_EQ, int compression_level = 4)

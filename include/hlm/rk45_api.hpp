@@ -24,6 +24,8 @@
 #pragma once
 
 #include <cstdint>
+#include <exception>
+#include <functional>
 #include <map>
 #include <mutex>
 #include <stdexcept>
@@ -210,6 +212,45 @@ std::pair<FinalType, DenseType> run_rk45(const std::vector<double>& h_y0, double
         throw;
     }
     return retrieve_and_free<Model>(d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, ns, nq, t0, tf, d_sp);
+}
+
+// ---- run_rk45 for dense output that fits no host array (BASELINE config 5: 864 GB per GPU) ----------------------
+// The rows reach `sink(q_begin, q_end, rows)` window by window, rows = [num_systems][q_end - q_begin][K] (K = N_EQ or the
+// length of set_output_states), valid until the sink returns, while the next window integrates; a sink that throws
+// ends the run and the exception is rethrown here.  Returns the final states; last_run_info() has flags / counters.
+template <class Model>
+FinalType run_rk45_streamed(const std::vector<double>& h_y0, double t0, double tf, const std::vector<double>& h_query_times,
+                            typename Model::SP_TYPE* d_sp, int window_queries,
+                            const std::function<void(int, int, const double*)>& sink)
+{
+    constexpr int N_EQ = Model::N_EQ;
+    const int ns = int(h_y0.size() / N_EQ);
+    struct Ctx {
+        const std::function<void(int, int, const double*)>* fn;
+        std::exception_ptr error;
+    } ctx{&sink, nullptr};
+    const hlm_window_sink tramp = [](void* user, int qb, int qe, const double* rows) -> int {
+        Ctx* c = static_cast<Ctx*>(user);
+        try {
+            (*c->fn)(qb, qe, rows);
+            return 0;
+        } catch (...) {
+            c->error = std::current_exception();
+            return -1;
+        }
+    };
+    FinalType h_final((size_t)ns * N_EQ);
+    RunInfo info;
+    info.stiff.resize(ns);
+    info.n_attempt.resize(ns);
+    info.n_accept.resize(ns);
+    const int rc = hlm_run_rk45_streamed(Model::UID, h_y0.data(), ns, t0, tf, h_query_times.data(), int(h_query_times.size()), d_sp,
+                                         window_queries, sink ? tramp : nullptr, &ctx, h_final.data(), info.stiff.data(),
+                                         info.n_attempt.data(), info.n_accept.data());
+    if (ctx.error) std::rethrow_exception(ctx.error);
+    detail::check(rc, "run_rk45_streamed");
+    detail::last_info() = std::move(info);
+    return h_final;
 }
 
 // flags / step counters of the most recent retrieve_and_free on the calling thread

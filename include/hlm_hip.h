@@ -315,6 +315,14 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
 typedef int (*hlm_window_sink)(void* user, int query_begin, int query_end, const double* h_rows);
 int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queries, hlm_window_sink sink, void* user,
                                      void* hip_stream, hlm_stream_stats* stats);
+/* run_rk45<M> (rk45_api.hpp:273-313) for dense output that fits neither HBM nor a host array: the host-buffer form
+ * of hlm_rk45_integrate_streamed_sink.  Registered parameters, forcings (resident: hlm_set_forcings) and output
+ * selection apply; the rows reach `sink` window by window ([ns][W][K], see above) instead of an h_dense array;
+ * finals, flags and counters come back as from hlm_run_rk45.  Not combinable with the Radau fallback (which needs
+ * the whole query range in one launch). */
+int hlm_run_rk45_streamed(int uid, const double* h_y0, int num_systems, double t0, double tf, const double* h_query_times,
+                          int num_queries, const void* d_sp, int window_queries, hlm_window_sink sink, void* user,
+                          double* h_final, int32_t* h_stiff, uint32_t* h_n_attempt, uint32_t* h_n_accept);
 /* Forcing series streamed through HBM in time chunks (BASELINE config 3: "NetCDF precip+t2m
  * forcings streamed").  h_tables[j]: HOST float [job->forc_nT[j]][job->forc_ld] of forcing j
  * (pinned memory makes the uploads asynchronous); job->d_forc is ignored.  The window [t0, tf]

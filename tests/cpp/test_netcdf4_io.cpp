@@ -43,6 +43,26 @@ int main(int argc, char** argv)
             write_dense_netcdf(argv[2], d.data(), t.data(), ids.data(), st.data(), nq, ns, neq, lvl);
             return 0;
         }
+        if (mode == "write_dense_windows" && argc == 8) {  // the same file through DenseNetcdfWriter, W queries per window
+            const int ns = std::atoi(argv[3]), nq = std::atoi(argv[4]), neq = std::atoi(argv[5]), lvl = std::atoi(argv[6]), W = std::atoi(argv[7]);
+            std::vector<double> t(nq);
+            std::vector<int> ids(ns), st(neq);
+            for (int s = 0; s < ns; ++s) ids[s] = s;
+            for (int q = 0; q < nq; ++q) t[q] = 60.0 * q;
+            for (int c = 0; c < neq; ++c) st[c] = c;
+            DenseNetcdfWriter w(argv[2], t.data(), ids.data(), st.data(), nq, ns, neq, lvl);
+            if (!w.ok()) return 4;
+            for (int qb = 0; qb < nq; qb += W) {
+                const int qe = qb + W < nq ? qb + W : nq;
+                std::vector<double> rows((size_t)ns * (qe - qb) * neq);  // [ns][W][neq], as a window sink receives them
+                for (int s = 0; s < ns; ++s)
+                    for (int q = qb; q < qe; ++q)
+                        for (int c = 0; c < neq; ++c) rows[((size_t)s * (qe - qb) + (q - qb)) * neq + c] = value(s, q, c);
+                if (!w.write_window(qb, qe, rows.data())) return 4;
+            }
+            if (w.write_window(nq - 1, nq + 1, nullptr)) return 5;  // a window past the end must be refused
+            return 0;
+        }
         if (mode == "write_final" && argc == 6) {
             const int ns = std::atoi(argv[3]), neq = std::atoi(argv[4]), lvl = std::atoi(argv[5]);
             std::vector<double> d((size_t)ns * neq);

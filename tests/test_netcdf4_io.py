@@ -108,3 +108,19 @@ def test_writers_produce_the_reference_file_structure_and_round_trip(nc, level):
         assert os.path.getsize(d) < 0.6 * 10 * 2881 * 5 * 8  # shuffle + deflate took effect
         hdr = subprocess.run([H5DUMP, "-p", "-H", str(d)], capture_output=True, text=True).stdout
         assert "COMPRESSION DEFLATE { LEVEL 4 }" in hdr and "SHUFFLE" in hdr
+
+
+@pytest.mark.skipif(not os.path.exists(H5DUMP), reason="h5dump not available")
+@pytest.mark.parametrize("level,window", [(0, 1), (0, 97), (0, 5000), (4, 97)])
+def test_windowed_writer_produces_the_same_file_contents(nc, level, window):
+    """DenseNetcdfWriter (the consumer of rk45_api::run_rk45_streamed's windows; BASELINE config 5's output never
+    exists whole on the host): same objects, attributes and values as write_dense_netcdf of the whole array."""
+    whole, piecewise = nc.dir / f"whole_{level}.nc", nc.dir / f"windows_{level}_{window}.nc"
+    nc("write_dense", whole, 7, 500, 3, level)
+    nc("write_dense_windows", piecewise, 7, 500, 3, level, window)   # (exit 0: every window written, one past the end refused)
+    assert _structure(str(piecewise)) == _structure(str(whole))
+    for ds in ("/outputs", "/time", "/system", "/variable"):
+        a, b = nc.dir / "a.bin", nc.dir / "b.bin"
+        subprocess.run([H5DUMP, "-d", ds, "-b", "LE", "-o", str(a), str(whole)], check=True, capture_output=True, cwd=nc.dir)
+        subprocess.run([H5DUMP, "-d", ds, "-b", "LE", "-o", str(b), str(piecewise)], check=True, capture_output=True, cwd=nc.dir)
+        assert open(a, "rb").read() == open(b, "rb").read(), ds

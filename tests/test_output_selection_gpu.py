@@ -186,7 +186,7 @@ def test_cpp_driver_states_selected_on_the_device(gpu, golden, tmp_path):
         assert p.returncode == 0, p.stderr
         line = json.loads(p.stdout.strip().splitlines()[-1])
         assert line["device_output_selection"] is (fmt == "nc") and line["dense_row_width"] == (2 if fmt == "nc" else 5)
-        assert set(line["phases"]) == {"params_csv_s", "forcing_read_s", "h2d_s", "integrate_s", "d2h_s", "write_s"}
+        assert set(line["phases"]) == {"params_csv_s", "forcing_read_s", "h2d_s", "integrate_s", "d2h_s", "write_s", "window_sink_s"}
         vals = []
         for name in ("final", "dense"):
             for ds in ("/outputs", "/variable"):
@@ -254,3 +254,61 @@ def test_streamed_sink_stops_when_the_consumer_says_so(gpu):
         eng.integrate_streamed_sink(16, broken)
     eng.integrate()                       # the library is usable afterwards
     assert np.isfinite(eng.results()["y_final"]).all()
+
+
+def test_host_api_streamed_run_and_the_driver_stream_dense(gpu, golden, tmp_path):
+    """hlm_run_rk45_streamed (run_rk45 whose dense rows go to a consumer window by window) with the registered
+    forcings and output selection, and rk45_solver --stream-dense W: dense.nc written one hyperslab per window
+    while the next window integrates, equal to the file of the run that held every row."""
+    H = gpu
+    api = H.api
+    ns, days = 130, 1
+    sp, y0, cells, pr, t2m, dt, nT, q = _case(H, ns=ns, days=days)
+    d_sp = api.upload_spatial_params(sp)
+    f = api.set_forcings(np.concatenate([pr, t2m], axis=0), dt, nT, pr.shape[1], col=cells)
+    try:
+        api.set_output_states(None)
+        full_final, full_dense = api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, q, d_sp)
+        full_dense = full_dense.reshape(ns, len(q), 5)
+        for sel in (None, (1, 4)):
+            api.set_output_states(sel)
+            width = 5 if sel is None else len(sel)
+            out = np.full((ns, len(q), width), np.nan)
+
+            def sink(qb, qe, rows):
+                out[:, qb:qe] = rows
+            final, info = api.run_rk45_streamed(H.Model204, y0, 0.0, days * 1440.0, q, d_sp, 50, sink, with_info=True)
+            assert np.array_equal(final, full_final) and info["n_attempt"].sum() > 0
+            assert np.array_equal(out, full_dense if sel is None else full_dense[:, :, list(sel)])
+        api.set_radau_fallback(True)
+        with pytest.raises(H.HlmError):
+            api.run_rk45_streamed(H.Model204, y0, 0.0, days * 1440.0, q, d_sp, 50, None)
+    finally:
+        api.set_radau_fallback(False)
+        api.set_output_states(None)
+        f.free()
+        d_sp.free()
+    exe = os.path.join(ROOT, "tools", "rk45_solver")
+    h5dump = os.path.join(os.environ.get("HDF5_DIR", "/opt/conda"), "bin", "h5dump")
+    if not os.path.exists(exe) or not os.path.exists(h5dump):
+        pytest.skip("driver or h5dump not available")
+    base = [exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "2880", "--query-stride", "7", "--initial-step", "1e-6",
+            "--out-format", "nc"]
+    blobs = {}
+    for tag, extra in (("whole", []), ("streamed", ["--stream-dense", "64"]), ("streamed_sel", ["--stream-dense", "64", "--states", "0,2"]),
+                       ("whole_sel", ["--states", "0,2"])):
+        d = tmp_path / tag
+        d.mkdir()
+        p = subprocess.run(base + extra + ["--out-final", str(d / "final.csv"), "--out-dense", str(d / "dense.csv")],
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr
+        line = json.loads(p.stdout.strip().splitlines()[-1])
+        assert line["streamed_dense_window"] == (64 if "streamed" in tag else 0)
+        vals = []
+        for name in ("final", "dense"):
+            for ds in ("/outputs", "/variable", "/time") if name == "dense" else ("/outputs", "/variable"):
+                b = str(d / f"{name}{ds.replace('/', '_')}.bin")
+                subprocess.run([h5dump, "-d", ds, "-b", "LE", "-o", b, str(d / f"{name}.nc")], check=True, capture_output=True)
+                vals.append(open(b, "rb").read())
+        blobs[tag] = vals
+    assert blobs["streamed"] == blobs["whole"] and blobs["streamed_sel"] == blobs["whole_sel"]

@@ -113,6 +113,8 @@ SIGNATURES = {
                                               C.POINTER(StreamStats)]),
     "hlm_rk45_integrate_streamed_sink": (C.c_int, [C.POINTER(DeviceJob), C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                                    C.POINTER(StreamStats)]),
+    "hlm_run_rk45_streamed": (C.c_int, [C.c_int, C.c_void_p, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_int, C.c_void_p,
+                                        C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hlm_rk45_integrate_forcing_streamed": (C.c_int, [C.POINTER(DeviceJob), C.POINTER(C.c_void_p), C.c_double,
                                                       C.c_void_p, C.POINTER(C.c_int)]),
     "hlm_rk45_integrate_compacting": (C.c_int, [C.POINTER(DeviceJob), C.c_double, C.c_void_p, C.POINTER(C.c_int)]),

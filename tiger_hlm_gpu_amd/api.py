@@ -256,6 +256,48 @@ def run_rk45(model, h_y0, t0, tf, h_query_times, d_sp, with_info=False, dense_wi
     return final, dense
 
 
+def run_rk45_streamed(model, h_y0, t0, tf, h_query_times, d_sp, window_queries, sink=None, with_info=False):
+    """run_rk45 for dense output that fits no host array (hlm_run_rk45_streamed): the rows reach
+    ``sink(query_begin, query_end, rows[ns, W, K])`` window by window (a view valid until the sink returns);
+    returns the final states (and flags / counters with ``with_info``)."""
+    y0 = np.ascontiguousarray(h_y0, dtype=np.float64).reshape(-1)
+    q = np.ascontiguousarray(h_query_times, dtype=np.float64).reshape(-1)
+    neq = model.N_EQ
+    ns, nq = y0.size // neq, q.size
+    width = [neq]
+    err = []
+
+    def trampoline(_user, qb, qe, ptr):
+        try:
+            r = sink(qb, qe, np.ctypeslib.as_array(ptr, shape=(ns, qe - qb, width[0])))
+            return int(r) if r else 0
+        except BaseException as ex:  # never let an exception cross the C frame
+            err.append(ex)
+            return -1
+    # the registered output selection decides the row width: ask the library through a zero-size setup
+    probe = GpuBuffers()
+    check(lib().hlm_setup_gpu_buffers_model(_uid(model), None, 0, None, 0, C.byref(probe)))
+    width[0] = probe.dense_ncomp if probe.dense_ncomp > 0 else neq
+    check(lib().hlm_retrieve_and_free(C.byref(probe), None, None, None, None, None))
+    cb = _lib.WINDOW_SINK(trampoline) if sink is not None else None
+    final = np.empty(ns * neq)
+    stiff = np.empty(ns, dtype=np.int32)
+    na = np.empty(ns, dtype=np.uint32)
+    nacc = np.empty(ns, dtype=np.uint32)
+    sp_ptr = d_sp.ptr if isinstance(d_sp, DeviceBuffer) else d_sp
+    try:
+        check(lib().hlm_run_rk45_streamed(_uid(model), _ptr(y0) if ns else None, ns, float(t0), float(tf), _ptr(q), nq, sp_ptr,
+                                          int(window_queries), C.cast(cb, C.c_void_p) if cb else None, None,
+                                          _ptr(final) if ns else None, _ptr(stiff), _ptr(na), _ptr(nacc)))
+    except HlmError:
+        if err:
+            raise err[0]
+        raise
+    if with_info:
+        return final, {"stiff": stiff, "n_attempt": na, "n_accept": nacc}
+    return final
+
+
 # ---- device-resident path (torch tensors as HBM buffers) ------------------------------------------
 def make_device_job(model, *, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_hours=(), forc_nT=(),
                     forc_ld=0, forc_col=None, params=None, fixed_step=0.0, attempt_cap=0,

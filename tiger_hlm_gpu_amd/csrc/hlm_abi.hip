@@ -1410,6 +1410,64 @@ int hlm_retrieve_and_free(hlm_gpu_buffers* b, double* h_final, double* h_dense, 
     return HLM_SUCCESS;
 }
 
+int hlm_run_rk45_streamed(int uid, const double* h_y0, int ns, double t0, double tf, const double* h_q, int nq, const void* d_sp,
+                          int window_queries, hlm_window_sink sink, void* user, double* h_final, int32_t* h_stiff,
+                          uint32_t* h_n_attempt, uint32_t* h_n_accept)
+{
+    if (nq <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "run_rk45_streamed needs query times (use hlm_run_rk45 for a run without dense output)");
+    hlm_gpu_buffers b;
+    int rc = hlm_setup_gpu_buffers_model(uid, h_y0, ns, h_q, 0, &b);  // no dense buffer: the windows are the callee's
+    if (rc != HLM_SUCCESS) return rc;
+    double* d_query = nullptr;
+    auto cleanup = [&](int code) {
+        char keep[sizeof(g_err)];
+        std::memcpy(keep, g_err, sizeof(keep));
+        if (d_query) (void)hipFree(d_query);
+        (void)hlm_retrieve_and_free(&b, nullptr, nullptr, nullptr, nullptr, nullptr);
+        std::memcpy(g_err, keep, sizeof(keep));
+        return code;
+    };
+    if (hipMalloc((void**)&d_query, sizeof(double) * (size_t)nq) != hipSuccess ||
+        hipMemcpy(d_query, h_q, sizeof(double) * (size_t)nq, hipMemcpyHostToDevice) != hipSuccess)
+        return cleanup(fail(HLM_ERR_HIP, "run_rk45_streamed: query upload failed"));
+    ForcingSlot* slot = forc_slot();
+    if (!slot) return cleanup(HLM_ERR_HIP);
+    hlm_device_job j;
+    std::memset(&j, 0, sizeof(j));
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        if (slot->in_flight)
+            return cleanup(fail(HLM_ERR_STATE, "another host-API integration is running on this device with the same forcing registration"));
+        if (g_radau) return cleanup(fail(HLM_ERR_INVALID_ARGUMENT, "run_rk45_streamed cannot be combined with the Radau fallback"));
+        if (slot->f.chunk_minutes > 0.0 && model_nf(uid) > 0)
+            return cleanup(fail(HLM_ERR_INVALID_ARGUMENT, "run_rk45_streamed needs the forcings resident in HBM (hlm_set_forcings)"));
+        const int rc0 = fill_job_from_registry(&j, uid, slot->f);
+        if (rc0 != HLM_SUCCESS) return cleanup(rc0);
+        slot->in_flight = 1;
+    }
+    struct Release {
+        ForcingSlot* s;
+        ~Release() { std::lock_guard<std::mutex> lk(g_mu); s->in_flight = 0; }
+    } release{slot};
+    j.num_systems = ns;
+    j.num_queries = nq;
+    j.t0 = t0;
+    j.tf = tf;
+    j.d_y0 = b.d_y0_all;
+    j.d_query = d_query;
+    j.d_sp = d_sp;
+    j.d_y_final = b.d_y_final_all;
+    j.d_stiff = b.d_stiff;
+    j.d_n_attempt = b.d_n_attempt;
+    j.d_n_accept = b.d_n_accept;
+    j.dense_ncomp = b.dense_ncomp;
+    std::memcpy(j.dense_comp, b.dense_comp, sizeof(j.dense_comp));
+    rc = ns > 0 ? hlm_rk45_integrate_streamed_sink(&j, window_queries, sink, user, nullptr, nullptr) : HLM_SUCCESS;
+    if (rc != HLM_SUCCESS) return cleanup(rc);
+    (void)hipFree(d_query);
+    return hlm_retrieve_and_free(&b, h_final, nullptr, h_stiff, h_n_attempt, h_n_accept);
+}
+
 int hlm_run_rk45(int uid, const double* h_y0, int ns, double t0, double tf, const double* h_q, int nq,
                  const void* d_sp, double* h_final, double* h_dense, int32_t* h_stiff,
                  uint32_t* h_n_attempt, uint32_t* h_n_accept)

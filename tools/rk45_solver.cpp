@@ -63,6 +63,8 @@ struct Options {
     bool expand_forcings = false; // reference per-stream layout instead of the per-cell table
     double stream_forcings = 0.0; // > 0: keep the series on the host, stream them in chunks of this many minutes
     std::string out_format = "csv";  // csv | nc | both  (nc: main.cpp:786-823)
+    int stream_dense = 0;         // > 0 (with --out-format nc, one GPU): the dense rows are never held whole -- windows of this
+                                  // many queries go from the device through pinned staging straight into the NetCDF file
     int nc_compression = 0;
     int device = 0;
     int gpus = 1;               // shard the hillslopes over this many GPUs (one host thread each)
@@ -80,7 +82,7 @@ struct Options {
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau | --radau-continue]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
-                 "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L] [--states I,J,..]\n"
+                 "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L] [--states I,J,..] [--stream-dense QUERIES_PER_WINDOW]\n"
                  "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
     std::exit(msg ? 2 : 0);
 }
@@ -164,6 +166,7 @@ Options parse(int argc, char** argv)
         else if (a == "--stream-forcings") o.stream_forcings = std::atof(val());
         else if (a == "--out-format") o.out_format = val();
         else if (a == "--nc-compression") o.nc_compression = std::atoi(val());
+        else if (a == "--stream-dense") o.stream_dense = std::atoi(val());
         else if (a == "--states") {  // config output.states from the command line: "1,3"
             o.states.clear();
             for (const char* p = val(); *p;) {
@@ -382,7 +385,17 @@ int run(const Options& o, hlm_io::CsvStyle style)
     const bool device_select = !o.states.empty() && (int)o.states.size() < N_EQ && o.out_format == "nc";
     const int width = device_select ? (int)o.states.size() : N_EQ;  // doubles per dense row as it leaves the device
     rk45_api::set_output_states(device_select ? o.states : std::vector<int>{});
-    std::vector<double> h_y_final((size_t)ns * N_EQ), h_dense((size_t)ns * nq * width);
+    // --stream-dense W: config 5's way -- the dense rows are never held whole on the host; each window of W queries is
+    // written into dense.nc as one hyperslab while the next one integrates (rk45_api::run_rk45_streamed)
+    const bool stream_dense = o.stream_dense > 0 && nq > 0;
+#ifdef HLM_WITH_HDF5
+    if (stream_dense && (o.out_format != "nc" || G != 1 || o.radau))
+        usage("--stream-dense needs --out-format nc, one GPU and no --radau");
+#else
+    if (stream_dense) usage("--stream-dense: this binary was built without HDF5 (HLM_WITH_HDF5)");
+#endif
+    double t_sink = 0.0;
+    std::vector<double> h_y_final((size_t)ns * N_EQ), h_dense(stream_dense ? 0 : (size_t)ns * nq * width);
     std::vector<double> t_h2d(G, 0.0), t_integrate(G, 0.0), t_d2h(G, 0.0);
     std::vector<int32_t> stiff(ns, 0);
     std::vector<uint32_t> n_attempt(ns, 0);
@@ -428,6 +441,36 @@ int run(const Options& o, hlm_io::CsvStyle style)
                 rk45_api::detail::check(hlm_clear_forcings(), "hlm_clear_forcings");
             }
             const std::vector<double> y0_shard(h_y0.begin() + (size_t)start * N_EQ, h_y0.begin() + (size_t)(start + count) * N_EQ);
+#ifdef HLM_WITH_HDF5
+            if (stream_dense) {
+                std::vector<int> linkid_vals(ns), state_vals(width);
+                for (int s = 0; s < ns; ++s) linkid_vals[s] = s;
+                for (int v = 0; v < width; ++v) state_vals[v] = device_select ? o.states[v] : v;
+                auto nc_name = [](std::string p) { const size_t d = p.rfind('.'); return (d == std::string::npos ? p : p.substr(0, d)) + ".nc"; };
+                DenseNetcdfWriter writer(nc_name(o.out_dense), h_query_times.data(), linkid_vals.data(), state_vals.data(), (int)nq, ns, width,
+                                         o.nc_compression);
+                if (!writer.ok()) throw std::runtime_error("cannot create " + nc_name(o.out_dense));
+                t_h2d[r] = since(ts);
+                ts = clk::now();
+                const auto yf = rk45_api::run_rk45_streamed<Model>(y0_shard, t0, tf, h_query_times, d_sp, o.stream_dense,
+                                                                   [&](int qb, int qe, const double* rows) {
+                                                                       const clk::time_point tw = clk::now();
+                                                                       if (!writer.write_window(qb, qe, rows)) throw std::runtime_error("dense.nc: window write failed");
+                                                                       t_sink += since(tw);
+                                                                   });
+                t_integrate[r] = since(ts);  // (integration, D2H and the file writes of the windows overlap: one phase)
+                writer.close();
+                const rk45_api::RunInfo info = rk45_api::last_run_info();
+                std::copy(yf.begin(), yf.end(), h_y_final.begin() + (size_t)start * N_EQ);
+                std::copy(info.stiff.begin(), info.stiff.end(), stiff.begin() + start);
+                if (!info.n_attempt.empty()) std::copy(info.n_attempt.begin(), info.n_attempt.end(), n_attempt.begin() + start);
+                rk45_api::device_free(d_sp);
+                hlm_clear_forcings();
+                if (d_forc) rk45_api::device_free(d_forc);
+                if (d_col) rk45_api::device_free(d_col);
+                return;
+            }
+#endif
             // run_rk45<Model> (rk45_api.hpp:273-313) spelt out in its three phases so that each can be timed
             auto [d_y0_all, d_y_final_all, d_query_times, d_dense_all, d_stiff, ns_b, nq_b] =
                 rk45_api::setup_gpu_buffers<Model>(y0_shard, h_query_times);
@@ -483,7 +526,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
         auto nc_name = [](std::string p) { const size_t d = p.rfind('.'); return (d == std::string::npos ? p : p.substr(0, d)) + ".nc"; };
         if (o.states.empty()) {
             write_final_netcdf(nc_name(o.out_final), h_y_final.data(), linkid_vals.data(), state_vals.data(), ns, N_EQ, o.nc_compression);
-            if (nq > 0)
+            if (nq > 0 && !stream_dense)
                 write_dense_netcdf(nc_name(o.out_dense), h_dense.data(), h_query_times.data(), linkid_vals.data(), state_vals.data(),
                                    (int)nq, ns, N_EQ, o.nc_compression);
         } else {
@@ -494,14 +537,14 @@ int run(const Options& o, hlm_io::CsvStyle style)
             std::vector<double> yf((size_t)ns * K), dn_host;
             for (size_t r = 0; r < (size_t)ns; ++r)
                 for (int k = 0; k < K; ++k) yf[r * K + k] = h_y_final[r * N_EQ + o.states[k]];
-            if (width != K) {
+            if (width != K && !stream_dense) {
                 dn_host.resize((size_t)ns * nq * K);
                 for (size_t r = 0; r < (size_t)ns * nq; ++r)
                     for (int k = 0; k < K; ++k) dn_host[r * K + k] = h_dense[r * N_EQ + o.states[k]];
             }
             const double* dn = width != K ? dn_host.data() : h_dense.data();
             write_final_netcdf(nc_name(o.out_final), yf.data(), linkid_vals.data(), o.states.data(), ns, K, o.nc_compression);
-            if (nq > 0)
+            if (nq > 0 && !stream_dense)
                 write_dense_netcdf(nc_name(o.out_dense), dn, h_query_times.data(), linkid_vals.data(), o.states.data(), (int)nq, ns, K,
                                    o.nc_compression);
         }
@@ -524,11 +567,12 @@ int run(const Options& o, hlm_io::CsvStyle style)
                     "\"initial_step\": %g, \"gpus\": %d, \"attempted_steps\": %llu, \"flagged\": %d, \"radau\": %s, \"unsolved\": %d, "
                     "\"run_rk45_seconds\": %.6f, \"dense_row_width\": %d, \"device_output_selection\": %s, "
                     "\"phases\": {\"params_csv_s\": %.6f, \"forcing_read_s\": %.6f, \"h2d_s\": %.6f, \"integrate_s\": %.6f, "
-                    "\"d2h_s\": %.6f, \"write_s\": %.6f}, \"final\": \"%s\", \"dense\": \"%s\"}\n",
+                    "\"d2h_s\": %.6f, \"write_s\": %.6f, \"window_sink_s\": %.6f}, \"streamed_dense_window\": %d, \"final\": \"%s\", \"dense\": \"%s\"}\n",
                     (int)Model::UID, ns, nq, t0, tf, hp.initialStep, G, attempts, flagged, o.radau ? "true" : "false", unsolved, secs,
                     width, device_select ? "true" : "false", t_params, t_forcing_read,
                     *std::max_element(t_h2d.begin(), t_h2d.end()), *std::max_element(t_integrate.begin(), t_integrate.end()),
-                    *std::max_element(t_d2h.begin(), t_d2h.end()), t_write, o.out_final.c_str(), o.out_dense.c_str());
+                    *std::max_element(t_d2h.begin(), t_d2h.end()), t_write, t_sink, stream_dense ? o.stream_dense : 0, o.out_final.c_str(),
+                    o.out_dense.c_str());
     return 0;
 }
 
