@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--lane-refill", action="store_true",
                     help="persistent grid with lane refill (a lane whose hillslope is finished or flagged takes the next one)")
     ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
+    ap.add_argument("--radau-continue", action="store_true",
+                    help="with --radau: the flagged hillslopes continue from the state RK45 reached instead of restarting at t0")
     ap.add_argument("--no-variants", action="store_true", help="skip the wet-surface variant pass")
     ap.add_argument("--no-dense", action="store_true", help="skip the dense-output (config 5 style) section")
     ap.add_argument("--dense-ns", type=int, default=1_000_000, help="hillslopes of the streamed dense-output measurement")
@@ -151,7 +153,7 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "")
+    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
     return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
@@ -673,7 +675,7 @@ def main():
     eng, total = build_engine(args, rank, world, wet=args.wet_surface, tmin=args.tmin)
     if args.radau:
         plain = eng.integrate
-        eng.integrate = lambda: plain(radau=True)
+        eng.integrate = lambda: plain(radau="continue" if args.radau_continue else True)
     elif args.compact_minutes > 0:
         eng.integrate = lambda: eng.integrate_compacting(args.compact_minutes)
     wall, kernel_ms, gather_ms = timed_passes(eng, total, world, args.warmup, args.steps)
