@@ -162,14 +162,20 @@ inline hid_t make_coord(hid_t file, const char* name, hid_t ftype, hid_t mtype, 
 
 // the "outputs" variable: contiguous, or chunked + shuffle + deflate like
 // nc_def_var_deflate(ncid, varid, 1, 1, level)
-inline hid_t make_outputs(hid_t file, int rank, const hsize_t* dims, int compression_level)
+// time_chunk > 0 (3-D, compressed): chunks span that many time steps instead of the whole time axis -- a file written
+// window by window (DenseNetcdfWriter) then touches every chunk once instead of recompressing it for every window
+inline hid_t make_outputs(hid_t file, int rank, const hsize_t* dims, int compression_level, hsize_t time_chunk = 0)
 {
     const hid_t s = H5Screate_simple(rank, dims, nullptr);
     const hid_t pl = H5Pcreate(H5P_DATASET_CREATE);
     if (compression_level > 0) {
         hsize_t chunk[3];
         hsize_t inner = 1;
-        for (int i = 1; i < rank; ++i) { chunk[i] = dims[i] ? dims[i] : 1; inner *= chunk[i]; }
+        for (int i = 1; i < rank; ++i) {
+            chunk[i] = dims[i] ? dims[i] : 1;
+            if (i == 1 && rank == 3 && time_chunk > 0 && time_chunk < chunk[i]) chunk[i] = time_chunk;
+            inner *= chunk[i];
+        }
         const hsize_t target = (4u << 20) / sizeof(double);  // ~4 MiB chunks
         chunk[0] = std::max<hsize_t>(1, std::min<hsize_t>(dims[0] ? dims[0] : 1, target / (inner ? inner : 1)));
         H5Pset_chunk(pl, rank, chunk);
@@ -236,8 +242,9 @@ done:
 // compression is asked for).  Failures are reported on stderr like the reference's writer and make ok() false.
 class DenseNetcdfWriter {
 public:
+    // window_queries: the window length the rows will arrive in (chunk shape of a compressed file; 0 = whole time axis)
     DenseNetcdfWriter(const std::string& filename, const double* time_vals, const int* linkid_vals, const int* state_vals,
-                      int num_queries, int num_systems, int N_EQ, int compression_level = 0)
+                      int num_queries, int num_systems, int N_EQ, int compression_level = 0, int window_queries = 0)
         : ns_((hsize_t)num_systems), nq_((hsize_t)num_queries), k_((hsize_t)N_EQ)
     {
         using namespace hlm_nc_detail;
@@ -258,7 +265,7 @@ public:
         HLM_NC_CHECK(put_text_attr(dt, "units", "minutes since start of simulation"));
         HLM_NC_CHECK(put_text_attr(dv, "long_name", "state variable"));
         HLM_NC_CHECK(put_text_attr(dv, "units", "various units"));
-        out_ = make_outputs(f_, 3, dims, compression_level);
+        out_ = make_outputs(f_, 3, dims, compression_level, window_queries > 0 ? (hsize_t)window_queries : 0);
         HLM_NC_CHECK(out_ >= 0);
         HLM_NC_CHECK(H5DSattach_scale(out_, ds, 0) >= 0 && H5DSattach_scale(out_, dt, 1) >= 0 && H5DSattach_scale(out_, dv, 2) >= 0);
         HLM_NC_CHECK(put_int_attr(out_, "_Netcdf4Coordinates", coords, 3, false));

@@ -50,7 +50,7 @@ int main(int argc, char** argv)
             for (int s = 0; s < ns; ++s) ids[s] = s;
             for (int q = 0; q < nq; ++q) t[q] = 60.0 * q;
             for (int c = 0; c < neq; ++c) st[c] = c;
-            DenseNetcdfWriter w(argv[2], t.data(), ids.data(), st.data(), nq, ns, neq, lvl);
+            DenseNetcdfWriter w(argv[2], t.data(), ids.data(), st.data(), nq, ns, neq, lvl, W);
             if (!w.ok()) return 4;
             for (int qb = 0; qb < nq; qb += W) {
                 const int qe = qb + W < nq ? qb + W : nq;

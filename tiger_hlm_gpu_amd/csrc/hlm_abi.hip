@@ -477,6 +477,7 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
 // Edges t0 = e_0 < e_1 < ... < e_n = tf of a window cut into pieces of `step` minutes, as t0 + k * step (never by
 // repeated addition: a step below the ulp of t would not advance, and the piece count is bounded up front).
 constexpr int kMaxPieces = 1 << 20;
+constexpr int kMaxTimedWindows = 4096;  // windowed pipelines keep four HIP events per window up to here
 int chunk_edges(double t0, double tf, double step, std::vector<double>* edge, const char* what)
 {
     edge->assign(1, t0);
@@ -823,7 +824,9 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
         ok(hipEventCreateWithFlags(&done_c[b], hipEventDisableTiming));
     }
     ok(hipMalloc(&resume, hlm_resume_bytes_model(job->uid, ns)));
-    ev.resize((size_t)nwin * 4, nullptr);
+    // per-window timing events: for up to kMaxTimedWindows windows (a run cut into more gets wall time only)
+    const bool timed = nwin <= kMaxTimedWindows;
+    ev.resize(timed ? (size_t)nwin * 4 : 0, nullptr);
     for (auto& x : ev) ok(hipEventCreate(&x));
 
     hipEvent_t wall0 = nullptr, wall1 = nullptr;
@@ -843,12 +846,12 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
         j.d_resume = resume;
         j.resume_in = k > 0;
         if (k >= 2) ok(hipStreamWaitEvent(compute, done_c[b], 0));  // buffer b is free again
-        ok(hipEventRecord(ev[4 * k + 0], compute));
+        if (timed) ok(hipEventRecord(ev[4 * k + 0], compute));
         if (e == hipSuccess) rc = launch(&j, compute);
-        ok(hipEventRecord(ev[4 * k + 1], compute));
+        if (timed) ok(hipEventRecord(ev[4 * k + 1], compute));
         ok(hipEventRecord(done_k[b], compute));
         ok(hipStreamWaitEvent(copy, done_k[b], 0));
-        ok(hipEventRecord(ev[4 * k + 2], copy));
+        if (timed) ok(hipEventRecord(ev[4 * k + 2], copy));
         if (tiled) {
             const int Wk = qe - qb;
             const dim3 grid((unsigned)nblk, (unsigned)((Wk + hlm::TILE_TQ - 1) / hlm::TILE_TQ));
@@ -860,7 +863,7 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
                                 (size_t)(qe - qb) * row, (size_t)(qe - qb) * row, (size_t)ns,
                                 hipMemcpyDeviceToHost, copy));
         }
-        ok(hipEventRecord(ev[4 * k + 3], copy));
+        if (timed) ok(hipEventRecord(ev[4 * k + 3], copy));
         ok(hipEventRecord(done_c[b], copy));
     }
     if (e == hipSuccess) ok(hipStreamSynchronize(compute));
@@ -870,7 +873,7 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
         float ms = 0.f;
         stats->windows = nwin;
         stats->dense_bytes = (uint64_t)ns * (uint64_t)nq * row;
-        for (int k = 0; k < nwin; ++k) {
+        for (int k = 0; timed && k < nwin; ++k) {
             if (hipEventElapsedTime(&ms, ev[4 * k + 0], ev[4 * k + 1]) == hipSuccess) stats->kernel_ms += ms;
             if (hipEventElapsedTime(&ms, ev[4 * k + 2], ev[4 * k + 3]) == hipSuccess) stats->copy_ms += ms;
         }
@@ -914,7 +917,8 @@ int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queri
     double* hbuf[2] = {nullptr, nullptr};  // pinned host staging
     void* resume = nullptr;
     hipEvent_t done_k[2] = {nullptr, nullptr}, done_c[2] = {nullptr, nullptr};
-    std::vector<hipEvent_t> ev((size_t)nwin * 4, nullptr);
+    const bool timed = nwin <= kMaxTimedWindows;  // per-window timing events (a run cut into more windows gets wall time only)
+    std::vector<hipEvent_t> ev(timed ? (size_t)nwin * 4 : 0, nullptr);
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
     ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
@@ -948,15 +952,15 @@ int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queri
         j.d_resume = resume;
         j.resume_in = k > 0;
         if (k >= 2) ok(hipStreamWaitEvent(compute, done_c[b], 0));  // device window b has been copied out
-        ok(hipEventRecord(ev[4 * k + 0], compute));
+        if (timed) ok(hipEventRecord(ev[4 * k + 0], compute));
         if (e == hipSuccess) rc = launch(&j, compute);
-        ok(hipEventRecord(ev[4 * k + 1], compute));
+        if (timed) ok(hipEventRecord(ev[4 * k + 1], compute));
         ok(hipEventRecord(done_k[b], compute));
         ok(hipStreamWaitEvent(copy, done_k[b], 0));
-        ok(hipEventRecord(ev[4 * k + 2], copy));
+        if (timed) ok(hipEventRecord(ev[4 * k + 2], copy));
         // (hbuf[b] is free: the sink of window k - 2 returned during iteration k - 1)
         ok(hipMemcpyAsync(hbuf[b], buf[b], (size_t)ns * (size_t)(qe - qb) * row, hipMemcpyDeviceToHost, copy));
-        ok(hipEventRecord(ev[4 * k + 3], copy));
+        if (timed) ok(hipEventRecord(ev[4 * k + 3], copy));
         ok(hipEventRecord(done_c[b], copy));
         if (k >= 1 && e == hipSuccess && rc == HLM_SUCCESS) deliver(k - 1);
     }
@@ -968,7 +972,7 @@ int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queri
         float ms = 0.f;
         stats->windows = nwin;
         stats->dense_bytes = delivered;
-        for (int k = 0; k < nwin; ++k) {
+        for (int k = 0; timed && k < nwin; ++k) {
             if (hipEventElapsedTime(&ms, ev[4 * k + 0], ev[4 * k + 1]) == hipSuccess) stats->kernel_ms += ms;
             if (hipEventElapsedTime(&ms, ev[4 * k + 2], ev[4 * k + 3]) == hipSuccess) stats->copy_ms += ms;
         }

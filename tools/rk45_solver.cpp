@@ -448,7 +448,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
                 for (int v = 0; v < width; ++v) state_vals[v] = device_select ? o.states[v] : v;
                 auto nc_name = [](std::string p) { const size_t d = p.rfind('.'); return (d == std::string::npos ? p : p.substr(0, d)) + ".nc"; };
                 DenseNetcdfWriter writer(nc_name(o.out_dense), h_query_times.data(), linkid_vals.data(), state_vals.data(), (int)nq, ns, width,
-                                         o.nc_compression);
+                                         o.nc_compression, o.stream_dense);
                 if (!writer.ok()) throw std::runtime_error("cannot create " + nc_name(o.out_dense));
                 t_h2d[r] = since(ts);
                 ts = clk::now();
