@@ -314,6 +314,10 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             // the rows of one lane interleave in the schedule)
 #pragma unroll
             for (int trip = 0; trip < R; ++trip) {
+#if HLM_ROWS_UNROLLED == 2
+                // (variant: a wave-uniform exit between the trips -- a trip no lane needs is skipped, not predicated)
+                if (trip >= 2 && __builtin_amdgcn_ballot_w64(want && next_q < q_lim) == 0ull) break;
+#endif
                 if (!(want && next_q < q_lim)) break;
 #else
             while (want && next_q < q_lim) {
