@@ -402,3 +402,24 @@ def test_cpp_params_loader_values_and_errors(hlm, golden, tmp_path):
         assert rc == 3 and lines[0].startswith("EXC " + kind), (name, lines[:1])
     rc, lines = run(tmp_path / "nowhere.csv")
     assert rc == 3 and lines[0].startswith("EXC runtime_error: Failed to open parameter file")
+
+
+def test_output_selection_is_validated_before_any_device_is_touched(hlm):
+    """hlm_set_output_states / hlm_device_job.dense_ncomp: components ascending, distinct, states of the model --
+    an argument error (1) straight from validation, with or without a GPU in the box."""
+    L = hlm._lib.lib()
+    for bad in ((3, 2), (1, 1), (-1,), (8,)):
+        arr = (C.c_int * len(bad))(*bad)
+        assert L.hlm_set_output_states(len(bad), arr) == 1, bad
+    assert L.hlm_set_output_states(9, (C.c_int * 9)(*range(9))) == 1
+    assert L.hlm_set_output_states(2, (C.c_int * 2)(1, 4)) == 0 and L.hlm_set_output_states(0, None) == 0
+    j = hlm._lib.DeviceJob()
+    j.uid, j.num_systems, j.num_queries, j.t0, j.tf = hlm._lib.UID_TOY3, 64, 4, 0.0, 10.0
+    j.d_y0 = j.d_y_final = j.d_stiff = j.d_query = j.d_dense = 4096  # never dereferenced: validation fails first
+    for k, v in enumerate((0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0)):
+        j.params[k] = v
+    j.math_mode = hlm.MATH_FAST
+    j.dense_ncomp, j.dense_comp[0] = 1, 4   # component 4 is not a state of the 3-state toy model
+    assert L.hlm_rk45_integrate_device(C.byref(j), None) == 1 and b"not a state" in L.hlm_last_error()
+    j.dense_ncomp, j.dense_comp[0], j.dense_comp[1] = 2, 2, 1
+    assert L.hlm_rk45_integrate_device(C.byref(j), None) == 1 and b"ascending" in L.hlm_last_error()

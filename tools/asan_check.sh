@@ -34,5 +34,23 @@ int main(int, char** argv) {
 CPP
 g++ $SAN $T/params.cpp -o $T/params && $T/params tests/golden/small_test.csv $T >/dev/null \
   && echo "PASS: parameters_loader.hpp, output_csv.hpp" || { echo "FAIL: parameters_loader.hpp / output_csv.hpp"; rc=1; }
+# the threaded parameter reader through its own test program (rows in order, error paths), under TSan as well
+g++ $SAN tests/cpp/test_params_loader.cpp -o $T/ploader && $T/ploader tests/golden/small_test.csv >/dev/null \
+  && { printf 'stream,next_stream\n1,2\n' > $T/short.csv; $T/ploader $T/short.csv | grep -q "Missing column"; } \
+  && echo "PASS: parameters_loader.hpp (test program, error path)" || { echo "FAIL: parameters_loader.hpp test program"; rc=1; }
+g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -Iinclude tests/cpp/test_params_loader.cpp -o $T/ploader_tsan 2>/dev/null \
+  && python3 - "$T" <<'PY' && $T/ploader_tsan $T/big.csv >/dev/null && echo "PASS: parameters_loader.hpp under TSan (several parser threads)" || { echo "FAIL: parameters_loader.hpp under TSan"; rc=1; }
+import sys
+sys.path.insert(0, ".")
+from tiger_hlm_gpu_amd import synth
+synth.write_params_csv(sys.argv[1] + "/big.csv", synth.model204_params(0, 60000))
+PY
+# the NetCDF writers incl. the windowed one (needs the HDF5 C library of the image; skipped without it)
+if [ -f /opt/conda/include/hdf5_hl.h ]; then
+  H5="-DHLM_WITH_HDF5 -isystem /opt/conda/include tools/hdf5_libs/libhdf5_hl.so tools/hdf5_libs/libhdf5.so -Wl,-rpath,$ROOT/tools/hdf5_libs"
+  [ -f tools/hdf5_libs/libhdf5.so ] || make -C tools hdf5_libs/libhdf5.so >/dev/null
+  g++ $SAN tests/cpp/test_netcdf4_io.cpp -o $T/nc $H5 && ASAN_OPTIONS=detect_leaks=0 $T/nc write_dense_windows $T/w.nc 7 500 3 0 97 \
+    && ASAN_OPTIONS=detect_leaks=0 $T/nc write_dense $T/d.nc 7 500 3 4 && echo "PASS: netcdf4_io.hpp writers (whole and windowed)" || { echo "FAIL: netcdf4_io.hpp writers"; rc=1; }
+fi
 rm -rf $T
 exit $rc
