@@ -312,3 +312,30 @@ def test_host_api_streamed_run_and_the_driver_stream_dense(gpu, golden, tmp_path
                 vals.append(open(b, "rb").read())
         blobs[tag] = vals
     assert blobs["streamed"] == blobs["whole"] and blobs["streamed_sel"] == blobs["whole_sel"]
+
+
+@pytest.mark.parametrize("layout", [0, 1, 2])
+def test_selection_on_the_three_state_model(gpu, layout):
+    """The selecting kernels are templates over Model::N_EQ like everything else: ToyModel3 (N_EQ = 3, one forcing),
+    every proper subset, all layouts and the Radau pass on its general (pivoted LU) route -- the selected columns of
+    the full run, bit for bit."""
+    H = gpu
+    from test_parity_gpu import _toy_case
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    y0, sp, inflow, cells, tf = _toy_case()
+    q = synth.minute_queries(0.0, tf, 17.0)
+
+    def run(sel, radau=False):
+        eng = ShardEngine(H.ToyModel3, y0, 0.0, tf, sp=sp, query=q, dense_tiled=layout, dense_states=sel)
+        eng.set_forcings_per_cell((inflow,), cells, (1.0,), (inflow.shape[0],))
+        eng.integrate(radau=radau)
+        return eng.results()
+    full = run(None)
+    for sel in ((0,), (1,), (2,), (0, 1), (0, 2), (1, 2)):
+        got = run(sel)
+        assert got["dense"].shape == (len(y0), len(q), len(sel))
+        assert np.array_equal(got["dense"], full["dense"][:, :, list(sel)]), (layout, sel)
+        assert np.array_equal(got["y_final"], full["y_final"])
+    with pytest.raises(H.HlmError):
+        run((3,))
