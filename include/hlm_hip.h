@@ -103,6 +103,9 @@ int hlm_set_attempt_cap(uint32_t cap);
 int hlm_set_math_mode(int mode);
 /* 1: the host API's launches without dense output use lane refill (hlm_device_job.lane_refill). */
 int hlm_set_lane_refill(int enabled);
+/* hlm_device_job.time_pieces of the host API's launches without dense output (0 / 1 = off; default 8 for launches of
+ * at least 65 536 hillslopes, where the tail of the launch is worth it; negative restores that default). */
+int hlm_set_time_pieces(int pieces);
 /* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
  * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free), every flagged system restarting at t0 as
  * radau_kernel.cu:44-52 does; 2: the same pass CONTINUING from the state each flagged system had reached
@@ -261,6 +264,14 @@ typedef struct hlm_device_job {
      * every flagged hillslope from that state -- the rows RK45 wrote up to there stay, nothing before the flag is
      * integrated twice -- taking the hillslopes flagged earliest (most left to do) first.  NULL: restart at t0. */
     double* d_flag_state;
+    /* Launch shape (build feature; csrc/hlm_rk45_queue_kernel.h).  time_pieces > 1, for a plain job without dense
+     * output (no d_resume / t_stop / query window / forcing chunk): the window [t0, tf] is cut into that many pieces
+     * and a persistent grid of waves draws (piece, 64-hillslope tile) items from a device queue until it is empty,
+     * instead of one wave per tile for the whole window -- the same integration bit for bit (a lane pauses before
+     * the first attempt that starts at or after its piece's end and continues from that state), but the launch no
+     * longer drains at its end behind the longest waves: 6 % of a 1 M-hillslope x 30-day launch.  0 / 1: one wave
+     * per tile (the reference's map, rk45_kernel.cu:33). */
+    int time_pieces;
 } hlm_device_job;
 
 size_t hlm_resume_bytes_model(int uid, int num_systems); /* (N_EQ + 2) doubles + 5 int32 per system */

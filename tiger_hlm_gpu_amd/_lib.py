@@ -60,7 +60,7 @@ class DeviceJob(C.Structure):
         ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
         ("lane_refill", C.c_int),
         ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
-        ("d_flag_state", C.c_void_p),
+        ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int),
     ]
 
 
@@ -92,6 +92,7 @@ SIGNATURES = {
     "hlm_set_radau_fallback": (C.c_int, [C.c_int]),
     "hlm_set_lane_refill": (C.c_int, [C.c_int]),
     "hlm_set_output_states": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
+    "hlm_set_time_pieces": (C.c_int, [C.c_int]),
     "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
                                    C.c_int64, C.c_void_p]),
     "hlm_set_forcings_host": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,

@@ -110,6 +110,13 @@ def set_lane_refill(enabled):
     check(lib().hlm_set_lane_refill(int(bool(enabled))))
 
 
+def set_time_pieces(pieces):
+    """Launch shape of the host API's runs without dense output (hlm_set_time_pieces): > 1 = a persistent grid over a
+    queue of (time piece, tile) items; 0 / 1 = one wave per tile; negative = the library's default (8 pieces from
+    65 536 hillslopes on)."""
+    check(lib().hlm_set_time_pieces(int(pieces)))
+
+
 def set_radau_fallback(enabled):
     """Host API (run_rk45 / launch_rk45_kernel): re-integrate flagged systems with Radau IIA.  False / 0: off
     (the reference's observable behaviour); True / 1: every flagged system restarts at t0 (radau_kernel.cu:44-52);

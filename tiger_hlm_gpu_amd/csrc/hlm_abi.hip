@@ -17,6 +17,7 @@
 #include "hlm_radau_kernel.h"
 #include "hlm_rk45_dense_kernel.h"
 #include "hlm_rk45_kernel.h"
+#include "hlm_rk45_queue_kernel.h"
 #include "hlm_rk45_refill_kernel.h"
 
 namespace {
@@ -79,6 +80,8 @@ int g_stream_layout = hlm::DENSE_TILE_COMP;  // device layout of the tiled strea
 int g_math = HLM_MATH_FAST;
 bool g_math_explicit = false;
 int g_refill = 0;  // hlm_set_lane_refill(): host-API launches without dense output use the refill kernel
+int g_time_pieces = -1;  // hlm_set_time_pieces(): < 0 = automatic (kAutoTimePieces from kAutoTimePiecesMinSystems hillslopes on)
+constexpr int kAutoTimePieces = 8, kAutoTimePiecesMinSystems = 65536, kMaxTimePieces = 4096;
 int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
 // hlm_set_output_states(): the dense rows of the host API carry only these state components (0 = all)
 int g_out_ncomp = 0;
@@ -217,6 +220,20 @@ RefillFn pick_refill(int uid, int math, bool fixed)
     return with_model<RefillFn>(uid, [&](auto m) { return pick_refill<decltype(m)>(math, fixed); });
 }
 
+// the persistent kernels over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): no dense output
+using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int);
+template <class Model>
+QueueFn pick_queue(int math, bool fixed)
+{
+    using namespace hlm;
+    if (math == HLM_MATH_FAST) return fixed ? rk45_queue_kernel<Model, MATH_FAST, true> : rk45_queue_kernel<Model, MATH_FAST, false>;
+    return fixed ? rk45_queue_kernel<Model, MATH_STRICT, true> : rk45_queue_kernel<Model, MATH_STRICT, false>;
+}
+QueueFn pick_queue(int uid, int math, bool fixed)
+{
+    return with_model<QueueFn>(uid, [&](auto m) { return pick_queue<decltype(m)>(math, fixed); });
+}
+
 KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
 {
     return with_model<KernelFn>(uid, [&](auto m) { return pick_kernel<decltype(m)>(math, dense, fixed, resumable); });
@@ -282,6 +299,7 @@ int validate_job(const hlm_device_job* j)
     if (j->dense_tiled < 0 || j->dense_tiled > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0, 1 or 2");
     if (const int rcs = validate_selection(j->uid, j->dense_ncomp, j->dense_comp); rcs != HLM_SUCCESS) return rcs;
     if (j->lane_refill != 0 && j->lane_refill != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane_refill must be 0 or 1");
+    if (j->time_pieces < 0 || j->time_pieces > kMaxTimePieces) return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces must be in [0, %d]", kMaxTimePieces);
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
@@ -376,11 +394,44 @@ int launch_refill(const hlm_device_job* j, hipStream_t stream)
     return HLM_SUCCESS;
 }
 
+// Persistent launch over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): as many one-wave workgroups as
+// the device holds at once; the lane states between the pieces live in a stream-ordered scratch allocation.
+int launch_queue(const hlm_device_job* j, hipStream_t stream)
+{
+    const bool fixed = j->fixed_step > 0.0;
+    QueueFn fn = pick_queue(j->uid, j->math_mode, fixed);
+    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
+    int dev = 0, cus = 0, per_cu = 0;
+    HLM_HIP_TRY(hipGetDevice(&dev));
+    HLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HLM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), hlm::WAVE, 0));
+    const long long resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
+    const long long tiles = ((long long)j->num_systems + hlm::WAVE - 1) / hlm::WAVE;
+    const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
+    const size_t rbytes = (hlm_resume_bytes_model(j->uid, j->num_systems) + 15u) & ~(size_t)15u;
+    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + 1);
+    char* pool = nullptr;
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + qbytes, stream));
+    unsigned int* queue = reinterpret_cast<unsigned int*>(pool + rbytes);
+    if (hipError_t e = hipMemsetAsync(queue, 0, qbytes, stream); e != hipSuccess) {
+        (void)hipFreeAsync(pool, stream);
+        return fail(HLM_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
+    }
+    hlm::Rk45Args a = make_args(j);
+    a.resume = reinterpret_cast<double*>(pool);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, j->time_pieces);
+    const hipError_t launched = hipGetLastError();
+    HLM_HIP_TRY(hipFreeAsync(pool, stream));  // stream-ordered: after the kernel
+    HLM_HIP_TRY(launched);
+    return HLM_SUCCESS;
+}
+
 int launch(const hlm_device_job* j, hipStream_t stream)
 {
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
     if (!dense && j->lane_refill && !job_is_resumable(j)) return launch_refill(j, stream);
+    if (!dense && j->time_pieces > 1 && !job_is_resumable(j)) return launch_queue(j, stream);
     KernelFn fn = dense && job_selects(j) ? pick_selecting(j->uid, j->math_mode, fixed, j->dense_tiled == hlm::DENSE_TILE_COMP)
                   : dense && j->dense_tiled == hlm::DENSE_TILE_COMP
                       ? pick_dense_ring(j->uid, j->math_mode, fixed, job_is_resumable(j))
@@ -504,6 +555,7 @@ int fill_job_from_registry(hlm_device_job* j, int uid, const ForcingState& F)
     j->fixed_step = m->fixed_step;
     j->attempt_cap = g_cap;
     j->lane_refill = g_refill;
+    j->time_pieces = g_time_pieces;  // (< 0: resolved by the caller once it knows the number of systems)
     j->math_mode = g_math;
     if (!g_math_explicit && !(m->p[2] >= 1e-60 && m->p[2] <= 1e50)) j->math_mode = HLM_MATH_STRICT;
     j->d_forc = F.d_forc;
@@ -727,6 +779,14 @@ int hlm_set_output_states(int n, const int* comps)
     std::lock_guard<std::mutex> lk(g_mu);
     g_out_ncomp = n;
     for (int k = 0; k < HLM_MAX_NEQ; ++k) g_out_comp[k] = k < n ? comps[k] : 0;
+    return HLM_SUCCESS;
+}
+
+int hlm_set_time_pieces(int pieces)
+{
+    if (pieces > kMaxTimePieces) return fail(HLM_ERR_INVALID_ARGUMENT, "time pieces %d (at most %d)", pieces, kMaxTimePieces);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_time_pieces = pieces < 0 ? -1 : pieces;
     return HLM_SUCCESS;
 }
 
@@ -1316,6 +1376,7 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     } release{slot};
     j.num_systems = b->num_systems;
     j.num_queries = b->num_queries;
+    if (j.time_pieces < 0) j.time_pieces = j.num_systems >= kAutoTimePiecesMinSystems ? kAutoTimePieces : 0;
     j.t0 = t0;
     j.tf = tf;
     j.d_y0 = b->d_y0_all;
@@ -1455,6 +1516,7 @@ int hlm_run_rk45_streamed(int uid, const double* h_y0, int ns, double t0, double
     } release{slot};
     j.num_systems = ns;
     j.num_queries = nq;
+    j.time_pieces = 0;  // (a launch shape of runs without dense output)
     j.t0 = t0;
     j.tf = tf;
     j.d_y0 = b.d_y0_all;

@@ -1,0 +1,156 @@
+// The RK45 loop of hlm_rk45_kernel.h as a PERSISTENT grid over a queue of (time chunk, tile) items: the window
+// [t0, tf] is cut into nchunk pieces, a tile is 64 consecutive hillslopes, and every resident wave keeps drawing the
+// next item -- chunk-major, so item (c, tile) is drawn a whole chunk of tiles after (c - 1, tile) -- until the queue
+// is empty.  Same integration, bit for bit (a lane pauses before the first attempt whose start time has reached the
+// chunk's end and continues from that state: the protocol of the RESUMABLE launches, tested against the uninterrupted
+// run); what changes is the SHAPE of the launch.
+//
+// Why.  One launch of the fixed map (rk45_multi_kernel: one wave per tile, grid = ceil(ns / 64)) drains at its end:
+// 15 625 waves on 3 072 resident slots are 5.09 rounds of 31 ms waves, the waves of a round do not finish together
+// (a rainy forcing cell costs 7 % more attempts than the mean), and the last stragglers run on a nearly empty
+// machine.  Measured on MI355X (headline workload): 160.3 ms for 1 M hillslopes, but 150.5 ms per million in a
+// 4 M launch (20 rounds amortise the same drain) -- 6 % of the 1 M launch is its tail.  With the window cut into
+// pieces the slots never run dry before the last piece, and the drain is that of a wave 1/nchunk as long.
+//
+// Restates reference src/solver/rk45_kernel.cu:17-176 like rk45_multi_kernel (no dense output here: the dense
+// kernels keep the fixed map).  Ordering between the pieces of one tile: a per-tile counter of finished pieces,
+// written with an agent-scope release after the state record and awaited with an acquire by the wave that draws the
+// next piece.  The awaited piece was drawn earlier (the queue is chunk-major), so it is finished or running on a
+// resident wave: the wait cannot deadlock, and with more tiles than resident waves it never waits at all.
+#pragma once
+
+#include "hlm_rk45_kernel.h"
+
+namespace hlm {
+
+// queue[0]: next item; queue[1 + tile]: pieces of `tile` finished so far.  The resume record (A.resume, SoA as in
+// the RESUMABLE kernels: y[N_EQ], t, h | reject_count, n_attempt, n_accept, next_q, status) carries the lanes.
+template <class Model, int MATH, bool FIXED>
+__global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
+    rk45_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nchunk)
+{
+    using namespace dp;
+    constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
+    const int lane = (int)threadIdx.x;
+    const unsigned ntiles = ((unsigned)A.ns + WAVE - 1u) / WAVE, nitems = ntiles * (unsigned)nchunk;
+    unsigned int* const done = queue + 1;
+    int* const resume_i = reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns);
+    const double tf = A.tf;
+    const double piece = (tf - A.t0) / (double)nchunk;
+
+    while (true) {
+        unsigned item = 0;
+        if (lane == 0) item = atomicAdd(queue, 1u);
+        item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+        if (item >= nitems) break;
+        const unsigned c = item / ntiles, tile = item - c * ntiles;
+        const int sys = (int)(tile * WAVE) + lane;
+        if (c > 0) {
+            // the previous piece of this tile: finished long ago when there are more tiles than resident waves
+            if (lane == 0)
+                while (__hip_atomic_load(&done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) __builtin_amdgcn_s_sleep(16);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // its state record is visible to every lane from here
+        }
+        // lanes pause the first time t reaches the end of their piece (the last piece runs to tf)
+        const double t_end = c + 1u < (unsigned)nchunk ? fmin(tf, A.t0 + (double)(c + 1u) * piece) : tf;
+
+        if (sys < A.ns) {
+            int status = HLM_SYS_OK;
+            bool runs = true;
+            if (c > 0) {
+                status = resume_i[(size_t)4 * A.ns + sys];
+                runs = status == SYS_PAUSED;  // else: finished or flagged in an earlier piece, its outputs were written then
+                if (runs) status = HLM_SYS_OK;
+            }
+            if (runs) {
+                const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
+                double y[NEQ];
+                double t = A.t0;
+                double h = FIXED ? A.fixed_step : A.h0;
+                int reject_count = 0;
+                uint32_t n_attempt = 0, n_accept = 0;
+                if (c == 0) {
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
+                    t = A.resume[(size_t)NEQ * A.ns + sys];
+                    h = A.resume[(size_t)(NEQ + 1) * A.ns + sys];
+                    reject_count = resume_i[(size_t)0 * A.ns + sys];
+                    n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
+                    n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
+                }
+                HeldForcing<Model, false> held;  // the samples of the first attempt are fetched at its t (as a resumed lane does)
+                held.init(A, sys);
+                typename Model::Forc FV = Model::prep_forcing(P, held.F);
+                bool have_k0 = false;  // k0 = rhs(t, y, F) is a pure function: recomputed, it has the bits of the carried one
+                double k0[NEQ];
+
+                // ---- the loop of rk45_multi_kernel --------------------------------------------------------
+                while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
+                    if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
+                    if (held.refresh(A, P, t, FV)) have_k0 = false;
+                    ++n_attempt;
+                    double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
+                    [[maybe_unused]] double err = 0.0, jump = 0.0;
+                    attempt_on_cheapest_path<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                    [[maybe_unused]] double fac = 1.0;
+                    if constexpr (!FIXED) {
+                        fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);  // rk45_kernel.cu:151,156
+                        if (err <= 1.0) {
+                            reject_count = 0;
+                            if (jump > SLOPE_JUMP_THRESH) {  // rk45_kernel.cu:132-136
+                                h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
+                                continue;
+                            }
+                        } else {  // rk45_kernel.cu:153-163
+                            ++reject_count;
+                            double f = fmin(fac, 1.0);
+                            f = fmin(fmax(f, A.min_scale), A.max_scale);
+                            h *= f;
+                            if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) status = HLM_SYS_STIFF;
+                            continue;
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) {
+                        y[i] = yt[i];
+                        k0[i] = k6[i];  // = rhs(t1, y_new, F): next attempt's k0 unless the forcing moves
+                    }
+                    t += h;
+                    ++n_accept;
+                    if constexpr (FIXED) h = A.fixed_step;
+                    else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+                }
+
+                if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
+                if (status == HLM_SYS_OK && t < tf) {
+                    // paused at the end of its piece: the next piece continues exactly here
+                    resume_i[(size_t)4 * A.ns + sys] = SYS_PAUSED;
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
+                    A.resume[(size_t)NEQ * A.ns + sys] = t;
+                    A.resume[(size_t)(NEQ + 1) * A.ns + sys] = h;
+                    resume_i[(size_t)0 * A.ns + sys] = reject_count;
+                    resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
+                    resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
+                } else {
+                    resume_i[(size_t)4 * A.ns + sys] = status;
+                    if (A.n_attempt) A.n_attempt[sys] = n_attempt;
+                    if (A.n_accept) A.n_accept[sys] = n_accept;
+                    const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170
+                    A.stiff[sys] = flagged ? status : HLM_SYS_OK;
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
+                    if (A.flag_state && flagged) record_flag_state<NEQ>(A.flag_state, sys, y, t);
+                }
+            }
+        }
+        // publish the piece: state record first, then the tile's counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(&done[tile], c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+}  // namespace hlm

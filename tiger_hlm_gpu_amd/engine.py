@@ -15,7 +15,7 @@ from .models import Parameters, SP_DTYPE
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
                  math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
-                 dense_tiled=2, lane_refill=False, dense_states=None):
+                 dense_tiled=2, lane_refill=False, dense_states=None, time_pieces=None):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -25,6 +25,9 @@ class ShardEngine:
         self.params = params if params is not None else Parameters()
         self.math_mode, self.fixed_step, self.attempt_cap = math_mode, fixed_step, attempt_cap
         self.lane_refill = int(bool(lane_refill))  # hlm_device_job.lane_refill (launches without dense output)
+        # hlm_device_job.time_pieces (launches without dense output): a persistent grid over (time piece, tile) items
+        # instead of one wave per tile; None = the host API's default rule (8 pieces from 65 536 hillslopes on)
+        self.time_pieces = time_pieces
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
         self.ns = y0.shape[0]
         dev = self.device
@@ -98,6 +101,10 @@ class ShardEngine:
             dense_states=self.dense_states)
         j.dense_tiled = self.dense_tiled if self.dense is not None else 0
         j.lane_refill = self.lane_refill
+        tp = self.time_pieces
+        j.time_pieces = (8 if self.ns >= 65536 else 0) if tp is None else int(tp)
+        if self.dense is not None or self.nq:
+            j.time_pieces = 0
         return j
 
     def integrate(self, stream=None, t_stop=None, resume_in=False, radau=False):
