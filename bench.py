@@ -90,6 +90,9 @@ def parse():
                     help="lower end of the daily temperatures; -5 is SURVEY 8d's C3 generator (cold cells get flagged stiff)")
     ap.add_argument("--compact-minutes", type=float, default=0.0,
                     help="> 0: the pass in launches of this many minutes with the surviving hillslopes compacted between them")
+    ap.add_argument("--time-pieces", type=int, default=-1,
+                    help="launch shape of the pass without dense output (hlm_device_job.time_pieces): > 1 = persistent grid "
+                         "over (time piece, tile) items, 0 = one wave per tile (the reference's map), -1 = the library's automatic rule")
     ap.add_argument("--lane-refill", action="store_true",
                     help="persistent grid with lane refill (a lane whose hillslope is finished or flagged takes the next one)")
     ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
@@ -143,7 +146,7 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
     eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q,
                       math_mode=H.MATH_FAST if (math or args.math) == "fast" else H.MATH_STRICT,
                       device=f"cuda:{torch.cuda.current_device()}", dense_tiled=args.dense_tiled,
-                      lane_refill=args.lane_refill)
+                      lane_refill=args.lane_refill, time_pieces=None if args.time_pieces < 0 else args.time_pieces)
     if args.layout == "per-stream":
         eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     else:
@@ -153,7 +156,7 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
+    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
     return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
@@ -707,8 +710,10 @@ def main():
     value = attempts_all * args.steps / wall
     ms_per_step = 1e3 * wall / args.steps
 
-    # dominant (only) kernel on this rank: rk45_multi_kernel<Model204Dev,...>
+    # dominant (only) kernel on this rank: rk45_queue_kernel<Model204Dev,...> (persistent grid over (time piece, tile)
+    # items) or, for small launches / --time-pieces 0, rk45_multi_kernel<Model204Dev,...> (one wave per tile)
     k_ms = float(np.mean(kernel_ms))
+    pieces = H.api.time_pieces_for(eng.job())
     local_attempts = eng.total_attempts()
     nq = eng.nq
     forc_bytes = 4.0 * sum(eng.forc_nT) * (eng.ns if args.layout == "per-stream" else eng.forc_ld)
@@ -725,7 +730,7 @@ def main():
                    eng.ns, total, args.days, args.layout,
                    "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})", args.math)
                 + (f", launches of {args.compact_minutes:g} min with compaction" if args.compact_minutes > 0 else "")
-                + (", lane refill" if args.lane_refill else "") + (", WET surface store" if args.wet_surface else "") + (f", T in [{args.tmin:g}, 15]" if args.tmin != 0.5 else "")
+                + (", lane refill" if args.lane_refill else "") + (f", {pieces} time pieces" if pieces else "") + (", WET surface store" if args.wet_surface else "") + (f", T in [{args.tmin:g}, 15]" if args.tmin != 0.5 else "")
                 + (", + Radau-IIA fallback" if args.radau else ""))
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/); only quoted
     # when they were collected on this same per-GPU workload
@@ -756,7 +761,9 @@ def main():
         "roofline": {"bound": "hbm", "achieved": hbm_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                      "frac": hbm_gbs / PEAK_HBM_GBS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": algo_bytes, "kernel_ms": k_ms,
-                     "kernel": "hlm::rk45_multi_kernel<Model204Dev>",
+                     "kernel": ("hlm::rk45_refill_kernel<Model204Dev>" if args.lane_refill and nq == 0 else
+                                "hlm::rk45_queue_kernel<Model204Dev>" if pieces else "hlm::rk45_multi_kernel<Model204Dev>"),
+                     "time_pieces": pieces,
                      "note": "0.19 algorithmic bytes per RK45 step: this kernel cannot be HBM-bound; its binding "
                              "roofline is roofline_valu_fp64 (FP64 vector ALU, no MFMA in a per-lane ODE)"},
         "roofline_valu_fp64": {"bound": "valu_fp64", "achieved": valu_tf, "peak": PEAK_FP64_VALU_TFLOPS,
@@ -771,6 +778,19 @@ def main():
         out["gather_ms_rank0_each"] = gather_ms
         out["gather_bytes_per_pass"] = 52.0 * total
         out["gather_collective"] = gather_collective()   # decided from the backend's name before any communication
+
+    if not args.no_variants and rank == 0 and world == 1 and pieces and nq == 0:
+        # the same pass as one wave per tile (the reference's map, rk45_kernel.cu:33): what the launch shape is worth
+        def _fixed_map():
+            eng.time_pieces = 0
+            try:
+                _, kms, _ = timed_passes(eng, total, 1, 1, 2)
+            finally:
+                eng.time_pieces = None if args.time_pieces < 0 else args.time_pieces
+            return {"kernel": "hlm::rk45_multi_kernel<Model204Dev>", "kernel_ms_each": kms,
+                    "queue_kernel_over_fixed_map": k_ms / float(np.mean(kms)), "time_pieces": pieces,
+                    "note": "same bits; the queue kernel removes the drain at the end of the launch"}
+        out["launch_shape"] = _optional(_fixed_map)
 
     if not args.no_variants and rank == 0 and world == 1:
         # extra single passes of the same shard: wet surface store (the Manning x^(2/3)

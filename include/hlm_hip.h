@@ -103,8 +103,8 @@ int hlm_set_attempt_cap(uint32_t cap);
 int hlm_set_math_mode(int mode);
 /* 1: the host API's launches without dense output use lane refill (hlm_device_job.lane_refill). */
 int hlm_set_lane_refill(int enabled);
-/* hlm_device_job.time_pieces of the host API's launches without dense output (0 / 1 = off; default 8 for launches of
- * at least 65 536 hillslopes, where the tail of the launch is worth it; negative restores that default). */
+/* hlm_device_job.time_pieces of the host API's launches without dense output: 0 / 1 = one wave per tile; negative
+ * (the default) = automatic: from 65 536 hillslopes on, one piece per two simulated days, at most 16. */
 int hlm_set_time_pieces(int pieces);
 /* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
  * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free), every flagged system restarting at t0 as
@@ -270,9 +270,14 @@ typedef struct hlm_device_job {
      * instead of one wave per tile for the whole window -- the same integration bit for bit (a lane pauses before
      * the first attempt that starts at or after its piece's end and continues from that state), but the launch no
      * longer drains at its end behind the longest waves: 6 % of a 1 M-hillslope x 30-day launch.  0 / 1: one wave
-     * per tile (the reference's map, rk45_kernel.cu:33). */
+     * per tile (the reference's map, rk45_kernel.cu:33).  Negative: automatic -- from 65 536 hillslopes on, one piece
+     * per two simulated days, at most 16; one wave per tile below that.  At most 4096. */
     int time_pieces;
 } hlm_device_job;
+
+/* The number of time pieces hlm_rk45_integrate_device(job) launches with (the automatic rule resolved; 0 = one wave
+ * per tile: dense output, a resumable job, lane refill, or too small a launch).  No device is touched. */
+int hlm_time_pieces_for(const hlm_device_job* job);
 
 size_t hlm_resume_bytes_model(int uid, int num_systems); /* (N_EQ + 2) doubles + 5 int32 per system */
 size_t hlm_resume_bytes(int num_systems);                /* the N_EQ = 5 models: 76 bytes per system */

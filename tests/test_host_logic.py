@@ -18,7 +18,7 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 43
+    assert len(names) == 44
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
@@ -350,6 +350,22 @@ def test_piece_count_of_chunked_launches_is_bounded(hlm):
     ptrs = (C.c_void_p * 1)(tab.ctypes.data)
     rc = L.hlm_rk45_integrate_forcing_streamed(C.byref(j), ptrs, 1e-30, None, None)
     assert rc == 1 and b"pieces" in L.hlm_last_error()
+
+
+def test_time_pieces_argument_is_validated_without_a_device(hlm):
+    """hlm_device_job.time_pieces / hlm_set_time_pieces: at most 4096 pieces (negative = automatic); refused before
+    anything touches a device."""
+    L = hlm._lib.lib()
+    assert L.hlm_set_time_pieces(4097) == 1 and b"4096" in L.hlm_last_error()
+    for ok in (0, 1, 16, 4096, -1):
+        assert L.hlm_set_time_pieces(ok) == 0
+    j = hlm._lib.DeviceJob()
+    j.uid, j.num_systems, j.num_queries, j.t0, j.tf = hlm.UID_DUMMY, 64, 0, 0.0, 5.0
+    j.d_y0 = j.d_y_final = j.d_stiff = 4096  # never dereferenced: validation fails first
+    for k, v in enumerate((0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0)):
+        j.params[k] = v
+    j.time_pieces = 4097
+    assert L.hlm_rk45_integrate_device(C.byref(j), None) == 1 and b"time_pieces" in L.hlm_last_error()
 
 
 def test_cpp_params_loader_values_and_errors(hlm, golden, tmp_path):

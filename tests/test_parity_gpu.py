@@ -942,7 +942,7 @@ def test_lane_refill_is_bit_identical_to_the_fixed_map(gpu, case):
         ns = 777
         model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 50.0, dict(fixed_step=0.05)
     forcing = None if sp is None else (pr, t2m, synth.cell_of_system(0, ns, run_len=64), dt, nT)
-    a = _run_engine(H, model, y0, 0.0, tf, sp=sp, forcing=forcing, per_cell=True, **kw)
+    a = _run_engine(H, model, y0, 0.0, tf, sp=sp, forcing=forcing, per_cell=True, time_pieces=0, **kw)
     b = _run_engine(H, model, y0, 0.0, tf, sp=sp, forcing=forcing, per_cell=True, lane_refill=True, **kw)
     for k in ("y_final", "stiff", "n_attempt", "n_accept"):
         assert np.array_equal(a[k], b[k]), (case, k)
@@ -950,6 +950,111 @@ def test_lane_refill_is_bit_identical_to_the_fixed_map(gpu, case):
         assert 0.05 < (a["stiff"] == 1).mean() < 0.95
     if case == "dummy-capped":
         assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()
+
+
+@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step", "toy", "strict-wet", "empty-window"])
+def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
+    """hlm_device_job.time_pieces (csrc/hlm_rk45_queue_kernel.h): the window cut into pieces, a persistent grid of
+    waves drawing (piece, tile) items from a device queue.  The launch shape changes, nothing else: finals, flags and
+    both counters of every hillslope equal the one-wave-per-tile launch (rk45_kernel.cu:33) bit for bit -- cold cells
+    flagged in different pieces, the benchmark workload (more tiles than resident waves), fewer hillslopes than a wave
+    (a wave waits for its own previous piece), the attempt cap hit in the first piece, fixed steps, the 3-state model,
+    STRICT math on a wet surface, an empty window; piece counts 2 ... 64, incl. more pieces than forcing samples."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    kw, pieces = {}, (2, 5, 16)
+    if case == "cold-cells":
+        ns, days = 250_037, 6
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
+    elif case == "benchmark":
+        ns, days, pieces = 300_000, 2, (3, 8)
+        pr, t2m, dt, nT = synth.forcing_tables(days=days)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
+    elif case == "ragged-small":
+        ns, days, pieces = 37, 3, (2, 7, 64)
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=True), synth.model204_params(0, ns), days * 1440.0
+    elif case == "dummy-capped":
+        ns = 1000
+        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 500.0, dict(attempt_cap=100)
+    elif case == "fixed-step":
+        ns = 777
+        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 50.0, dict(fixed_step=0.05)
+    elif case == "toy":
+        y0, sp, inflow, cells, tf = _toy_case(ns=1300)
+        model, ns = H.ToyModel3, len(y0)
+    elif case == "strict-wet":
+        ns, days, kw = 5000, 2, dict(math_mode=H.MATH_STRICT)
+        pr, t2m, dt, nT = synth.forcing_tables(days=days)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=True), synth.model204_params(0, ns), days * 1440.0
+    else:
+        ns, days, pieces = 200, 1, (4,)
+        pr, t2m, dt, nT = synth.forcing_tables(days=days)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), 0.0   # tf == t0
+
+    def run(p):
+        from tiger_hlm_gpu_amd.engine import ShardEngine
+        eng = ShardEngine(model, y0, 0.0, tf, sp=sp, time_pieces=p, **kw)
+        if case == "toy":
+            eng.set_forcings_per_cell((inflow,), cells, (1.0,), (inflow.shape[0],))
+        elif sp is not None:
+            eng.set_forcings_per_cell((pr, t2m), synth.cell_of_system(0, ns, run_len=64), dt, nT)
+        eng.integrate()
+        return eng.results()
+    a = run(0)
+    for p in pieces:
+        b = run(p)
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(a[k], b[k]), (case, p, k)
+    if case == "cold-cells":
+        assert 0.05 < (a["stiff"] == 1).mean() < 0.95
+    if case == "dummy-capped":
+        assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()
+    if case == "empty-window":
+        assert np.array_equal(a["y_final"], y0) and (a["n_attempt"] == 0).all()
+
+
+def test_time_pieces_default_rule_and_the_radau_hand_over(gpu):
+    """The automatic launch shape (hlm_set_time_pieces(-1): from 65 536 hillslopes on, one piece per two simulated
+    days, at most 16) gives the host API's run_rk45 the same bits as the forced fixed map, and a flagged hillslope
+    leaves the same flag state for the Radau pass whichever kernel integrated it."""
+    H = gpu
+    import torch
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    api = H.api
+    ns, days = 70_000, 5
+    sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns)
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    tf = days * 1440.0
+    d_sp = api.upload_spatial_params(sp)
+    f = api.set_forcings(np.concatenate([pr, t2m], axis=0), dt, nT, pr.shape[1], col=cells)
+    try:
+        api.set_time_pieces(0)
+        fixed, _, info0 = api.run_rk45(H.Model204, y0, 0.0, tf, None, d_sp, with_info=True)
+        api.set_time_pieces(-1)     # automatic: 70 000 hillslopes x 5 days -> 2 pieces
+        auto, _, info1 = api.run_rk45(H.Model204, y0, 0.0, tf, None, d_sp, with_info=True)
+        assert np.array_equal(fixed, auto) and all(np.array_equal(info0[k], info1[k]) for k in info0)
+        with pytest.raises(H.HlmError):
+            api.set_time_pieces(5000)
+    finally:
+        api.set_time_pieces(-1)
+        f.free()
+        d_sp.free()
+    res = []
+    for p in (0, 6):
+        eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, time_pieces=p)
+        eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+        eng.integrate(radau="continue")
+        torch.cuda.synchronize()
+        res.append((eng.results(), eng._flag_state.cpu().numpy().reshape(ns, 6)))
+    fl = res[0][0]["stiff"] == 1
+    assert 100 < fl.sum() < ns
+    assert np.array_equal(res[0][1][fl], res[1][1][fl])                      # the same {y, t} left at every flag
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(res[0][0][k], res[1][0][k]), k
 
 
 # ---- the plug-in surface is generic: a model with N_EQ = 3 and one forcing -------------------------------

@@ -112,9 +112,14 @@ def set_lane_refill(enabled):
 
 def set_time_pieces(pieces):
     """Launch shape of the host API's runs without dense output (hlm_set_time_pieces): > 1 = a persistent grid over a
-    queue of (time piece, tile) items; 0 / 1 = one wave per tile; negative = the library's default (8 pieces from
-    65 536 hillslopes on)."""
+    queue of (time piece, tile) items; 0 / 1 = one wave per tile; negative = automatic (from 65 536 hillslopes
+    on, one piece per two simulated days, at most 16)."""
     check(lib().hlm_set_time_pieces(int(pieces)))
+
+
+def time_pieces_for(job):
+    """The number of time pieces integrate_device(job) launches with (0 = one wave per tile)."""
+    return int(lib().hlm_time_pieces_for(C.byref(job)))
 
 
 def set_radau_fallback(enabled):

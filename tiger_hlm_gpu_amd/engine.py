@@ -26,7 +26,8 @@ class ShardEngine:
         self.math_mode, self.fixed_step, self.attempt_cap = math_mode, fixed_step, attempt_cap
         self.lane_refill = int(bool(lane_refill))  # hlm_device_job.lane_refill (launches without dense output)
         # hlm_device_job.time_pieces (launches without dense output): a persistent grid over (time piece, tile) items
-        # instead of one wave per tile; None = the host API's default rule (8 pieces from 65 536 hillslopes on)
+        # instead of one wave per tile; None = the host API's automatic rule (from 65 536 hillslopes on, one piece per
+        # two simulated days, at most 16)
         self.time_pieces = time_pieces
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
         self.ns = y0.shape[0]
@@ -102,7 +103,7 @@ class ShardEngine:
         j.dense_tiled = self.dense_tiled if self.dense is not None else 0
         j.lane_refill = self.lane_refill
         tp = self.time_pieces
-        j.time_pieces = (8 if self.ns >= 65536 else 0) if tp is None else int(tp)
+        j.time_pieces = -1 if tp is None else int(tp)
         if self.dense is not None or self.nq:
             j.time_pieces = 0
         return j

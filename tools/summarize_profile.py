@@ -33,7 +33,10 @@ stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
 lines = open(stats).read().splitlines()
 with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("\n".join(lines[:12]) + "\n")
-kstat = next(r for r in csv.DictReader(open(stats)) if "rk45_multi_kernel" in r["Name"])
+# the headline kernel: the queue kernel (persistent grid over (time piece, tile) items) or, with --time-pieces 0,
+# the one-wave-per-tile kernel; the busiest of them in this trace
+kstat = max((r for r in csv.DictReader(open(stats)) if "rk45_queue_kernel" in r["Name"] or "rk45_multi_kernel" in r["Name"]),
+            key=lambda r: float(r["Percentage"]))
 
 out = {"kernel": kstat["Name"], "calls": int(kstat["Calls"]), "avg_duration_ms": float(kstat["AverageNs"]) / 1e6,
        "min_duration_ms": float(kstat["MinNs"]) / 1e6, "max_duration_ms": float(kstat["MaxNs"]) / 1e6,
