@@ -2,6 +2,7 @@
 GPU, parameter/lookup readers, synthetic generators, shard rule.  No compute calls."""
 import ctypes as C
 import os
+import sys
 import re
 
 import numpy as np
@@ -366,6 +367,21 @@ def test_time_pieces_argument_is_validated_without_a_device(hlm):
         j.params[k] = v
     j.time_pieces = 4097
     assert L.hlm_rk45_integrate_device(C.byref(j), None) == 1 and b"time_pieces" in L.hlm_last_error()
+
+
+def test_queue_kernels_keep_the_item_loop_wave_uniform():
+    """csrc/hlm_rk45_queue_kernel.h: the loop over (piece, tile) items must stay uniform over the wave in every
+    instance -- with `if (lane == 0)` around the draw the compiler once let lane 0 leave the loop alone (Dummy FAST
+    instance: the other 63 lanes repeated item 0 for ever).  tools/check_queue_isa.py reads the assembler's loop
+    structure of all 12 instances from a fresh `make asm`."""
+    import subprocess
+    csrc = os.path.join(ROOT, "tiger_hlm_gpu_amd", "csrc")
+    asm = os.path.join(ROOT, "build", "hlm_abi-hip-amdgcn-amd-amdhsa-gfx950.s")
+    srcs = [os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".h", ".hip"))]
+    if not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(f) for f in srcs):
+        subprocess.run(["make", "-C", csrc, "asm"], check=True, capture_output=True)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_queue_isa.py"), asm], capture_output=True, text=True)
+    assert r.returncode == 0 and "12 instances, 0 bad" in r.stdout, r.stdout + r.stderr
 
 
 def test_cpp_params_loader_values_and_errors(hlm, golden, tmp_path):

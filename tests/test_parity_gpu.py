@@ -952,14 +952,16 @@ def test_lane_refill_is_bit_identical_to_the_fixed_map(gpu, case):
         assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()
 
 
-@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step", "toy", "strict-wet", "empty-window"])
+@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step", "fixed-step-short", "toy", "strict-wet", "empty-window"])
 def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
     """hlm_device_job.time_pieces (csrc/hlm_rk45_queue_kernel.h): the window cut into pieces, a persistent grid of
     waves drawing (piece, tile) items from a device queue.  The launch shape changes, nothing else: finals, flags and
     both counters of every hillslope equal the one-wave-per-tile launch (rk45_kernel.cu:33) bit for bit -- cold cells
     flagged in different pieces, the benchmark workload (more tiles than resident waves), fewer hillslopes than a wave
-    (a wave waits for its own previous piece), the attempt cap hit in the first piece, fixed steps, the 3-state model,
-    STRICT math on a wet surface, an empty window; piece counts 2 ... 64, incl. more pieces than forcing samples."""
+    (a wave waits for its own previous piece), the attempt cap hit in the first piece, fixed steps (also a short window,
+    where a last-bit difference of one resumed attempt survives to tf: the copies of a model's RHS the compiler inlines
+    must round alike, csrc/hlm_models.h DummyDev::rhs), the 3-state model, STRICT math on a wet surface, an empty
+    window; piece counts 2 ... 64, incl. more pieces than forcing samples."""
     H = gpu
     from tiger_hlm_gpu_amd import synth
     kw, pieces = {}, (2, 5, 16)
@@ -981,6 +983,9 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
     elif case == "fixed-step":
         ns = 777
         model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 50.0, dict(fixed_step=0.05)
+    elif case == "fixed-step-short":
+        ns, pieces = 777, (2, 4, 7, 16)
+        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 8.0, dict(fixed_step=0.05)
     elif case == "toy":
         y0, sp, inflow, cells, tf = _toy_case(ns=1300)
         model, ns = H.ToyModel3, len(y0)

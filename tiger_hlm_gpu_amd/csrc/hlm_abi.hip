@@ -404,6 +404,13 @@ int launch_refill(const hlm_device_job* j, hipStream_t stream)
     return HLM_SUCCESS;
 }
 
+#ifdef HLM_QUEUE_DEBUG
+// experiment builds only (not in include/hlm_hip.h): where the last queue launch keeps its state, for a look at a
+// kernel that does not finish (tools/queue_hang_probe.py)
+char* g_debug_queue_pool = nullptr;
+size_t g_debug_queue_rbytes = 0, g_debug_queue_qbytes = 0;
+#endif
+
 // Persistent launch over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): as many one-wave workgroups as
 // the device holds at once; the lane states between the pieces live in a stream-ordered scratch allocation.
 int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
@@ -419,16 +426,32 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
     const long long tiles = ((long long)j->num_systems + hlm::WAVE - 1) / hlm::WAVE;
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
     const size_t rbytes = (hlm_resume_bytes_model(j->uid, j->num_systems) + 15u) & ~(size_t)15u;
-    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + 1);
+    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + 2);  // next item | finished pieces per tile | abort word
     char* pool = nullptr;
     HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + qbytes, stream));
     unsigned int* queue = reinterpret_cast<unsigned int*>(pool + rbytes);
+#ifdef HLM_QUEUE_MEMSET
     if (hipError_t e = hipMemsetAsync(queue, 0, qbytes, stream); e != hipSuccess) {
         (void)hipFreeAsync(pool, stream);
         return fail(HLM_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
     }
+#else
+    {
+        const unsigned int words = (unsigned int)(qbytes / sizeof(unsigned int));
+        hipLaunchKernelGGL(hlm::queue_init_kernel, dim3((words + 255u) / 256u), dim3(256), 0, stream, queue, words);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+            (void)hipFreeAsync(pool, stream);
+            return fail(HLM_ERR_HIP, "queue_init_kernel failed: %s", hipGetErrorString(e));
+        }
+    }
+#endif
     hlm::Rk45Args a = make_args(j);
     a.resume = reinterpret_cast<double*>(pool);
+#ifdef HLM_QUEUE_DEBUG
+    g_debug_queue_pool = pool;
+    g_debug_queue_rbytes = rbytes;
+    g_debug_queue_qbytes = qbytes;
+#endif
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, pieces);
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(pool, stream));  // stream-ordered: after the kernel
@@ -1299,6 +1322,30 @@ int hlm_kernel_info(int uid, int dense, int math_mode, int* vgprs, int* scratch_
     if (max_threads) *max_threads = at.maxThreadsPerBlock;
     return HLM_SUCCESS;
 }
+
+#ifdef HLM_QUEUE_MARKS
+// pinned host memory for the waves' progress marks (NULL: none); returns the host pointer
+int hlm_debug_queue_marks(unsigned int** host, size_t words)
+{
+    unsigned int* h = nullptr;
+    unsigned int* d = nullptr;
+    HLM_HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&h), words * sizeof(unsigned int), hipHostMallocMapped));
+    std::memset(h, 0, words * sizeof(unsigned int));
+    HLM_HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&d), h, 0));
+    HLM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hlm::g_queue_marks), &d, sizeof(d)));
+    *host = h;
+    return HLM_SUCCESS;
+}
+#endif
+#ifdef HLM_QUEUE_DEBUG
+int hlm_debug_queue_pool(void** pool, size_t* rbytes, size_t* qbytes)
+{
+    *pool = g_debug_queue_pool;
+    *rbytes = g_debug_queue_rbytes;
+    *qbytes = g_debug_queue_qbytes;
+    return 0;
+}
+#endif
 
 #ifdef HLM_PHASE_TIMING
 // experiment builds only (not in include/hlm_hip.h): read (and optionally clear) the phase-cycle sums

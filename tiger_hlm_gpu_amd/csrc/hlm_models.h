@@ -420,13 +420,19 @@ struct DummyDev {
     static __device__ __forceinline__ void rhs(const Local&, const Forc&, const double (&y)[N_EQ],
                                                double (&dydt)[N_EQ])
     {
+        // Every product-sum below is written as the ONE operation sequence it is to compile to (contraction off,
+        // explicit FMAs): the kernels inline this function several times (k0 / k1..k6, first attempt / loop body,
+        // resumed / fresh lane) and all copies must round alike, or a resumed run differs from the uninterrupted
+        // one in the last bit.  Left to -ffp-contract=fast, "I2 - I3" (two products, one sum) was fused as
+        // fma(-0.4, H3, I2) in one copy and as fma(0.6, H1, -I3) in another.  The forms are the ones the compiler
+        // had chosen for the majority of the copies.
+#pragma clang fp contract(off)
         const double H0 = y[0], H1 = y[1], H3 = y[3];
-        const double Y0 = 0.5 * H0, X2 = 0.3 * H1, I2 = 0.6 * H1, I3 = 0.4 * H3;
-        dydt[0] = 1.0 - Y0;
-        dydt[1] = 1.2 + Y0 - X2 - 0.4 - I2;
-        dydt[2] = X2 - 0.2;
-        dydt[3] = I2 - I3 - 0.3;
-        dydt[4] = I3 - 0.1;
+        dydt[0] = __builtin_fma(-0.5, H0, 1.0);                                                          // 1.0 - Y0
+        dydt[1] = __builtin_fma(-0.6, H1, __builtin_fma(-0.3, H1, __builtin_fma(0.5, H0, 1.2)) - 0.4);   // 1.2 + Y0 - X2 - 0.4 - I2
+        dydt[2] = __builtin_fma(0.3, H1, -0.2);                                                          // X2 - 0.2
+        dydt[3] = __builtin_fma(-0.4, H3, 0.6 * H1) - 0.3;                                               // I2 - I3 - 0.3
+        dydt[4] = __builtin_fma(0.4, H3, -0.1);                                                          // I3 - 0.1
     }
 };
 
@@ -478,10 +484,13 @@ struct ToyDev {
     template <int MATH>
     static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[N_EQ], double (&dydt)[N_EQ])
     {
-        const double out0 = P.k1 * y[0], up = 0.3 * y[0] * y[2], out1 = 0.02 * y[1] * y[1];
-        dydt[0] = F.inflow - out0 - up;
-        dydt[1] = out0 - out1;
-        dydt[2] = out1 - P.k3 * y[2] + up;
+        // (one operation sequence per statement, contraction off: see DummyDev::rhs.  "out0 - out1" and
+        // "out1 - k3 y2" are sums of two products.)
+#pragma clang fp contract(off)
+        const double u = 0.3 * y[0], out1 = (0.02 * y[1]) * y[1];
+        dydt[0] = __builtin_fma(-y[2], u, __builtin_fma(-P.k1, y[0], F.inflow));   // F0 - out0 - up
+        dydt[1] = __builtin_fma(P.k1, y[0], -out1);                                // out0 - out1
+        dydt[2] = __builtin_fma(y[2], u, __builtin_fma(-P.k3, y[2], out1));        // out1 - k3 y2 + up
     }
 };
 

@@ -17,14 +17,46 @@
 // written with an agent-scope release after the state record and awaited with an acquire by the wave that draws the
 // next piece.  The awaited piece was drawn earlier (the queue is chunk-major), so it is finished or running on a
 // resident wave: the wait cannot deadlock, and with more tiles than resident waves it never waits at all.
+//
+// Every wave reaches the end of the grid whatever happens: the wait is bounded by a wall-clock watchdog
+// (QUEUE_WAIT_LIMIT_TICKS of the 100 MHz real-time counter).  A wait that outlasts it -- a lost wave; never seen --
+// gives the tile up: its unfinished hillslopes come back flagged HLM_SYS_CAPPED with zero finals, the channel of
+// "stopped before tf by a resource limit", and an abort word makes every later wait give up at once.
 #pragma once
 
 #include "hlm_rk45_kernel.h"
 
 namespace hlm {
 
-// queue[0]: next item; queue[1 + tile]: pieces of `tile` finished so far.  The resume record (A.resume, SoA as in
+#ifndef HLM_QUEUE_WAIT_ACQUIRE
+#define HLM_QUEUE_WAIT_ACQUIRE 0  // 1: acquire load inside the wait loop (cache invalidate per poll) instead of one fence after it
+#endif
+#ifdef HLM_QUEUE_MARKS
+// experiment builds: progress marks of every wave in pinned HOST memory (tools/queue_hang_probe.py reads them while
+// the kernel is still there): [block * 8 + k], k = 0 items drawn, 1 last item, 2 stage, 3 last counter seen, 4 polls
+__device__ unsigned int* g_queue_marks = nullptr;
+#define HLM_QMARK(k, v)                                                                                            \
+    do {                                                                                                           \
+        if (g_queue_marks && lane == 0)                                                                            \
+            __hip_atomic_store(&g_queue_marks[blockIdx.x * 8 + (k)], (unsigned)(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); \
+    } while (0)
+#else
+#define HLM_QMARK(k, v) do { } while (0)
+#endif
+#ifndef HLM_QUEUE_WAIT_LIMIT_TICKS
+#define HLM_QUEUE_WAIT_LIMIT_TICKS 2000000000ull  // 20 s of wall_clock64() (100 MHz)
+#endif
+constexpr unsigned long long QUEUE_WAIT_LIMIT_TICKS = HLM_QUEUE_WAIT_LIMIT_TICKS;
+
+// queue[0]: next item; queue[1 + tile]: pieces of `tile` finished so far; queue[1 + ntiles]: abort word.  The resume record (A.resume, SoA as in
 // the RESUMABLE kernels: y[N_EQ], t, h | reject_count, n_attempt, n_accept, next_q, status) carries the lanes.
+// the queue of a launch, zeroed by a kernel of the same stream
+__global__ void queue_init_kernel(unsigned int* __restrict__ queue, unsigned int words)
+{
+    const unsigned int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words) queue[i] = 0u;
+}
+
 template <class Model, int MATH, bool FIXED>
 __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
     rk45_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nchunk)
@@ -38,23 +70,58 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
     const double tf = A.tf;
     const double piece = (tf - A.t0) / (double)nchunk;
 
-    while (true) {
-        unsigned item = 0;
-        if (lane == 0) item = atomicAdd(queue, 1u);
-        item = (unsigned)__builtin_amdgcn_readfirstlane((int)item);
+    // Every step of the queue protocol below is written WITHOUT a branch on the lane number: all 64 lanes issue the
+    // draw (lane 0 adds 1, the others 0: one atomic per wave after the compiler's wave-level combining), all poll the
+    // tile's counter and all store it.  With `if (lane == 0)` around them the compiler threaded the end of one
+    // iteration into the start of the next for the lanes != 0 (seen in the Dummy FAST instance: lane 0 left the
+    // loop alone, nobody drew any more and the other lanes repeated item 0 for ever).  And whatever a compiler does
+    // to this loop, a wave leaves it after nitems iterations at the latest.
+    for (unsigned drawn = 0; drawn <= nitems; ++drawn) {
+        const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_fetch_add(queue, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        HLM_QMARK(1, item);
+        HLM_QMARK(2, 1);
         if (item >= nitems) break;
         const unsigned c = item / ntiles, tile = item - c * ntiles;
         const int sys = (int)(tile * WAVE) + lane;
+        bool lost = false;  // the watchdog fired: this tile is given up
         if (c > 0) {
             // the previous piece of this tile: finished long ago when there are more tiles than resident waves
-            if (lane == 0)
-                while (__hip_atomic_load(&done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < c) __builtin_amdgcn_s_sleep(16);
+            constexpr int order = HLM_QUEUE_WAIT_ACQUIRE ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED;
+            auto finished = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&done[tile], order, __HIP_MEMORY_SCOPE_AGENT)); };
+            if (finished() < c) {
+                const unsigned long long since = wall_clock64();
+                HLM_QMARK(2, 2);
+                [[maybe_unused]] unsigned polls = 0;
+                while (finished() < c) {
+                    __builtin_amdgcn_s_sleep(16);
+                    HLM_QMARK(4, ++polls);
+                    const unsigned aborted = (unsigned)__builtin_amdgcn_readfirstlane(
+                        (int)__hip_atomic_load(&done[ntiles], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (aborted != 0u || wall_clock64() - since > QUEUE_WAIT_LIMIT_TICKS) {
+                        __hip_atomic_store(&done[ntiles], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lost = true;
+                        break;
+                    }
+                }
+            }
+            HLM_QMARK(2, 3);
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // its state record is visible to every lane from here
         }
         // lanes pause the first time t reaches the end of their piece (the last piece runs to tf)
         const double t_end = c + 1u < (unsigned)nchunk ? fmin(tf, A.t0 + (double)(c + 1u) * piece) : tf;
 
-        if (sys < A.ns) {
+        if (sys < A.ns && lost) {
+            // (watchdog) whatever this hillslope's record says, nobody continues it: flagged, zero finals
+            if (resume_i[(size_t)4 * A.ns + sys] == SYS_PAUSED || c == 0u) {
+                A.stiff[sys] = HLM_SYS_CAPPED;
+                if (A.n_attempt) A.n_attempt[sys] = 0u;
+                if (A.n_accept) A.n_accept[sys] = 0u;
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = 0.0;
+            }
+            resume_i[(size_t)4 * A.ns + sys] = HLM_SYS_CAPPED;
+        } else if (sys < A.ns) {
             int status = HLM_SYS_OK;
             bool runs = true;
             if (c > 0) {
@@ -124,6 +191,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                     else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
                 }
 
+                HLM_QMARK(2, 4);
                 if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
                 if (status == HLM_SYS_OK && t < tf) {
                     // paused at the end of its piece: the next piece continues exactly here
@@ -148,8 +216,14 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
             }
         }
         // publish the piece: state record first, then the tile's counter
+        HLM_QMARK(2, 5);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        if (lane == 0) __hip_atomic_store(&done[tile], c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // (the fence's L2 write-back and the wait for it, once more as one unit: in some instances the scheduler
+        // left the wait BEFORE the write-back and the counter's store right behind it)
+        asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        HLM_QMARK(2, 6);
+        __hip_atomic_store(&done[tile], c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
+        HLM_QMARK(2, 7);
     }
 }
 

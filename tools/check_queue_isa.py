@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""After `make -C tiger_hlm_gpu_amd/csrc asm`: every instance of rk45_queue_kernel must keep the loop over queue items
+wave-uniform.  A compiler that threads lanes != 0 past the draw (seen once, with `if (lane == 0)` around the atomics)
+shows up as a third loop level and as an exec-masked back-edge of the item loop; both are checked here from the
+assembler's own loop comments.  usage: tools/check_queue_isa.py [build/...gfx950.s]"""
+import glob
+import os
+import re
+import sys
+
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+path = sys.argv[1] if len(sys.argv) > 1 else glob.glob(os.path.join(root, "build", "*gfx950.s"))[0]
+text = open(path).read().splitlines()
+bad, seen = [], 0
+i = 0
+while i < len(text):
+    m = re.match(r"^(_ZN3hlm17rk45_queue_kernel\w+):", text[i])
+    if not m:
+        i += 1
+        continue
+    name, j = m.group(1), i
+    while "s_endpgm" not in text[j]:
+        j += 1
+    body = text[i:j]
+    seen += 1
+    depth3 = [k for k, ln in enumerate(body) if re.search(r"Depth[= ]3", ln)]
+    atom = [k for k, ln in enumerate(body) if "global_atomic_add" in ln]
+    # the item loop: the Depth=1 header; its latch must be a scalar or unconditional branch back to the header
+    hdr = None
+    for k, ln in enumerate(body):
+        if "=>This Loop Header: Depth=1" in ln:
+            hdr = re.match(r"^(\.LBB\d+_\d+):", ln).group(1)
+            break
+    back = [ln.strip() for ln in body if hdr and re.search(r"s_c?branch\w*\s+%s$" % re.escape(hdr), ln.strip())]
+    masked = [b for b in back if "execz" in b or "execnz" in b or "vcc" in b]
+    ok = not depth3 and len(atom) == 1 and hdr is not None and back and not masked
+    print(("ok  " if ok else "BAD ") + name, "loops<=2" if not depth3 else "DEPTH 3", f"draws={len(atom)}", "item-loop latch:", back)
+    if not ok:
+        bad.append(name)
+    i = j
+print(f"{seen} instances, {len(bad)} bad")
+sys.exit(1 if bad or seen == 0 else 0)
