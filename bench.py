@@ -765,7 +765,10 @@ def main():
                                 "hlm::rk45_queue_kernel<Model204Dev>" if pieces else "hlm::rk45_multi_kernel<Model204Dev>"),
                      "time_pieces": pieces,
                      "note": "0.19 algorithmic bytes per RK45 step: this kernel cannot be HBM-bound; its binding "
-                             "roofline is roofline_valu_fp64 (FP64 vector ALU, no MFMA in a per-lane ODE)"},
+                             "roofline is roofline_valu_fp64 (FP64 vector ALU, no MFMA in a per-lane ODE)"
+                             + ("; traffic above the algorithmic bytes is the queue kernel's own: every time piece re-reads the "
+                                "parameter record and hands the lane state over through HBM (device-coherent loads / stores)"
+                                if pieces else "")},
         "roofline_valu_fp64": {"bound": "valu_fp64", "achieved": valu_tf, "peak": PEAK_FP64_VALU_TFLOPS,
                                "unit": "TFLOP/s", "frac": valu_tf / PEAK_FP64_VALU_TFLOPS,
                                "algorithmic_flops_per_step": F_STEP_204},

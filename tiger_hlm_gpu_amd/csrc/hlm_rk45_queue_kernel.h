@@ -14,8 +14,12 @@
 //
 // Restates reference src/solver/rk45_kernel.cu:17-176 like rk45_multi_kernel (no dense output here: the dense
 // kernels keep the fixed map).  Ordering between the pieces of one tile: a per-tile counter of finished pieces,
-// written with an agent-scope release after the state record and awaited with an acquire by the wave that draws the
-// next piece.  The awaited piece was drawn earlier (the queue is chunk-major), so it is finished or running on a
+// stored after the state record and awaited by the wave that draws the next piece.  The record and the counter are
+// read and written with agent-scope (device-coherent, sc1) loads and stores, the writer waits for its record stores
+// (s_waitcnt) before it stores the counter, the reader loads the record after it has seen the counter: no cache
+// write-back or invalidate anywhere.  (An agent-scope release / acquire FENCE pair does the same with two
+// buffer_wbl2 + buffer_inv per item -- and the write-back flushes every dirty line of the XCD's L2, the scratch of
+// all its waves included: 22.8 GB of HBM writes per headline launch, measured, and 3 % of its time.)  The awaited piece was drawn earlier (the queue is chunk-major), so it is finished or running on a
 // resident wave: the wait cannot deadlock, and with more tiles than resident waves it never waits at all.
 //
 // Every wave reaches the end of the grid whatever happens: the wait is bounded by a wall-clock watchdog
@@ -28,9 +32,6 @@
 
 namespace hlm {
 
-#ifndef HLM_QUEUE_WAIT_ACQUIRE
-#define HLM_QUEUE_WAIT_ACQUIRE 0  // 1: acquire load inside the wait loop (cache invalidate per poll) instead of one fence after it
-#endif
 #ifdef HLM_QUEUE_MARKS
 // experiment builds: progress marks of every wave in pinned HOST memory (tools/queue_hang_probe.py reads them while
 // the kernel is still there): [block * 8 + k], k = 0 items drawn, 1 last item, 2 stage, 3 last counter seen, 4 polls
@@ -50,6 +51,12 @@ constexpr unsigned long long QUEUE_WAIT_LIMIT_TICKS = HLM_QUEUE_WAIT_LIMIT_TICKS
 
 // queue[0]: next item; queue[1 + tile]: pieces of `tile` finished so far; queue[1 + ntiles]: abort word.  The resume record (A.resume, SoA as in
 // the RESUMABLE kernels: y[N_EQ], t, h | reject_count, n_attempt, n_accept, next_q, status) carries the lanes.
+// device-coherent accesses to the lane states between the pieces (any wave of any XCD may continue a tile)
+__device__ __forceinline__ double coherent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int coherent_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // the queue of a launch, zeroed by a kernel of the same stream
 __global__ void queue_init_kernel(unsigned int* __restrict__ queue, unsigned int words)
 {
@@ -87,8 +94,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         bool lost = false;  // the watchdog fired: this tile is given up
         if (c > 0) {
             // the previous piece of this tile: finished long ago when there are more tiles than resident waves
-            constexpr int order = HLM_QUEUE_WAIT_ACQUIRE ? __ATOMIC_ACQUIRE : __ATOMIC_RELAXED;
-            auto finished = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&done[tile], order, __HIP_MEMORY_SCOPE_AGENT)); };
+            auto finished = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
             if (finished() < c) {
                 const unsigned long long since = wall_clock64();
                 HLM_QMARK(2, 2);
@@ -106,26 +112,26 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 }
             }
             HLM_QMARK(2, 3);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // its state record is visible to every lane from here
+            asm volatile("" ::: "memory");  // (the record is loaded after the counter, also as the compiler sees it)
         }
         // lanes pause the first time t reaches the end of their piece (the last piece runs to tf)
         const double t_end = c + 1u < (unsigned)nchunk ? fmin(tf, A.t0 + (double)(c + 1u) * piece) : tf;
 
         if (sys < A.ns && lost) {
             // (watchdog) whatever this hillslope's record says, nobody continues it: flagged, zero finals
-            if (resume_i[(size_t)4 * A.ns + sys] == SYS_PAUSED || c == 0u) {
+            if (coherent_load(&resume_i[(size_t)4 * A.ns + sys]) == SYS_PAUSED) {
                 A.stiff[sys] = HLM_SYS_CAPPED;
                 if (A.n_attempt) A.n_attempt[sys] = 0u;
                 if (A.n_accept) A.n_accept[sys] = 0u;
 #pragma unroll
                 for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = 0.0;
             }
-            resume_i[(size_t)4 * A.ns + sys] = HLM_SYS_CAPPED;
+            coherent_store(&resume_i[(size_t)4 * A.ns + sys], HLM_SYS_CAPPED);
         } else if (sys < A.ns) {
             int status = HLM_SYS_OK;
             bool runs = true;
             if (c > 0) {
-                status = resume_i[(size_t)4 * A.ns + sys];
+                status = coherent_load(&resume_i[(size_t)4 * A.ns + sys]);
                 runs = status == SYS_PAUSED;  // else: finished or flagged in an earlier piece, its outputs were written then
                 if (runs) status = HLM_SYS_OK;
             }
@@ -141,12 +147,12 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                     for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
                 } else {
 #pragma unroll
-                    for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
-                    t = A.resume[(size_t)NEQ * A.ns + sys];
-                    h = A.resume[(size_t)(NEQ + 1) * A.ns + sys];
-                    reject_count = resume_i[(size_t)0 * A.ns + sys];
-                    n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
-                    n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
+                    for (int i = 0; i < NEQ; ++i) y[i] = coherent_load(&A.resume[(size_t)i * A.ns + sys]);
+                    t = coherent_load(&A.resume[(size_t)NEQ * A.ns + sys]);
+                    h = coherent_load(&A.resume[(size_t)(NEQ + 1) * A.ns + sys]);
+                    reject_count = coherent_load(&resume_i[(size_t)0 * A.ns + sys]);
+                    n_attempt = (uint32_t)coherent_load(&resume_i[(size_t)1 * A.ns + sys]);
+                    n_accept = (uint32_t)coherent_load(&resume_i[(size_t)2 * A.ns + sys]);
                 }
                 HeldForcing<Model, false> held;  // the samples of the first attempt are fetched at its t (as a resumed lane does)
                 held.init(A, sys);
@@ -195,16 +201,16 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
                 if (status == HLM_SYS_OK && t < tf) {
                     // paused at the end of its piece: the next piece continues exactly here
-                    resume_i[(size_t)4 * A.ns + sys] = SYS_PAUSED;
+                    coherent_store(&resume_i[(size_t)4 * A.ns + sys], SYS_PAUSED);
 #pragma unroll
-                    for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
-                    A.resume[(size_t)NEQ * A.ns + sys] = t;
-                    A.resume[(size_t)(NEQ + 1) * A.ns + sys] = h;
-                    resume_i[(size_t)0 * A.ns + sys] = reject_count;
-                    resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
-                    resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
+                    for (int i = 0; i < NEQ; ++i) coherent_store(&A.resume[(size_t)i * A.ns + sys], y[i]);
+                    coherent_store(&A.resume[(size_t)NEQ * A.ns + sys], t);
+                    coherent_store(&A.resume[(size_t)(NEQ + 1) * A.ns + sys], h);
+                    coherent_store(&resume_i[(size_t)0 * A.ns + sys], reject_count);
+                    coherent_store(&resume_i[(size_t)1 * A.ns + sys], (int)n_attempt);
+                    coherent_store(&resume_i[(size_t)2 * A.ns + sys], (int)n_accept);
                 } else {
-                    resume_i[(size_t)4 * A.ns + sys] = status;
+                    coherent_store(&resume_i[(size_t)4 * A.ns + sys], status);
                     if (A.n_attempt) A.n_attempt[sys] = n_attempt;
                     if (A.n_accept) A.n_accept[sys] = n_accept;
                     const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170
@@ -215,12 +221,9 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 }
             }
         }
-        // publish the piece: state record first, then the tile's counter
+        // publish the piece: the state record's stores complete (acknowledged at device scope), then the tile's counter
         HLM_QMARK(2, 5);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        // (the fence's L2 write-back and the wait for it, once more as one unit: in some instances the scheduler
-        // left the wait BEFORE the write-back and the counter's store right behind it)
-        asm volatile("buffer_wbl2 sc1\n\ts_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         HLM_QMARK(2, 6);
         __hip_atomic_store(&done[tile], c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
         HLM_QMARK(2, 7);
