@@ -59,11 +59,12 @@ def make_case(seed, ns, days, radau=False):
                 block=block, tf=days * 1440.0)
 
 
-def gpu_run(case, math_mode, params=DEFAULT_PARAMS, radau=False, query=None):
-    """One GPU integration of a fuzz case through the engine (the C ABI underneath)."""
-    q = case["q"] if query is None else query
+def gpu_run(case, math_mode, params=DEFAULT_PARAMS, radau=False, query=None, time_pieces=None):
+    """One GPU integration of a fuzz case through the engine (the C ABI underneath).  ``time_pieces`` given: without
+    dense output, in that launch shape (hlm_device_job.time_pieces)."""
+    q = None if time_pieces is not None else (case["q"] if query is None else query)
     eng = ShardEngine(H.Model204, case["y0"], 0.0, case["tf"], sp=case["sp"], query=q, math_mode=math_mode,
-                      attempt_cap=2_000_000, params=H.Parameters(*params))
+                      attempt_cap=2_000_000, params=H.Parameters(*params), time_pieces=time_pieces)
     if case["per_cell"]:
         eng.set_forcings_per_cell((case["pr"], case["t2m"]), case["cells"], case["dt"], case["nT"])
     else:

@@ -50,3 +50,21 @@ def test_fuzz_parity_gpu(oracle, seed, math_mode):
     same = got["stiff"] == ref["stiff"]
     dn = np.abs(got["n_attempt"][same].astype(np.int64) - ref["n_attempt"][same].astype(np.int64))
     print(f"fuzz seed {seed} math {math_mode}: exempt {n} (cap {cap1}), worst within {worst:.4f}, max |d attempts| {int(dn.max())}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("seed", sorted(COMMITTED))
+def test_fuzz_launch_shapes_agree_bit_for_bit(seed, math_mode):
+    """The same fuzz cases without dense output, one wave per tile (rk45_kernel.cu:33) against the queue kernel
+    (hlm_device_job.time_pieces, csrc/hlm_rk45_queue_kernel.h) with a piece count drawn from the seed (2 ... 14, so
+    that pieces end inside forcing hours as well as on them) and with 72 pieces (one per forcing hour): finals, flags
+    and both step counters of every hillslope identical -- 16 tiles on 3 072 resident waves, so every piece but the
+    first waits for another wave's."""
+    import fuzz_parity as F
+    c = F.make_case(seed, NS, DAYS)
+    a = F.gpu_run(c, math_mode, time_pieces=0)
+    for pieces in (2 + seed % 13, 72):
+        b = F.gpu_run(c, math_mode, time_pieces=pieces)
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(a[k], b[k]), (seed, math_mode, pieces, k)
