@@ -1347,6 +1347,18 @@ int hlm_debug_queue_pool(void** pool, size_t* rbytes, size_t* qbytes)
 }
 #endif
 
+#ifdef HLM_RADAU_COUNTERS
+// experiment builds only (not in include/hlm_hip.h): read and clear the Radau pass's divergence counters
+int hlm_debug_radau_counters(unsigned long long out[8])
+{
+    HLM_HIP_TRY(hipDeviceSynchronize());
+    HLM_HIP_TRY(hipMemcpyFromSymbol(out, HIP_SYMBOL(hlm::g_radau_ctr), 8 * sizeof(unsigned long long)));
+    const unsigned long long zero[8] = {};
+    HLM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hlm::g_radau_ctr), zero, sizeof(zero)));
+    return HLM_SUCCESS;
+}
+#endif
+
 #ifdef HLM_PHASE_TIMING
 // experiment builds only (not in include/hlm_hip.h): read (and optionally clear) the phase-cycle sums
 int hlm_debug_phase_cycles(unsigned long long out[8], int reset)

@@ -233,6 +233,21 @@ __device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], con
 // = ~14 times, and STRICT's OCML pow costs ~200 instructions each.
 // Occupancy: the general path keeps two 5x5 LU factorisations (75 doubles) in registers: one wave per
 // SIMD.  With a triangular Jacobian they are gone and two waves fit.
+#ifdef HLM_RADAU_COUNTERS
+// experiment builds: where the lanes of a wave wait for each other.  [2k] wave-level trips through section k,
+// [2k + 1] lane-level trips (sum of the active lanes): k = 0 step attempts, 1 Newton iterations, 2 accepted-step tails
+__device__ unsigned long long g_radau_ctr[8];
+#define HLM_RCOUNT(k)                                                                    \
+    do {                                                                                 \
+        const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true);                 \
+        if (lane == (int)__builtin_ctzll(m_)) {                                          \
+            atomicAdd(&g_radau_ctr[2 * (k)], 1ull);                                      \
+            atomicAdd(&g_radau_ctr[2 * (k) + 1], (unsigned long long)__builtin_popcountll(m_)); \
+        }                                                                                \
+    } while (0)
+#else
+#define HLM_RCOUNT(k) do { } while (0)
+#endif
 #ifndef HLM_RADAU_TRI_WAVES
 #define HLM_RADAU_TRI_WAVES 2
 #endif
@@ -308,6 +323,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll 1
     while (t < tf) {
         if (n_attempt >= A.cap) { capped = true; break; }
+        HLM_RCOUNT(0);
         double t_b = __builtin_inf();  // the next sample boundary of any stream
         if constexpr (Model::NF > 0) {
             bool moved = false;
@@ -398,6 +414,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         double prev = __builtin_inf();
 #pragma unroll 1
         for (int it = 0; ok && it < NEWTON_MAXITER; ++it) {
+            HLM_RCOUNT(1);
             double Fs[NS][NEQ], d0[NEQ], d1[NEQ], d2[NEQ];
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
@@ -433,6 +450,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         }
         if (!converged) { h *= 0.5; continue; }
 
+        HLM_RCOUNT(2);
         double y_new[NEQ], ev[NEQ];
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) {
