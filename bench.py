@@ -408,16 +408,21 @@ def driver_e2e_section(args):
                "--forcing-nc", os.path.join(tmp, "pr.nc") + ":pr:1", "--forcing-nc", os.path.join(tmp, "t2m.nc") + ":t2m:24",
                "--lookup", lcsv, "--math", args.math, "--out-format", "nc", "--out-final", os.path.join(tmp, "final.csv"),
                "--out-dense", os.path.join(tmp, "dense.csv"), "--device", str(torch.cuda.current_device())]
-        t0 = time.perf_counter()
-        p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
-        wall = time.perf_counter() - t0
-        if p.returncode != 0:
-            return {"error": "rk45_solver exit %d: %s" % (p.returncode, p.stderr[-400:])}
+        # twice: the first process of a fresh box also pages in the binary, the HDF5 and HIP libraries and the
+        # device code; both walls are reported, the phases are the second run's
+        walls = []
+        for _ in range(2):
+            t0 = time.perf_counter()
+            p = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+            walls.append(time.perf_counter() - t0)
+            if p.returncode != 0:
+                return {"error": "rk45_solver exit %d: %s" % (p.returncode, p.stderr[-400:])}
+        wall = walls[1]
         line = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
         ph = line["phases"]
         return {"workload": f"tools/rk45_solver: Model 204, {ns} hillslopes, {days} days, params CSV ({os.path.getsize(pcsv) / 1e6:.0f} MB) + lookup CSV "
                             f"+ NetCDF pr / t2m on a 32x32 grid (per-cell table), final.nc ({os.path.getsize(os.path.join(tmp, 'final.nc')) / 1e6:.0f} MB), math={args.math}",
-                "process_wall_s": wall, "phases_s": ph, "attempted_steps": line["attempted_steps"], "flagged": line["flagged"],
+                "process_wall_s": wall, "first_process_wall_s": walls[0], "phases_s": ph, "attempted_steps": line["attempted_steps"], "flagged": line["flagged"],
                 "steps_per_s_integrate_phase": line["attempted_steps"] / ph["integrate_s"],
                 "steps_per_s_whole_process": line["attempted_steps"] / wall,
                 "dominant_host_phase": max((k for k in ph if k != "integrate_s"), key=lambda k: ph[k])}

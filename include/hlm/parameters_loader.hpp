@@ -4,6 +4,10 @@
 // conversions and std::runtime_error conditions.  Header-only.
 #pragma once
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
 #include <cerrno>
 #include <cstdlib>
 #include <cstring>
@@ -65,6 +69,29 @@ inline long field_to_long(const char* b, const char* e)
     }
     return std::stol(std::string(b, e));
 }
+// read-only mapping of a whole file whose last page has room for a terminating NUL
+struct FileMapping {
+    const char* data = nullptr;
+    size_t length = 0;
+    bool map(const std::string& path, size_t file_size)
+    {
+        const long page = sysconf(_SC_PAGESIZE);
+        if (page <= 0 || file_size == 0 || file_size % (size_t)page == 0) return false;
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        void* p = ::mmap(nullptr, file_size, PROT_READ, MAP_PRIVATE, fd, 0);
+        ::close(fd);
+        if (p == MAP_FAILED) return false;
+        (void)::madvise(p, file_size, MADV_WILLNEED);
+        data = static_cast<const char*>(p);
+        length = file_size;
+        return true;
+    }
+    ~FileMapping() { if (data) ::munmap(const_cast<char*>(data), length); }
+    FileMapping() = default;
+    FileMapping(const FileMapping&) = delete;
+    FileMapping& operator=(const FileMapping&) = delete;
+};
 }  // namespace hlm_detail
 
 // The reader.  The file is read whole and its rows are parsed by several threads, each on a run of whole lines
@@ -93,18 +120,28 @@ inline std::vector<SpatialParams> loadSpatialParams(const std::string& csv_path)
     }
     const size_t ncol = headers.size();
 
-    // the rest of the file, NUL-terminated (no zero-fill of a quarter of a gigabyte first)
+    // The rest of the file, NUL-terminated.  Mapped where possible (no copy of a quarter of a gigabyte out of the
+    // page cache; the parsing threads fault their own parts in): the bytes after the end of a mapped file up to
+    // the end of its last page read as zero, which is the terminator -- unless the file ends exactly on a page
+    // boundary, then (or when mapping fails) it is read into a buffer.
     size_t body_size = 0;
+    const char* body_ptr = nullptr;
     std::unique_ptr<char[]> body;
+    hlm_detail::FileMapping mapping;
     {
         const std::streampos here = in.tellg();
         in.seekg(0, std::ios::end);
         const std::streampos end = in.tellg();
         in.seekg(here);
         body_size = (size_t)(end - here);
-        body.reset(new char[body_size + 1]);
-        in.read(body.get(), (std::streamsize)body_size);
-        body[body_size] = '\0';
+        if (mapping.map(csv_path, (size_t)end)) {
+            body_ptr = mapping.data + (size_t)here;
+        } else {
+            body.reset(new char[body_size + 1]);
+            in.read(body.get(), (std::streamsize)body_size);
+            body[body_size] = '\0';
+            body_ptr = body.get();
+        }
     }
 
     constexpr double c_1 = 0.001 / 60.0;  // mm/hr -> m/min
@@ -151,7 +188,7 @@ inline std::vector<SpatialParams> loadSpatialParams(const std::string& csv_path)
         }
     };
 
-    const char* const b0 = body.get();
+    const char* const b0 = body_ptr;
     const char* const b1 = b0 + body_size;
     unsigned nthreads = std::thread::hardware_concurrency();
     if (nthreads > 16) nthreads = 16;

@@ -423,6 +423,20 @@ def test_cpp_params_loader_values_and_errors(hlm, golden, tmp_path):
     rc, lines = run(big)
     assert rc == 0 and lines[0] == "ROWS 60000"
     assert rows_of(lines) == expect(params.load_spatial_params(big))
+    # the loader maps the file and takes the zero bytes after its end in the last page as the terminator; a file
+    # that ends exactly on a page boundary has none and goes through the buffered read: same rows, also when the last
+    # field of the file is the one that touches the boundary
+    for pad in ("\r\n", ""):
+        want = -(-(len(body) + 64) // 4096) * 4096
+        if pad:
+            padded = body + pad * ((want - len(body)) // 2) + "\n" * ((want - len(body)) % 2)
+        else:
+            padded = body + "0" * (want - len(body))                # ...,0 -> ...,000000: the same number
+        aligned = tmp_path / ("aligned%d.csv" % len(pad))
+        open(aligned, "w", newline="").write(padded)
+        assert os.path.getsize(aligned) % 4096 == 0
+        rc, lines = run(aligned)
+        assert rc == 0 and lines[0] == "ROWS 60000" and rows_of(lines) == expect(params.load_spatial_params(big)), pad
     hdr = text[0]
     for name, content, kind in (("missing_col.csv", hdr.replace(",hu,", ",HU,") + "\n" + text[1] + "\n", "runtime_error: Missing column 'hu'"),
                                 ("short_row.csv", hdr + "\n" + ",".join(text[1].split(",")[:10]) + "\n", "runtime_error: Bad row with too few fields"),

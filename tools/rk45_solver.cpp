@@ -21,6 +21,8 @@
 #include <algorithm>
 #include <mutex>
 #include <string>
+#include <future>
+#include <memory>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -217,6 +219,25 @@ int run(const Options& o, hlm_io::CsvStyle style)
     auto since = [](clk::time_point a) { return std::chrono::duration<double>(clk::now() - a).count(); };
     double t_params = 0, t_forcing_read = 0, t_write = 0;
     clk::time_point tp = clk::now();
+    // The HIP runtime and the device context take 0.1-0.2 s to come up: let them do so while this thread parses the
+    // parameter file (first device of the run; any error is reported by the shard that uses the device)
+    std::thread device_warmup([&o] {
+        if (hlm_set_device(o.device) == HLM_SUCCESS) {
+            void* p = nullptr;
+            if (hlm_device_malloc(&p, 256) == HLM_SUCCESS) (void)hlm_device_free(p);
+        }
+    });
+    struct JoinOnExit {
+        std::thread& t;
+        ~JoinOnExit() { if (t.joinable()) t.join(); }
+    } join_warmup{device_warmup};
+    // ... and the lookup table (one row per stream, main.cpp:495-507) parses beside the parameter file
+    std::unique_ptr<LookupMapper> lookup;
+    std::future<bool> lookup_loaded;
+    if (is204 && !o.forcing_nc.empty() && !o.lookup.empty()) {
+        lookup.reset(new LookupMapper(o.lookup));
+        lookup_loaded = std::async(std::launch::async, [&lookup] { return lookup->load(); });
+    }
 
     // ---- streams ---------------------------------------------------------------------------
     std::vector<SpatialParams> spatial;
@@ -248,8 +269,8 @@ int run(const Options& o, hlm_io::CsvStyle style)
     if (is204 && !o.forcing_nc.empty()) {
 #ifdef HLM_WITH_HDF5
         if (o.lookup.empty()) usage("--forcing-nc needs --lookup <csv>");
-        LookupMapper lm(o.lookup);
-        if (!lm.load()) throw std::runtime_error("Lookup load failed: " + o.lookup);
+        if (!lookup_loaded.get()) throw std::runtime_error("Lookup load failed: " + o.lookup);
+        LookupMapper& lm = *lookup;
         std::vector<size_t> cell_of_col;
         size_t lon_size = 0;
         const double days = std::ceil((tf - t0) / 1440.0);
@@ -370,6 +391,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
     // remainder), one per worker rank / GPU (main.cpp:275-307).  Same rule here, one host thread per
     // GPU instead of one MPI rank; hillslopes are independent, so the shards never talk, and
     // the "gather" is each thread writing its rows of the host result arrays.
+    if (device_warmup.joinable()) device_warmup.join();
     int ndev = 0;
     rk45_api::detail::check(hlm_device_count(&ndev), "hlm_device_count");
     const int G = std::max(1, o.gpus);
