@@ -952,7 +952,7 @@ def test_lane_refill_is_bit_identical_to_the_fixed_map(gpu, case):
         assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()
 
 
-@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step", "fixed-step-short", "toy", "strict-wet", "empty-window"])
+@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step", "fixed-step-short", "toy", "strict-wet", "empty-window", "late-start"])
 def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
     """hlm_device_job.time_pieces (csrc/hlm_rk45_queue_kernel.h): the window cut into pieces, a persistent grid of
     waves drawing (piece, tile) items from a device queue.  The launch shape changes, nothing else: finals, flags and
@@ -964,7 +964,7 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
     window; piece counts 2 ... 64, incl. more pieces than forcing samples."""
     H = gpu
     from tiger_hlm_gpu_amd import synth
-    kw, pieces = {}, (2, 5, 16)
+    kw, pieces, t0 = {}, (2, 5, 16), 0.0
     if case == "cold-cells":
         ns, days = 250_037, 6
         pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
@@ -993,6 +993,11 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
         ns, days, kw = 5000, 2, dict(math_mode=H.MATH_STRICT)
         pr, t2m, dt, nT = synth.forcing_tables(days=days)
         model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=True), synth.model204_params(0, ns), days * 1440.0
+    elif case == "late-start":
+        # a window that starts and ends inside forcing hours (t0 = 1 d 7 h 20 min): the pieces are cut from t0
+        ns, days, pieces, t0 = 3000, 4, (2, 3, 11), 1880.0
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=True), synth.model204_params(0, ns), days * 1440.0 - 333.0
     else:
         ns, days, pieces = 200, 1, (4,)
         pr, t2m, dt, nT = synth.forcing_tables(days=days)
@@ -1000,7 +1005,7 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
 
     def run(p):
         from tiger_hlm_gpu_amd.engine import ShardEngine
-        eng = ShardEngine(model, y0, 0.0, tf, sp=sp, time_pieces=p, **kw)
+        eng = ShardEngine(model, y0, t0, tf, sp=sp, time_pieces=p, **kw)
         if case == "toy":
             eng.set_forcings_per_cell((inflow,), cells, (1.0,), (inflow.shape[0],))
         elif sp is not None:
@@ -1018,6 +1023,8 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
         assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()
     if case == "empty-window":
         assert np.array_equal(a["y_final"], y0) and (a["n_attempt"] == 0).all()
+    if case == "late-start":
+        assert (a["n_attempt"] > 100).mean() > 0.5 and (a["stiff"] == 0).any()
 
 
 def test_time_pieces_default_rule_and_the_radau_hand_over(gpu):
