@@ -1414,6 +1414,38 @@ def test_streamed_forcings_keep_the_rows_of_lanes_that_finished_early(gpu, case,
     assert np.array_equal(eng.results()["dense"], ref["dense"])
 
 
+@pytest.mark.parametrize("layout", ["per-cell", "per-stream"])
+@pytest.mark.parametrize("case", ["hourly-chunks", "odd-chunks", "daily-chunks-cold", "two-chunks", "sub-wave"])
+def test_streamed_forcings_without_dense_output(gpu, layout, case):
+    """hlm_rk45_integrate_forcing_streamed without dense output (BASELINE config 3 as worded; what bench.py's
+    variant_forcings_streamed times): finals, flags and counters equal the run with all forcings resident bit for
+    bit -- 120 hourly chunks, chunk edges inside forcing hours on 70 001 hillslopes, cold cells (hillslopes flagged
+    in different chunks), two chunks, fewer hillslopes than a wave; whatever launch shape the job asks for (the
+    chunk launches are RESUMABLE ones: time_pieces does not apply to them)."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days, chunk, tmin = {"hourly-chunks": (5000, 5, 60.0, 0.5), "odd-chunks": (70_001, 3, 433.0, 0.5),
+                             "daily-chunks-cold": (20_000, 8, 1440.0, -5.0), "two-chunks": (3000, 2, 1500.0, 0.5),
+                             "sub-wave": (40, 3, 777.0, -5.0)}[case]
+    tf = days * 1440.0
+    sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns, wet_surface=(case == "odd-chunks"))
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=tmin)
+    ref = _run_engine(H, H.Model204, y0, 0.0, tf, sp=sp, forcing=(pr, t2m, cells, dt, nT), per_cell=(layout == "per-cell"), time_pieces=0)
+    if case == "daily-chunks-cold":
+        assert 0.05 < (ref["stiff"] == 1).mean() < 0.95
+    tables = (pr, t2m) if layout == "per-cell" else (pr[:, cells], t2m[:, cells])
+    for pieces in (None, 0):
+        eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, time_pieces=pieces)
+        eng.y_final.fill_(-3.0)
+        n = eng.integrate_forcing_streamed_abi(tables, dt, chunk, cells=cells if layout == "per-cell" else None)
+        assert n == int(np.ceil(tf / chunk))
+        got = eng.results()
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(got[k], ref[k]), (case, layout, pieces, k)
+
+
 def test_host_api_streamed_forcings_equal_resident_bitwise(gpu):
     """hlm_set_forcings_host: run_rk45 with the series left in host memory (time chunks through
     HBM) returns the bits of the run with the block resident (hlm_set_forcings)."""
