@@ -1420,13 +1420,13 @@ def test_streamed_forcings_without_dense_output(gpu, layout, case):
     """hlm_rk45_integrate_forcing_streamed without dense output (BASELINE config 3 as worded; what bench.py's
     variant_forcings_streamed times): finals, flags and counters equal the run with all forcings resident bit for
     bit -- 120 hourly chunks, chunk edges inside forcing hours on 70 001 hillslopes, cold cells (hillslopes flagged
-    in different chunks), two chunks, fewer hillslopes than a wave; whatever launch shape the job asks for (the
-    chunk launches are RESUMABLE ones: time_pieces does not apply to them)."""
+    in different chunks, 66 000 of them), two chunks, fewer hillslopes than a wave; whatever launch shape the job
+    asks for (the chunk launches are RESUMABLE ones, one wave per tile: time_pieces does not apply to them)."""
     H = gpu
     from tiger_hlm_gpu_amd import synth
     from tiger_hlm_gpu_amd.engine import ShardEngine
     ns, days, chunk, tmin = {"hourly-chunks": (5000, 5, 60.0, 0.5), "odd-chunks": (70_001, 3, 433.0, 0.5),
-                             "daily-chunks-cold": (20_000, 8, 1440.0, -5.0), "two-chunks": (3000, 2, 1500.0, 0.5),
+                             "daily-chunks-cold": (66_000, 6, 1440.0, -5.0), "two-chunks": (3000, 2, 1500.0, 0.5),
                              "sub-wave": (40, 3, 777.0, -5.0)}[case]
     tf = days * 1440.0
     sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns, wet_surface=(case == "odd-chunks"))
@@ -1436,7 +1436,7 @@ def test_streamed_forcings_without_dense_output(gpu, layout, case):
     if case == "daily-chunks-cold":
         assert 0.05 < (ref["stiff"] == 1).mean() < 0.95
     tables = (pr, t2m) if layout == "per-cell" else (pr[:, cells], t2m[:, cells])
-    for pieces in (None, 0):
+    for pieces in (None, 0, 3):
         eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, time_pieces=pieces)
         eng.y_final.fill_(-3.0)
         n = eng.integrate_forcing_streamed_abi(tables, dt, chunk, cells=cells if layout == "per-cell" else None)
