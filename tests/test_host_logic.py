@@ -367,6 +367,8 @@ def test_time_pieces_argument_is_validated_without_a_device(hlm):
         j.params[k] = v
     j.time_pieces = 4097
     assert L.hlm_rk45_integrate_device(C.byref(j), None) == 1 and b"time_pieces" in L.hlm_last_error()
+    j.time_pieces, j.num_systems = 4096, 2_000_000_000   # 3.1e7 tiles x 4096 pieces: the 32-bit item number would wrap
+    assert L.hlm_rk45_integrate_device(C.byref(j), None) == 1 and b"items" in L.hlm_last_error()
 
 
 def test_queue_kernels_keep_the_item_loop_wave_uniform():

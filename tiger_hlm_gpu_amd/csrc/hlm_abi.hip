@@ -310,6 +310,9 @@ int validate_job(const hlm_device_job* j)
     if (const int rcs = validate_selection(j->uid, j->dense_ncomp, j->dense_comp); rcs != HLM_SUCCESS) return rcs;
     if (j->lane_refill != 0 && j->lane_refill != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane_refill must be 0 or 1");
     if (j->time_pieces > kMaxTimePieces) return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces must be at most %d (negative = automatic)", kMaxTimePieces);
+    // (the queue kernel numbers its (piece, tile) items with 32 bits)
+    if (j->time_pieces > 1 && ((long long)j->num_systems + 63) / 64 * (long long)j->time_pieces >= (1ll << 32) - 1)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces %d x %d hillslopes: more than 2^32 (piece, tile) items", j->time_pieces, j->num_systems);
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
