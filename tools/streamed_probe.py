@@ -30,7 +30,7 @@ print(f"resident: {e0.elapsed_time(e1):.1f} ms")
 want = ref.results()
 del ref
 torch.cuda.empty_cache()
-for pieces in (None,):
+for pieces in [int(x) if x != "auto" else None for x in os.environ.get("HLM_PROBE_PIECES", "auto").split(",")]:
     for chunk in (1440.0,) if os.environ.get("HLM_PROBE_SHORT") else (1440.0, 2880.0, 720.0):
         eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, time_pieces=pieces)
         for rep in range(3):
@@ -44,5 +44,5 @@ for pieces in (None,):
             wall = (time.perf_counter() - t0) * 1e3
         got = eng.results()
         same = all(np.array_equal(got[k], want[k]) for k in ("y_final", "stiff", "n_attempt", "n_accept"))
-        print(f"streamed, chunk {chunk:6.0f} min: wall {wall:7.1f} ms, events {e0.elapsed_time(e1):7.1f} ms, bit-identical to resident: {same}")
+        print(f"streamed, time_pieces {pieces}, chunk {chunk:6.0f} min: wall {wall:7.1f} ms, events {e0.elapsed_time(e1):7.1f} ms, bit-identical to resident: {same}")
         del eng
