@@ -1028,8 +1028,8 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
 
 
 def test_time_pieces_default_rule_and_the_radau_hand_over(gpu):
-    """The automatic launch shape (hlm_set_time_pieces(-1): from 65 536 hillslopes on, one piece per two simulated
-    days, at most 16) gives the host API's run_rk45 the same bits as the forced fixed map, and a flagged hillslope
+    """The automatic launch shape (hlm_set_time_pieces(-1): from 65 536 hillslopes on, one piece per twelve
+    simulated hours, at most 32, none below 8) gives the host API's run_rk45 the same bits as the forced fixed map, and a flagged hillslope
     leaves the same flag state for the Radau pass whichever kernel integrated it."""
     H = gpu
     import torch
@@ -1046,7 +1046,7 @@ def test_time_pieces_default_rule_and_the_radau_hand_over(gpu):
     try:
         api.set_time_pieces(0)
         fixed, _, info0 = api.run_rk45(H.Model204, y0, 0.0, tf, None, d_sp, with_info=True)
-        api.set_time_pieces(-1)     # automatic: 70 000 hillslopes x 5 days -> 2 pieces
+        api.set_time_pieces(-1)     # automatic: 70 000 hillslopes x 5 days -> 10 pieces
         auto, _, info1 = api.run_rk45(H.Model204, y0, 0.0, tf, None, d_sp, with_info=True)
         assert np.array_equal(fixed, auto) and all(np.array_equal(info0[k], info1[k]) for k in info0)
         with pytest.raises(H.HlmError):

@@ -83,14 +83,15 @@ int g_refill = 0;  // hlm_set_lane_refill(): host-API launches without dense out
 int g_time_pieces = -1;  // hlm_set_time_pieces(): < 0 = automatic (auto_time_pieces)
 constexpr int kMaxTimePieces = 4096;
 // The automatic launch shape of a run without dense output: from 65 536 hillslopes on (more tiles than a third of
-// the resident waves: below that the fixed map's one launch is as good, measured), one piece per two simulated days
-// (Model 204 with hourly forcings: >= ~1 000 attempts per piece, the per-piece state hand-over stays below 0.3 %),
-// at most 16 (measured on the 30-day headline: 8 pieces -5.1 %, 16 -6.4 %, 32 -6.6 %).
+// the resident waves: below that the fixed map's one launch is as good, measured), one piece per twelve simulated
+// hours, at most 32 -- and none at all when that makes fewer than 8: FEW pieces cost more than the drain they
+// remove (measured, 1 M / 100 000 hillslopes: 2 pieces +3 / +17 %, 4 pieces -1 / +5 %, 8 pieces -3 / -3 %,
+// 16 pieces -4 / -7 %, 32 pieces -5 / -10 % on 8- to 30-day windows; profiles/r03_launch_shape_probe.txt).
 int auto_time_pieces(int num_systems, double t0, double tf)
 {
     if (num_systems < 65536 || !(tf > t0)) return 0;
-    const double p = (tf - t0) / 2880.0;
-    return p >= 16.0 ? 16 : (p >= 2.0 ? (int)p : 0);
+    const double p = (tf - t0) / 720.0;
+    return p >= 32.0 ? 32 : (p >= 8.0 ? (int)p : 0);
 }
 int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
 // hlm_set_output_states(): the dense rows of the host API carry only these state components (0 = all)

@@ -27,7 +27,7 @@ class ShardEngine:
         self.lane_refill = int(bool(lane_refill))  # hlm_device_job.lane_refill (launches without dense output)
         # hlm_device_job.time_pieces (launches without dense output): a persistent grid over (time piece, tile) items
         # instead of one wave per tile; None = the host API's automatic rule (from 65 536 hillslopes on, one piece per
-        # two simulated days, at most 16)
+        # twelve simulated hours, at most 32, none below 8)
         self.time_pieces = time_pieces
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
         self.ns = y0.shape[0]
