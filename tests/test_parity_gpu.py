@@ -1069,6 +1069,34 @@ def test_time_pieces_default_rule_and_the_radau_hand_over(gpu):
         assert np.array_equal(res[0][0][k], res[1][0][k]), k
 
 
+def test_closed_form_linear_stores_agree_with_the_stage_arithmetic(gpu):
+    """Launches without dense output (FAST) take the gravitational and the aquifer store of a hillslope on the no-rain
+    path in closed form, y R(lambda h) with the Dormand-Prince stability polynomial (csrc/hlm_rk45_kernel.h: rk_stages
+    CLOSED, attempt_per_lane_path; hlm_tableau.h: LINEAR); launches with dense output keep the stage-by-stage
+    arithmetic (they read the slopes).  Same method, different rounding: the finals of the two agree to a small
+    fraction of the tolerance on (almost) every hillslope -- a marginal accept / reject decision may still separate a
+    few -- and STRICT, which has no closed form, agrees bit for bit."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 20_000, 6
+    sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days)
+    tf = days * 1440.0
+    q = np.array([tf])   # one query at the very end: the dense kernels, the same steps
+    for mode in (H.MATH_FAST, H.MATH_STRICT):
+        a = _run_engine(H, H.Model204, y0, 0.0, tf, sp=sp, forcing=(pr, t2m, cells, dt, nT), per_cell=True, math_mode=mode)
+        b = _run_engine(H, H.Model204, y0, 0.0, tf, sp=sp, query=q, forcing=(pr, t2m, cells, dt, nT), per_cell=True, math_mode=mode)
+        assert np.array_equal(a["stiff"], b["stiff"])
+        ok = a["stiff"] == 0
+        dev = _scaled_err(a["y_final"][ok], b["y_final"][ok]).max(axis=1)
+        if mode == H.MATH_STRICT:
+            assert np.array_equal(a["y_final"], b["y_final"]) and np.array_equal(a["n_attempt"], b["n_attempt"])
+        else:
+            print(f"closed form vs stage arithmetic: median {np.median(dev):.3g}, 99th percentile {np.quantile(dev, 0.99):.3g}, max {dev.max():.3g} of the bound; "
+                  f"step counts equal on {np.mean(a['n_attempt'] == b['n_attempt']):.4f}")
+            assert np.quantile(dev, 0.99) < 1e-3 and dev.max() < 1.0
+            assert np.mean(a["n_attempt"] == b["n_attempt"]) > 0.98
+
+
 # ---- the plug-in surface is generic: a model with N_EQ = 3 and one forcing -------------------------------
 def _toy_case(ns=300, days=3, seed=3):
     from tiger_hlm_gpu_amd import synth

@@ -223,6 +223,12 @@ struct Model204Dev {
     // expressions are the general ones with rain, x2, x3, x4, d2, d3 replaced by the literal 0.0
     // they evaluate to: same values.
     static constexpr bool HAS_NORAINPATH = true;
+    // On the no-rain path (x3 = x4 = 0) the gravitational and the aquifer store only drain: y' = -y / alpha, linear
+    // and homogeneous -- the kernels may take them in closed form (rk_stages, CLOSED).  FAST arithmetic: the rate is
+    // the reciprocal the RHS multiplies by (0 where the reference does not drain, alpha < 1).
+    static constexpr int NORAIN_LINEAR = 2;
+    static constexpr int NORAIN_LINEAR_COMP[2] = {3, 4};
+    static __device__ __forceinline__ double norain_rate(const Local& P, int k) { return k == 0 ? -P.inv_alpha3 : -P.inv_alpha4; }
     static __device__ __forceinline__ bool norainpath_ok(const Local& P, const Forc& F, const double (&y)[N_EQ])
     {
         return y[2] == 0.0 && F.rain == 0.0 && P.nonneg;
@@ -390,6 +396,9 @@ struct DummyDev {
     static constexpr bool HAS_FASTPATH = false;
     static constexpr bool HAS_NORAINPATH = false;
     static constexpr int FAST_ZERO_COMP = 0;
+    static constexpr int NORAIN_LINEAR = 0;
+    static constexpr int NORAIN_LINEAR_COMP[1] = {0};
+    static __device__ __forceinline__ double norain_rate(const Local&, int) { return 0.0; }
     static __device__ __forceinline__ bool norainpath_ok(const Local&, const Forc&, const double (&)[N_EQ]) { return false; }
     template <int MATH>
     static __device__ __forceinline__ bool rhs_norain(const Local&, const Forc&, const double (&)[N_EQ],
@@ -459,6 +468,9 @@ struct ToyDev {
     static constexpr bool HAS_JACOBIAN = false;
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = false;
     static constexpr int FAST_ZERO_COMP = 0;
+    static constexpr int NORAIN_LINEAR = 0;
+    static constexpr int NORAIN_LINEAR_COMP[1] = {0};
+    static __device__ __forceinline__ double norain_rate(const Local&, int) { return 0.0; }
     static __device__ __forceinline__ bool norainpath_ok(const Local&, const Forc&, const double (&)[N_EQ]) { return false; }
     template <int MATH>
     static __device__ __forceinline__ bool rhs_norain(const Local&, const Forc&, const double (&)[N_EQ], double (&)[N_EQ]) { return true; }

@@ -192,7 +192,21 @@ constexpr int PATH_GENERAL = 0, PATH_DRY = 1, PATH_NORAIN = 2;
 // index of the c-th moving component when component Z is pinned (identity for Z >= N)
 constexpr int moving_component(int c, int Z) { return c < Z ? c : c + 1; }
 
-template <class Model, int MATH, int PATH>
+// CLOSED (no-rain path, FAST, launches that need no stage slopes afterwards): the components the model declares
+// linear and homogeneous on that path (Model::NORAIN_LINEAR_COMP: pure decay y' = lambda y while nothing flows in)
+// are left out of the stage arithmetic as well -- the method applied to y' = lambda y has a closed form, y R(lambda h)
+// with R the stability polynomial, evaluated instead (hlm_tableau.h: LINEAR).
+template <class Model, int PATH, bool CLOSED>
+constexpr bool through_stages(int i)
+{
+    if (PATH != 0 /* PATH_GENERAL */ && i == Model::FAST_ZERO_COMP) return false;
+    if (CLOSED)
+        for (int k = 0; k < Model::NORAIN_LINEAR; ++k)
+            if (i == Model::NORAIN_LINEAR_COMP[k]) return false;
+    return true;
+}
+
+template <class Model, int MATH, int PATH, bool CLOSED = false>
 __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const typename Model::Forc& FV,
                                           const double (&y)[Model::N_EQ], double h, bool have_k0, double (&k0)[Model::N_EQ],
                                           double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ], double (&k3)[Model::N_EQ],
@@ -203,14 +217,17 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     constexpr int NEQ = Model::N_EQ;
     // components that move: all of them, or all but the one the fast path pins
     constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : NEQ;
-    constexpr int NC = PATH != PATH_GENERAL ? NEQ - 1 : NEQ;
     bool broke = false;
     auto f = [&](const double (&state)[NEQ], double (&slope)[NEQ]) {
         if constexpr (PATH == PATH_NORAIN) broke |= Model::template rhs_norain<MATH>(P, FV, state, slope);
         else if constexpr (PATH == PATH_DRY) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
         else Model::template rhs<MATH>(P, FV, state, slope);
     };
-    if constexpr (PATH != PATH_GENERAL) yt[Z] = y[Z];
+    // components that stand still in the stage states: the pinned one, and (CLOSED) the linear ones, whose slopes the
+    // RHS calls below then compute from an unchanged state and nobody reads
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i)
+        if (!through_stages<Model, PATH, CLOSED>(i)) yt[i] = y[i];
     if (!have_k0) f(y, k0);  // no FSAL in the reference: see the have_k0 comment in the kernel
     // a pinned component must really stand still: a carried-over k0 (k6 of a step the general path
     // took) can hold the first inflow into a still-dry store, which the stage states below would ignore
@@ -218,43 +235,55 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     {
         const double a10 = h * A10;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a10, k0[i]); }
+        for (int i = 0; i < NEQ; ++i) if (through_stages<Model, PATH, CLOSED>(i)) yt[i] = lc(y[i], a10, k0[i]);
         f(yt, k1);
     }
     {
         const double a20 = h * A20, a21 = h * A21;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a20, k0[i], a21, k1[i]); }
+        for (int i = 0; i < NEQ; ++i) if (through_stages<Model, PATH, CLOSED>(i)) yt[i] = lc(y[i], a20, k0[i], a21, k1[i]);
         f(yt, k2);
     }
     {
         const double a30 = h * A30, a31 = h * A31, a32 = h * A32;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]); }
+        for (int i = 0; i < NEQ; ++i) if (through_stages<Model, PATH, CLOSED>(i)) yt[i] = lc(y[i], a30, k0[i], a31, k1[i], a32, k2[i]);
         f(yt, k3);
     }
     {
         const double a40 = h * A40, a41 = h * A41, a42 = h * A42, a43 = h * A43;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) { const int i = moving_component(c, Z); yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]); }
+        for (int i = 0; i < NEQ; ++i) if (through_stages<Model, PATH, CLOSED>(i)) yt[i] = lc(y[i], a40, k0[i], a41, k1[i], a42, k2[i], a43, k3[i]);
         f(yt, k4);
     }
     {
         const double a50 = h * A50, a51 = h * A51, a52 = h * A52, a53 = h * A53, a54 = h * A54;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int i = moving_component(c, Z);
-            yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
-        }
+        for (int i = 0; i < NEQ; ++i)
+            if (through_stages<Model, PATH, CLOSED>(i)) yt[i] = lc(y[i], a50, k0[i], a51, k1[i], a52, k2[i], a53, k3[i], a54, k4[i]);
         f(yt, k5);
     }
     {
         // stage 6 state: row 6 of a is b (rk45_step_dense.cuh:66-68)
         const double hb0 = h * B0, hb2 = h * B2, hb3 = h * B3, hb4 = h * B4, hb5 = h * B5;
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-            const int i = moving_component(c, Z);
-            yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
+        for (int i = 0; i < NEQ; ++i)
+            if (through_stages<Model, PATH, CLOSED>(i)) yt[i] = lc(y[i], hb0, k0[i], hb2, k2[i], hb3, k3[i], hb4, k4[i], hb5, k5[i]);
+        if constexpr (CLOSED) {
+            // the linear components' 5th-order solution y R(z), z = lambda h, before the last RHS call (k6 = rhs(yt))
+#pragma unroll
+            for (int k = 0; k < Model::NORAIN_LINEAR; ++k) {
+                const int i = Model::NORAIN_LINEAR_COMP[k];
+                const double lam = Model::norain_rate(P, k), z = lam * h;
+                // a slope carried over from another path's attempt may hold an inflow this path does not have
+                broke |= k0[i] != lam * y[i];
+                double q = __builtin_fma(LIN_R[6], z, LIN_R[5]);
+                q = __builtin_fma(q, z, LIN_R[4]);
+                q = __builtin_fma(q, z, LIN_R[3]);
+                q = __builtin_fma(q, z, LIN_R[2]);
+                q = __builtin_fma(q, z, LIN_R[1]);
+                yt[i] = __builtin_fma(y[i], q * z, y[i]);
+            }
         }
         f(yt, k6);
     }
@@ -269,7 +298,7 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
 // stage: error term 0, tolerance atol, slope difference 0) drops out at compile time, and so that
 // only y_new, k0 and k6 -- not all seven slope vectors -- have to meet in the same registers where
 // the paths join.
-template <class Model, int MATH, int PATH, bool FIXED>
+template <class Model, int MATH, int PATH, bool FIXED, bool CLOSED = false>
 __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const typename Model::Forc& FV,
                                            const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool have_k0,
                                            double (&k0)[Model::N_EQ], double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ],
@@ -278,7 +307,19 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
 {
     using namespace dp;
     constexpr int NEQ = Model::N_EQ;
-    const bool broke = rk_stages<Model, MATH, PATH>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+    const bool broke = rk_stages<Model, MATH, PATH, CLOSED>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+    // closed-form error estimate y E(z) and first slope difference k0 - k1 = -k0 A10 z of the linear components
+    [[maybe_unused]] double e_lin[NEQ], j_lin[NEQ];
+    if constexpr (CLOSED && !FIXED) {
+#pragma unroll
+        for (int k = 0; k < Model::NORAIN_LINEAR; ++k) {
+            const int i = Model::NORAIN_LINEAR_COMP[k];
+            const double z = Model::norain_rate(P, k) * h, z2 = z * z, z5 = z2 * z2 * z;
+            e_lin[i] = (y[i] * z5) * __builtin_fma(__builtin_fma(LIN_E7, z, LIN_E6), z, LIN_E5);
+            j_lin[i] = k0[i] * (A10 * z);
+        }
+    }
+    auto closed = [](int i) { return CLOSED && i != Model::FAST_ZERO_COMP && !through_stages<Model, PATH, true>(i); };
     if constexpr (!FIXED) {
         constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : -1;  // pinned component, if any
         const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5, he6 = h * E6;
@@ -295,7 +336,7 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
                     e[i] = 0.0;
                     tl[i] = A.atol;  // fma(rtol, max(|0|, |0|), atol)
                 } else {
-                    e[i] = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                    e[i] = closed(i) ? e_lin[i] : lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
                     tl[i] = __builtin_fma(A.rtol, vmax_abs(y[i], yt[i]), A.atol);
                 }
             }
@@ -312,7 +353,7 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) {
                 if (i == Z) continue;
-                const double y_err = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+                const double y_err = closed(i) ? e_lin[i] : lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
                 err = vmax_abs2(err, y_err * fast_rcp(__builtin_fma(A.rtol, vmax_abs(y[i], yt[i]), A.atol)));
             }
         } else {
@@ -328,7 +369,7 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
         jump = 0.0;
 #pragma unroll
         for (int i = 0; i < NEQ; ++i)
-            if (i != Z) jump = vmax_abs2(jump, k0[i] - k1[i]);
+            if (i != Z) jump = vmax_abs2(jump, closed(i) ? j_lin[i] : k0[i] - k1[i]);
     }
     return broke;
 }
@@ -394,13 +435,54 @@ struct HeldForcing {
 // step (inflow reached the surface store); if it did for any lane the attempt is simply recomputed
 // with the general RHS -- same bits either way.  On return have_k0 is true (k0 stays valid through a
 // reject / slope-jump retry) and yt is the 5th-order solution.
+// The same for launches that do not read the stage slopes afterwards (no dense output), FAST arithmetic, models with
+// linear components on the no-rain path: that path then takes those components in closed form, which rounds
+// differently from the stage-by-stage arithmetic of the other two -- so WHICH path integrates a hillslope may no longer
+// depend on its 63 neighbours, or the results would depend on the launch shape and on where a shard ends.  Here every
+// lane decides for itself: the lanes that qualify run the no-rain path (under their mask when the wave is mixed), and
+// those that did not qualify or left the regime during the step (their own tests) are integrated by the dry / general
+// paths -- which of the two is still decided per wave: they agree bit for bit.
 template <class Model, int MATH, bool FIXED>
+__device__ __forceinline__ void attempt_per_lane_path(const typename Model::Local& P, const typename Model::Forc& FV,
+                                                      const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool& have_k0,
+                                                      double (&k0)[Model::N_EQ], double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ],
+                                                      double (&k3)[Model::N_EQ], double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ],
+                                                      double (&k6)[Model::N_EQ], double (&yt)[Model::N_EQ], double& err, double& jump)
+{
+    bool stagewise = true;  // this lane still needs the dry / general path
+    if (Model::norainpath_ok(P, FV, y)) {
+        const bool had_k0 = have_k0;
+        const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED, true>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        stagewise = broke;
+        have_k0 = broke ? had_k0 : true;  // (a k0 evaluated in an attempt that falls back is not kept: see below)
+    }
+    if (stagewise) {
+        bool general = true;
+        if constexpr (Model::HAS_FASTPATH) {
+            if (__builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {  // (among the lanes in here)
+                const bool broke = rk_attempt<Model, MATH, PATH_DRY, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                have_k0 = true;  // k0 of a qualifying state is exact
+                general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+            }
+        }
+        if (general) rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+    }
+    have_k0 = true;
+}
+
+// NEED_K: the caller reads the stage slopes of the accepted step afterwards (dense output); else the no-rain path
+// may take its linear components in closed form (FAST only: attempt_per_lane_path).
+template <class Model, int MATH, bool FIXED, bool NEED_K = true>
 __device__ __forceinline__ void attempt_on_cheapest_path(const typename Model::Local& P, const typename Model::Forc& FV,
                                                          const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool& have_k0,
                                                          double (&k0)[Model::N_EQ], double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ],
                                                          double (&k3)[Model::N_EQ], double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ],
                                                          double (&k6)[Model::N_EQ], double (&yt)[Model::N_EQ], double& err, double& jump)
 {
+    if constexpr (!NEED_K && MATH == MATH_FAST && Model::HAS_NORAINPATH && Model::NORAIN_LINEAR > 0) {
+        attempt_per_lane_path<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        return;
+    }
     bool general = true;
     if constexpr (Model::HAS_NORAINPATH) {
         // between storms (no rain in the held sample, dry surface): the cascade below the static store is idle
@@ -608,7 +690,7 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         // ---- 7 stages + the two norms, on the cheapest RHS path the wave qualifies for -------------
         double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ], yn[NEQ];
         [[maybe_unused]] double err = 0.0, jump = 0.0;
-        attempt_on_cheapest_path<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        attempt_on_cheapest_path<Model, MATH, FIXED, DENSE>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
         // 5th-order solution (rk45_step_dense.cuh:111-117).  b[6] = 0, so it is the same
         // chain of operations as the stage-6 state: identical bits, reuse it.
 #pragma unroll

@@ -41,6 +41,60 @@ constexpr double P51 = -282668133.0 / 205662961.0, P52 = 2019193451.0 / 61698888
 constexpr double P61 = 40617522.0 / 29380423.0, P62 = -110615467.0 / 29380423.0,
                  P63 = 69997945.0 / 29380423.0;
 
+// ---- the method applied to y' = lambda y, in closed form ----------------------------------------------------
+// For a linear homogeneous component every stage slope is lambda y p_j(z), z = lambda h, with polynomials p_j fixed by
+// the tableau; so are the 5th-order solution y R(z) (R = p_6: the stability polynomial) and the error estimate
+// y E(z).  Derived from the tableau at compile time and checked against the closed expressions the kernels use:
+// R = 1 + z + z^2/2 + z^3/6 + z^4/24 + z^5/120 + z^6/600,  E = -97/120000 z^5 + 13/40000 z^6 - 1/24000 z^7
+// (E starts at z^5: the embedded solution is of order 4).
+struct Poly8 { double c[8]; };
+constexpr Poly8 poly8_zero() { return Poly8{{0, 0, 0, 0, 0, 0, 0, 0}}; }
+constexpr Poly8 poly8_axpy(Poly8 acc, double a, const Poly8& p)  // acc + a p
+{
+    for (int k = 0; k < 8; ++k) acc.c[k] += a * p.c[k];
+    return acc;
+}
+constexpr Poly8 poly8_z_times(const Poly8& p)
+{
+    Poly8 r = poly8_zero();
+    for (int k = 0; k < 7; ++k) r.c[k + 1] = p.c[k];
+    return r;
+}
+constexpr Poly8 poly8_one_plus_z_times(const Poly8& p)  // 1 + z p
+{
+    Poly8 r = poly8_z_times(p);
+    r.c[0] = 1.0;
+    return r;
+}
+struct LinearTest { Poly8 R, E; };
+constexpr LinearTest linear_test_polynomials()
+{
+    Poly8 p0 = poly8_zero();
+    p0.c[0] = 1.0;
+    const Poly8 p1 = poly8_one_plus_z_times(poly8_axpy(poly8_zero(), A10, p0));
+    const Poly8 p2 = poly8_one_plus_z_times(poly8_axpy(poly8_axpy(poly8_zero(), A20, p0), A21, p1));
+    const Poly8 p3 = poly8_one_plus_z_times(poly8_axpy(poly8_axpy(poly8_axpy(poly8_zero(), A30, p0), A31, p1), A32, p2));
+    const Poly8 p4 = poly8_one_plus_z_times(poly8_axpy(poly8_axpy(poly8_axpy(poly8_axpy(poly8_zero(), A40, p0), A41, p1), A42, p2), A43, p3));
+    const Poly8 p5 = poly8_one_plus_z_times(
+        poly8_axpy(poly8_axpy(poly8_axpy(poly8_axpy(poly8_axpy(poly8_zero(), A50, p0), A51, p1), A52, p2), A53, p3), A54, p4));
+    const Poly8 p6 = poly8_one_plus_z_times(
+        poly8_axpy(poly8_axpy(poly8_axpy(poly8_axpy(poly8_axpy(poly8_zero(), B0, p0), B2, p2), B3, p3), B4, p4), B5, p5));
+    const Poly8 e = poly8_z_times(poly8_axpy(
+        poly8_axpy(poly8_axpy(poly8_axpy(poly8_axpy(poly8_axpy(poly8_zero(), E0, p0), E2, p2), E3, p3), E4, p4), E5, p5), E6, p6));
+    return LinearTest{p6, e};
+}
+constexpr LinearTest LINEAR = linear_test_polynomials();
+constexpr double LIN_R[7] = {1.0, 1.0, 1.0 / 2.0, 1.0 / 6.0, 1.0 / 24.0, 1.0 / 120.0, 1.0 / 600.0};
+constexpr double LIN_E5 = -97.0 / 120000.0, LIN_E6 = 13.0 / 40000.0, LIN_E7 = -1.0 / 24000.0;
+constexpr bool near_c(double a, double b) { return (a - b < 0 ? b - a : a - b) < 1e-15; }
+static_assert(near_c(LINEAR.R.c[0], LIN_R[0]) && near_c(LINEAR.R.c[1], LIN_R[1]) && near_c(LINEAR.R.c[2], LIN_R[2]) &&
+                  near_c(LINEAR.R.c[3], LIN_R[3]) && near_c(LINEAR.R.c[4], LIN_R[4]) && near_c(LINEAR.R.c[5], LIN_R[5]) &&
+                  near_c(LINEAR.R.c[6], LIN_R[6]) && LINEAR.R.c[7] == 0.0,
+              "stability polynomial of the Dormand-Prince pair");
+static_assert(near_c(LINEAR.E.c[0], 0) && near_c(LINEAR.E.c[1], 0) && near_c(LINEAR.E.c[2], 0) && near_c(LINEAR.E.c[3], 0) &&
+                  near_c(LINEAR.E.c[4], 0) && near_c(LINEAR.E.c[5], LIN_E5) && near_c(LINEAR.E.c[6], LIN_E6) && near_c(LINEAR.E.c[7], LIN_E7),
+              "error polynomial of the Dormand-Prince pair");
+
 }  // namespace dp
 
 // reference src/solver/event_detector.cuh:11,15
