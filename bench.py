@@ -776,7 +776,9 @@ def main():
                                 if pieces else "")},
         "roofline_valu_fp64": {"bound": "valu_fp64", "achieved": valu_tf, "peak": PEAK_FP64_VALU_TFLOPS,
                                "unit": "TFLOP/s", "frac": valu_tf / PEAK_FP64_VALU_TFLOPS,
-                               "algorithmic_flops_per_step": F_STEP_204},
+                               "algorithmic_flops_per_step": F_STEP_204,
+                               "note": "606 flop/step is the reference algorithm's count (SURVEY 8d): the kernel executes fewer -- "
+                                       "FSAL reuse, cheap RHS paths between storms, two stores in closed form -- for the same steps"},
         "attempts_per_pass": attempts_all, "attempts_per_hillslope": attempts_all / total,
         "flagged_fraction": float(flagged.item()) / total, "kernel_ms_each": kernel_ms,
     }
