@@ -104,7 +104,7 @@ int hlm_set_math_mode(int mode);
 /* 1: the host API's launches without dense output use lane refill (hlm_device_job.lane_refill). */
 int hlm_set_lane_refill(int enabled);
 /* hlm_device_job.time_pieces of the host API's launches without dense output: 0 / 1 = one wave per tile; negative
- * (the default) = automatic: from 65 536 hillslopes on, one piece per twelve simulated hours, at most 32, none
+ * (the default) = automatic: from 4 096 hillslopes on, one piece per twelve simulated hours, at most 32, none
  * when that makes fewer than 8 (a 4-day window is the shortest that is cut). */
 int hlm_set_time_pieces(int pieces);
 /* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
@@ -271,7 +271,7 @@ typedef struct hlm_device_job {
      * instead of one wave per tile for the whole window -- the same integration bit for bit (a lane pauses before
      * the first attempt that starts at or after its piece's end and continues from that state), but the launch no
      * longer drains at its end behind the longest waves: 6 % of a 1 M-hillslope x 30-day launch.  0 / 1: one wave
-     * per tile (the reference's map, rk45_kernel.cu:33).  Negative: automatic -- from 65 536 hillslopes on, one piece
+     * per tile (the reference's map, rk45_kernel.cu:33).  Negative: automatic -- from 4 096 hillslopes on, one piece
      * per twelve simulated hours, at most 32, none when that makes fewer than 8 (few pieces cost more than they
      * save); one wave per tile otherwise.  At most 4096. */
     int time_pieces;

@@ -1028,7 +1028,7 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
 
 
 def test_time_pieces_default_rule_and_the_radau_hand_over(gpu):
-    """The automatic launch shape (hlm_set_time_pieces(-1): from 65 536 hillslopes on, one piece per twelve
+    """The automatic launch shape (hlm_set_time_pieces(-1): from 4 096 hillslopes on, one piece per twelve
     simulated hours, at most 32, none below 8) gives the host API's run_rk45 the same bits as the forced fixed map, and a flagged hillslope
     leaves the same flag state for the Radau pass whichever kernel integrated it."""
     H = gpu

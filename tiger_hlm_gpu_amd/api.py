@@ -112,7 +112,7 @@ def set_lane_refill(enabled):
 
 def set_time_pieces(pieces):
     """Launch shape of the host API's runs without dense output (hlm_set_time_pieces): > 1 = a persistent grid over a
-    queue of (time piece, tile) items; 0 / 1 = one wave per tile; negative = automatic (from 65 536 hillslopes
+    queue of (time piece, tile) items; 0 / 1 = one wave per tile; negative = automatic (from 4 096 hillslopes
     on, one piece per twelve simulated hours, at most 32, none below 8)."""
     check(lib().hlm_set_time_pieces(int(pieces)))
 

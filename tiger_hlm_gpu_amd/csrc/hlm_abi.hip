@@ -82,14 +82,16 @@ bool g_math_explicit = false;
 int g_refill = 0;  // hlm_set_lane_refill(): host-API launches without dense output use the refill kernel
 int g_time_pieces = -1;  // hlm_set_time_pieces(): < 0 = automatic (auto_time_pieces)
 constexpr int kMaxTimePieces = 4096;
-// The automatic launch shape of a run without dense output: from 65 536 hillslopes on (more tiles than a third of
-// the resident waves: below that the fixed map's one launch is as good, measured), one piece per twelve simulated
-// hours, at most 32 -- and none at all when that makes fewer than 8: FEW pieces cost more than the drain they
-// remove (measured, 1 M / 100 000 hillslopes: 2 pieces +3 / +17 %, 4 pieces -1 / +5 %, 8 pieces -3 / -3 %,
-// 16 pieces -4 / -7 %, 32 pieces -5 / -10 % on 8- to 30-day windows; profiles/r03_launch_shape_probe.txt).
+// The automatic launch shape of a run without dense output: from 4 096 hillslopes on, one piece per twelve simulated
+// hours, at most 32 -- and none at all when that makes fewer than 8: FEW pieces cost more than the drain they remove
+// (measured, 1 M / 100 000 hillslopes: 2 pieces +3 / +17 %, 4 pieces -1 / +5 %, 8 pieces -3 / -3 %, 16 pieces -4 /
+// -7 %, 32 pieces -5 / -10 % on 8- to 30-day windows; profiles/r03_launch_shape_probe.txt).  Since the no-rain path
+// takes its linear stores in closed form and every lane picks its path by itself, the pieces pay at every size
+// measured (4 096 ... 1 M hillslopes: -4 ... -13 %): they re-align the lanes of a wave in simulated time, and waves
+// whose lanes sit on both sides of a storm's edge run both paths.
 int auto_time_pieces(int num_systems, double t0, double tf)
 {
-    if (num_systems < 65536 || !(tf > t0)) return 0;
+    if (num_systems < 4096 || !(tf > t0)) return 0;
     const double p = (tf - t0) / 720.0;
     return p >= 32.0 ? 32 : (p >= 8.0 ? (int)p : 0);
 }

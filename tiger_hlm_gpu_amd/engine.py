@@ -26,7 +26,7 @@ class ShardEngine:
         self.math_mode, self.fixed_step, self.attempt_cap = math_mode, fixed_step, attempt_cap
         self.lane_refill = int(bool(lane_refill))  # hlm_device_job.lane_refill (launches without dense output)
         # hlm_device_job.time_pieces (launches without dense output): a persistent grid over (time piece, tile) items
-        # instead of one wave per tile; None = the host API's automatic rule (from 65 536 hillslopes on, one piece per
+        # instead of one wave per tile; None = the host API's automatic rule (from 4 096 hillslopes on, one piece per
         # twelve simulated hours, at most 32, none below 8)
         self.time_pieces = time_pieces
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
