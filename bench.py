@@ -799,7 +799,7 @@ def main():
                 eng.time_pieces = None if args.time_pieces < 0 else args.time_pieces
             return {"kernel": "hlm::rk45_multi_kernel<Model204Dev>", "kernel_ms_each": kms,
                     "queue_kernel_over_fixed_map": k_ms / float(np.mean(kms)), "time_pieces": pieces,
-                    "note": "same bits; the queue kernel removes the drain at the end of the launch"}
+                    "note": "same bits; the queue kernel removes the drain at the end of the launch and re-aligns the lanes of a wave in simulated time (fewer waves on two RHS paths)"}
         out["launch_shape"] = _optional(_fixed_map)
 
     if not args.no_variants and rank == 0 and world == 1:
