@@ -1080,6 +1080,10 @@ def test_closed_form_linear_stores_agree_with_the_stage_arithmetic(gpu):
     from tiger_hlm_gpu_amd import synth
     ns, days = 20_000, 6
     sp, y0, cells, pr, t2m, dt, nT = _m204_case(H, ns, days)
+    sp = sp.copy()
+    sp["alpha3"][::7] = 0.5     # a store the reference does not drain (alpha < 1: rate 0, R(0) = 1)
+    sp["alpha4"][::5] = 1.5     # ... and one that empties within minutes: |lambda h| up to ~2, the far end of R
+    sp["alpha3"][3::11] = 4.0
     tf = days * 1440.0
     q = np.array([tf])   # one query at the very end: the dense kernels, the same steps
     for mode in (H.MATH_FAST, H.MATH_STRICT):
