@@ -642,6 +642,28 @@ def test_cpp_driver_model204_g2(gpu, golden, tmp_path):
     assert np.allclose(got60, golden["g2_dense_sys0"][60], rtol=0, atol=6e-10 + 1e-6 * 5)
 
 
+def test_cpp_driver_time_pieces_same_final_csv(gpu, tmp_path):
+    """rk45_solver --time-pieces P (rk45_api::set_time_pieces -> hlm_set_time_pieces): 6 000 hillslopes x 6 days
+    without dense output, one wave per tile (0) against 12 pieces and the automatic choice: the same final.csv byte
+    for byte, the same attempted steps."""
+    import json
+    import subprocess
+    from tiger_hlm_gpu_amd import synth
+    exe = _driver_exe()
+    pcsv = tmp_path / "params.csv"
+    synth.write_params_csv(pcsv, synth.model204_params(0, 6000))
+    outs = {}
+    for tag, extra in (("fixed", ["--time-pieces", "0"]), ("twelve", ["--time-pieces", "12"]), ("auto", [])):
+        f = tmp_path / f"final_{tag}.csv"
+        out = subprocess.run([exe, "--model", "204", "--params", str(pcsv), "--tf", str(6 * 1440), "--nq", "0", "--initial-step", "0.01",
+                              "--rain", "0.0004", "--out-final", str(f), "--out-dense", str(tmp_path / f"dense_{tag}.csv")] + extra,
+                             check=True, timeout=300, capture_output=True, text=True).stdout
+        info = json.loads(out.strip().splitlines()[-1])
+        outs[tag] = (open(f, "rb").read(), info["attempted_steps"])
+    assert outs["fixed"][1] > 6000 * 100
+    assert outs["fixed"] == outs["twelve"] == outs["auto"]
+
+
 # ---- dense output in query windows (BASELINE config 5) ------------------------------------------
 @pytest.mark.parametrize("path", ["transfer-kernel", "transfer-kernel-tile-row", "copy-engine", "pageable"])
 @pytest.mark.parametrize("window", [1, 7, 48, 1000])

@@ -72,6 +72,7 @@ struct Options {
     int gpus = 1;               // shard the hillslopes over this many GPUs (one host thread each)
     bool radau = false;         // re-integrate flagged systems with the Radau-IIA fallback
     bool radau_continue = false; // ... continuing from the state RK45 reached instead of restarting at t0
+    int time_pieces = -1;        // launch shape of runs without dense output (-1 automatic, 0 one wave per tile)
     bool oversubscribe = false; // allow --gpus > visible devices (shards share GPUs round-robin)
     bool quiet = false;
 };
@@ -82,7 +83,7 @@ struct Options {
     std::fprintf(stderr,
                  "usage: rk45_solver [--config run.yaml] [--init-file states.csv] [--model dummy|204|toy3] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
-                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau | --radau-continue]\n"
+                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau | --radau-continue] [--time-pieces P]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
                  "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L] [--states I,J,..] [--stream-dense QUERIES_PER_WINDOW]\n"
                  "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
@@ -160,6 +161,7 @@ Options parse(int argc, char** argv)
         else if (a == "--math") o.math = val();
         else if (a == "--radau") o.radau = true;
         else if (a == "--radau-continue") o.radau = o.radau_continue = true;
+        else if (a == "--time-pieces") o.time_pieces = std::atoi(val());
         else if (a == "--out-final") o.out_final = val();
         else if (a == "--out-dense") o.out_dense = val();
         else if (a == "--forcing-nc") o.forcing_nc.push_back(val());
@@ -340,6 +342,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
         rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
     }
     rk45_api::set_radau_mode(o.radau_continue ? 2 : (o.radau ? 1 : 0));
+    rk45_api::set_time_pieces(o.time_pieces);
 
     // ---- initial state and query grid --------------------------------------------------------------------
     std::vector<double> h_y0((size_t)ns * N_EQ);
