@@ -386,6 +386,40 @@ def test_queue_kernels_keep_the_item_loop_wave_uniform():
     assert r.returncode == 0 and "12 instances, 0 bad" in r.stdout, r.stdout + r.stderr
 
 
+def test_tableau_polynomials_of_the_linear_test_equation(tmp_path):
+    """csrc/hlm_tableau.h derives, at compile time from the Dormand-Prince tableau (rk45_step_dense.cuh:54-83), the
+    polynomials of the method applied to y' = lambda y -- what the kernels' closed form for the linear stores evaluates:
+    R(z) = sum z^k / k! up to z^5, + z^6/600 (the stability polynomial) and the error estimate
+    -97/120000 z^5 + 13/40000 z^6 - 1/24000 z^7.  The header's static_asserts hold under g++ too, and the derived
+    coefficients printed here equal the rationals; and stepping y' = lambda y through the seven stages in plain Python
+    gives y R(lambda h)."""
+    import subprocess
+    src = tmp_path / "tp.cpp"
+    src.write_text('#include <cstdio>\n#include "hlm_tableau.h"\nint main(){ using namespace hlm::dp; for (int k = 0; k < 8; ++k) '
+                   'std::printf("%.17g %.17g\\n", LINEAR.R.c[k], LINEAR.E.c[k]); }\n')
+    exe = tmp_path / "tp"
+    subprocess.run(["g++", "-std=c++17", "-I", os.path.join(ROOT, "tiger_hlm_gpu_amd", "csrc"), "-o", str(exe), str(src)], check=True)
+    rows = [tuple(float(x) for x in ln.split()) for ln in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines()]
+    R = [1.0, 1.0, 1 / 2, 1 / 6, 1 / 24, 1 / 120, 1 / 600, 0.0]
+    E = [0.0, 0.0, 0.0, 0.0, 0.0, -97 / 120000, 13 / 40000, -1 / 24000]
+    assert np.allclose([r[0] for r in rows], R, rtol=0, atol=1e-15) and np.allclose([r[1] for r in rows], E, rtol=0, atol=1e-15)
+    # the stages, spelt out (a, b, b_alt of the pair)
+    from fractions import Fraction as F
+    a = [[], [F(1, 5)], [F(3, 40), F(9, 40)], [F(44, 45), F(-56, 15), F(32, 9)],
+         [F(19372, 6561), F(-25360, 2187), F(64448, 6561), F(-212, 729)],
+         [F(9017, 3168), F(-355, 33), F(46732, 5247), F(49, 176), F(-5103, 18656)],
+         [F(35, 384), F(0), F(500, 1113), F(125, 192), F(-2187, 6784), F(11, 84)]]
+    b_alt = [F(5179, 57600), F(0), F(7571, 16695), F(393, 640), F(-92097, 339200), F(187, 2100), F(1, 40)]
+    z = F(-37, 100)
+    k = []
+    for i in range(7):
+        k.append(1 + z * sum(a[i][j] * k[j] for j in range(i)))      # slope / (lambda y) of stage i
+    y5 = k[6]                                                          # stage 6 sits at the 5th-order solution
+    y4 = 1 + z * sum(b_alt[j] * k[j] for j in range(7))
+    assert abs(float(y5) - sum(R[m] * float(z) ** m for m in range(8))) < 1e-15
+    assert abs(float(y5 - y4) - sum(E[m] * float(z) ** m for m in range(8))) < 1e-17
+
+
 def test_cpp_params_loader_values_and_errors(hlm, golden, tmp_path):
     """include/hlm/parameters_loader.hpp (buffer + strtod, rows parsed by several threads) against the Python mirror
     of reference src/I_O/parameters_loader.cpp:8-107: the same rows bit for bit on the reference's sample file and
