@@ -216,12 +216,13 @@ struct Model204Dev {
     static constexpr int FAST_ZERO_COMP = 2;  // rhs_fast: dydt[2] == 0 unless it reports "broke"
     static __device__ __forceinline__ bool fastpath_ok(const double (&y)[N_EQ]) { return y[2] == 0.0; }
 
-    // No-rain path: a dry surface store AND no rainfall in the held sample.  Then x1 is the
-    // snowmelt alone and, while the static store stays below Hu, x2 = max(0, x1 + h_stat - Hu) = 0
-    // takes x3, x4, d2, d3 with it (model_204.hpp:94-113, given infil, perco >= 0): the cascade
-    // below the static store is not evaluated at all.  rhs_norain reports x1 + h_stat > Hu.  The
-    // expressions are the general ones with rain, x2, x3, x4, d2, d3 replaced by the literal 0.0
-    // they evaluate to: same values.
+    // "No-rain" path -- since round 3 really the UNSATURATED path: a dry surface store and, rain or not, a static
+    // store that stays below its capacity.  While x1 + h_stat <= Hu, x2 = max(0, x1 + h_stat - Hu) = 0 takes x3, x4,
+    // d2, d3 with it (model_204.hpp:94-113, given infil, perco >= 0): the cascade below the static store is not
+    // evaluated at all.  rhs_norain reports x1 + h_stat > Hu (every call: that is the regime test).  The expressions
+    // are the general ones with x2, x3, x4, d2, d3 replaced by the literal 0.0 they evaluate to: same values.
+    // (Until round 3 the path also required F.rain == 0 and dropped the rain from x1; rain that the static store
+    // absorbs -- most of it, with Hu of 100-250 -- then went the dry path's longer way.)
     static constexpr bool HAS_NORAINPATH = true;
     // On the no-rain path (x3 = x4 = 0) the gravitational and the aquifer store only drain: y' = -y / alpha, linear
     // and homogeneous -- the kernels may take them in closed form (rk_stages, CLOSED).  FAST arithmetic: the rate is
@@ -231,16 +232,18 @@ struct Model204Dev {
     static __device__ __forceinline__ double norain_rate(const Local& P, int k) { return k == 0 ? -P.inv_alpha3 : -P.inv_alpha4; }
     static __device__ __forceinline__ bool norainpath_ok(const Local& P, const Forc& F, const double (&y)[N_EQ])
     {
-        return y[2] == 0.0 && F.rain == 0.0 && P.nonneg;
+        (void)F;  // (round 3: rain or not -- what the path needs is x2 == 0, which rhs_norain tests in every call)
+        return y[2] == 0.0 && P.nonneg;
     }
     template <int MATH>
     static __device__ __forceinline__ bool rhs_norain(const Local& P, const Forc& F, const double (&y)[N_EQ],
                                                       double (&dydt)[N_EQ])
     {
         const double h_snow = y[0], h_stat = y[1], h_grav = y[3], h_aq = y[4];
-        const double x1 =
+        const double snowmelt =
             __longlong_as_double(__double_as_longlong(vmin(h_snow, F.melt_pot)) & (long long)F.warm_mask);
-        dydt[0] = 0.0 - x1;
+        const double x1 = F.rain + snowmelt;  // (:87-91; with no rain in the sample: 0 + snowmelt, the same value)
+        dydt[0] = F.rain - snowmelt;
         // x2 = max(0, x1 + h_stat - Hu) > 0; (a - b > 0) == (a > b) exactly in IEEE arithmetic
         const bool wet = x1 + h_stat > P.Hu;
         const double Emax = vmin(F.e_pot, h_stat);
