@@ -262,6 +262,29 @@ struct Model204Dev {
         return wet;
     }
 
+    // The unsaturated regime with a WET surface store: as rhs_norain, and the surface store drains by the Manning term
+    // (model_204.hpp:101-105 with d2 = 0); the gravitational and the aquifer store still only drain (closed form).
+    // FAST arithmetic, launches without dense output (attempt_per_lane_path).
+    static __device__ __forceinline__ bool wetupath_ok(const Local& P, const Forc&, const double (&y)[N_EQ]) { return y[2] > 0.0 && P.nonneg; }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_wetu(const Local& P, const Forc& F, const double (&y)[N_EQ], double (&dydt)[N_EQ])
+    {
+        const double h_snow = y[0], h_stat = y[1], h_surf = y[2], h_grav = y[3], h_aq = y[4];
+        const double snowmelt =
+            __longlong_as_double(__double_as_longlong(vmin(h_snow, F.melt_pot)) & (long long)F.warm_mask);
+        const double x1 = F.rain + snowmelt;
+        dydt[0] = F.rain - snowmelt;
+        const bool wet = x1 + h_stat > P.Hu;
+        const double Emax = vmin(F.e_pot, h_stat);
+        const double s = h_stat * P.inv_Hu;
+        dydt[1] = x1 - s * Emax;
+        const double w = vmin(1.0, P.manning * pow_two_thirds<MATH>(h_surf));
+        dydt[2] = 0.0 - h_surf * w;
+        dydt[3] = 0.0 - h_grav * P.inv_alpha3;
+        dydt[4] = 0.0 - h_aq * P.inv_alpha4;
+        return wet;
+    }
+
     template <int MATH>
     static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[N_EQ],
                                                double (&dydt)[N_EQ])

@@ -187,7 +187,11 @@ __device__ __forceinline__ void record_flag_state(double* flag_state, int sys, c
 // every stage, so it is left out of the stage arithmetic (y + sum h*a*0 == y, bit for bit).  The
 // return value tells whether any stage left the regime (always false for PATH_GENERAL).
 // PATH_NORAIN = Model::rhs_norain: the dry path's regime with no rainfall in the held sample.
-constexpr int PATH_GENERAL = 0, PATH_DRY = 1, PATH_NORAIN = 2;
+// PATH_WETU = Model::rhs_wetu: the unsaturated regime with a WET surface store -- the surface store moves (it only
+// drains: -h w(h)), nothing is pinned, the cascade below the static store is idle as on PATH_NORAIN.  Only the
+// per-lane selection (attempt_per_lane_path) takes it.
+constexpr int PATH_GENERAL = 0, PATH_DRY = 1, PATH_NORAIN = 2, PATH_WETU = 3;
+constexpr bool path_pins(int path) { return path == PATH_DRY || path == PATH_NORAIN; }
 
 // index of the c-th moving component when component Z is pinned (identity for Z >= N)
 constexpr int moving_component(int c, int Z) { return c < Z ? c : c + 1; }
@@ -199,7 +203,7 @@ constexpr int moving_component(int c, int Z) { return c < Z ? c : c + 1; }
 template <class Model, int PATH, bool CLOSED>
 constexpr bool through_stages(int i)
 {
-    if (PATH != 0 /* PATH_GENERAL */ && i == Model::FAST_ZERO_COMP) return false;
+    if ((PATH == 1 || PATH == 2) /* the paths that pin the surface store */ && i == Model::FAST_ZERO_COMP) return false;
     if (CLOSED)
         for (int k = 0; k < Model::NORAIN_LINEAR; ++k)
             if (i == Model::NORAIN_LINEAR_COMP[k]) return false;
@@ -216,10 +220,11 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     using namespace dp;
     constexpr int NEQ = Model::N_EQ;
     // components that move: all of them, or all but the one the fast path pins
-    constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : NEQ;
+    constexpr int Z = path_pins(PATH) ? Model::FAST_ZERO_COMP : NEQ;
     bool broke = false;
     auto f = [&](const double (&state)[NEQ], double (&slope)[NEQ]) {
         if constexpr (PATH == PATH_NORAIN) broke |= Model::template rhs_norain<MATH>(P, FV, state, slope);
+        else if constexpr (PATH == PATH_WETU) broke |= Model::template rhs_wetu<MATH>(P, FV, state, slope);
         else if constexpr (PATH == PATH_DRY) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
         else Model::template rhs<MATH>(P, FV, state, slope);
     };
@@ -231,7 +236,7 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
     if (!have_k0) f(y, k0);  // no FSAL in the reference: see the have_k0 comment in the kernel
     // a pinned component must really stand still: a carried-over k0 (k6 of a step the general path
     // took) can hold the first inflow into a still-dry store, which the stage states below would ignore
-    if constexpr (PATH != PATH_GENERAL) broke |= k0[Z] != 0.0;
+    if constexpr (path_pins(PATH)) broke |= k0[Z] != 0.0;
     {
         const double a10 = h * A10;
 #pragma unroll
@@ -319,9 +324,9 @@ __device__ __forceinline__ bool rk_attempt(const typename Model::Local& P, const
             j_lin[i] = k0[i] * (A10 * z);
         }
     }
-    auto closed = [](int i) { return CLOSED && i != Model::FAST_ZERO_COMP && !through_stages<Model, PATH, true>(i); };
+    auto closed = [](int i) { return CLOSED && !(path_pins(PATH) && i == Model::FAST_ZERO_COMP) && !through_stages<Model, PATH, true>(i); };
     if constexpr (!FIXED) {
-        constexpr int Z = PATH != PATH_GENERAL ? Model::FAST_ZERO_COMP : -1;  // pinned component, if any
+        constexpr int Z = path_pins(PATH) ? Model::FAST_ZERO_COMP : -1;  // pinned component, if any
         const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5, he6 = h * E6;
         // yt is the 5th-order solution: b[6] = 0 makes it the same chain of operations as the
         // stage-6 state (rk45_step_dense.cuh:111-117)
@@ -439,9 +444,10 @@ struct HeldForcing {
 // linear components on the no-rain path: that path then takes those components in closed form, which rounds
 // differently from the stage-by-stage arithmetic of the other two -- so WHICH path integrates a hillslope may no longer
 // depend on its 63 neighbours, or the results would depend on the launch shape and on where a shard ends.  Here every
-// lane decides for itself: the lanes that qualify run the no-rain path (under their mask when the wave is mixed), and
-// those that did not qualify or left the regime during the step (their own tests) are integrated by the dry / general
-// paths -- which of the two is still decided per wave: they agree bit for bit.
+// lane decides for itself: the lanes that qualify run the unsaturated path -- its dry-surface form (PATH_NORAIN) or its
+// wet-surface form (PATH_WETU), each under its mask when the wave is mixed -- and those that did not qualify or left
+// the regime during the step (their own tests) are integrated by the dry / general paths -- which of the two is still
+// decided per wave: they agree bit for bit.
 template <class Model, int MATH, bool FIXED>
 __device__ __forceinline__ void attempt_per_lane_path(const typename Model::Local& P, const typename Model::Forc& FV,
                                                       const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool& have_k0,
@@ -455,6 +461,12 @@ __device__ __forceinline__ void attempt_per_lane_path(const typename Model::Loca
         const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED, true>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
         stagewise = broke;
         have_k0 = broke ? had_k0 : true;  // (a k0 evaluated in an attempt that falls back is not kept: see below)
+    }
+    else if (Model::wetupath_ok(P, FV, y)) {
+        const bool had_k0 = have_k0;
+        const bool broke = rk_attempt<Model, MATH, PATH_WETU, FIXED, true>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        stagewise = broke;
+        have_k0 = broke ? had_k0 : true;
     }
     if (stagewise) {
         bool general = true;
