@@ -436,12 +436,6 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
     char* pool = nullptr;
     HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + qbytes, stream));
     unsigned int* queue = reinterpret_cast<unsigned int*>(pool + rbytes);
-#ifdef HLM_QUEUE_MEMSET
-    if (hipError_t e = hipMemsetAsync(queue, 0, qbytes, stream); e != hipSuccess) {
-        (void)hipFreeAsync(pool, stream);
-        return fail(HLM_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e));
-    }
-#else
     {
         const unsigned int words = (unsigned int)(qbytes / sizeof(unsigned int));
         hipLaunchKernelGGL(hlm::queue_init_kernel, dim3((words + 255u) / 256u), dim3(256), 0, stream, queue, words);
@@ -450,7 +444,6 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
             return fail(HLM_ERR_HIP, "queue_init_kernel failed: %s", hipGetErrorString(e));
         }
     }
-#endif
     hlm::Rk45Args a = make_args(j);
     a.resume = reinterpret_cast<double*>(pool);
 #ifdef HLM_QUEUE_DEBUG
