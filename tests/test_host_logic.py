@@ -19,13 +19,13 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 44
+    assert len(names) == 45
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
     # and the python binding covers exactly the header
     assert sorted(hlm._lib.SIGNATURES) == names
-    assert hlm._lib.lib().hlm_abi_version() == 3
+    assert hlm._lib.lib().hlm_abi_version() == 4
 
 
 def test_struct_layouts_match_header(hlm, tmp_path):
@@ -49,12 +49,12 @@ def test_struct_layouts_match_header(hlm, tmp_path):
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
     got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout.splitlines())
-    assert int(got["abi"]) == hlm._lib.lib().hlm_abi_version() == 3
+    assert int(got["abi"]) == hlm._lib.lib().hlm_abi_version() == 4
     for cname, ct in structs.items():
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
-    assert len(hlm._lib.DeviceJob._fields_) == 37 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
+    assert len(hlm._lib.DeviceJob._fields_) == 38 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
 
 
 def test_registry_roundtrip_and_validation_without_gpu(hlm):

@@ -983,7 +983,8 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
     (a wave waits for its own previous piece), the attempt cap hit in the first piece, fixed steps (also a short window,
     where a last-bit difference of one resumed attempt survives to tf: the copies of a model's RHS the compiler inlines
     must round alike, csrc/hlm_models.h DummyDev::rhs), the 3-state model, STRICT math on a wet surface, an empty
-    window; piece counts 2 ... 64, incl. more pieces than forcing samples."""
+    window; piece counts 2 ... 64, incl. more pieces than forcing samples; and whatever runs of pieces the queue hands
+    out (lane states in registers inside a run, through HBM between runs)."""
     H = gpu
     from tiger_hlm_gpu_amd import synth
     kw, pieces, t0 = {}, (2, 5, 16), 0.0
@@ -1025,9 +1026,9 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
         pr, t2m, dt, nT = synth.forcing_tables(days=days)
         model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), 0.0   # tf == t0
 
-    def run(p):
+    def run(p, run_pieces=0):
         from tiger_hlm_gpu_amd.engine import ShardEngine
-        eng = ShardEngine(model, y0, t0, tf, sp=sp, time_pieces=p, **kw)
+        eng = ShardEngine(model, y0, t0, tf, sp=sp, time_pieces=p, queue_run_pieces=run_pieces, **kw)
         if case == "toy":
             eng.set_forcings_per_cell((inflow,), cells, (1.0,), (inflow.shape[0],))
         elif sp is not None:
@@ -1036,9 +1037,13 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
         return eng.results()
     a = run(0)
     for p in pieces:
-        b = run(p)
-        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
-            assert np.array_equal(a[k], b[k]), (case, p, k)
+        # what the queue hands out (hlm_device_job.queue_run_pieces, round 4): automatic runs of pieces (one run while
+        # the tiles fit the resident waves, halving runs beyond: cold-cells and benchmark), every piece handed over
+        # through HBM (1: round 3's protocol), runs of 3 pieces (the last run shorter)
+        for run_pieces in (0, 1, 3):
+            b = run(p, run_pieces)
+            for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+                assert np.array_equal(a[k], b[k]), (case, p, run_pieces, k)
     if case == "cold-cells":
         assert 0.05 < (a["stiff"] == 1).mean() < 0.95
     if case == "dummy-capped":
@@ -1119,7 +1124,7 @@ def test_closed_form_linear_stores_agree_with_the_stage_arithmetic(gpu):
         else:
             print(f"closed form vs stage arithmetic: median {np.median(dev):.3g}, 99th percentile {np.quantile(dev, 0.99):.3g}, max {dev.max():.3g} of the bound; "
                   f"step counts equal on {np.mean(a['n_attempt'] == b['n_attempt']):.4f}")
-            assert np.quantile(dev, 0.99) < 1e-3 and dev.max() < 1.0
+            assert np.quantile(dev, 0.99) < 1e-3 and dev.max() < 1e-2   # (observed maximum: 5e-4 of the bound)
             assert np.mean(a["n_attempt"] == b["n_attempt"]) > 0.98
 
 

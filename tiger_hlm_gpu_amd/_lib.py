@@ -60,7 +60,7 @@ class DeviceJob(C.Structure):
         ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
         ("lane_refill", C.c_int),
         ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
-        ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int),
+        ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int), ("queue_run_pieces", C.c_int),
     ]
 
 
@@ -127,6 +127,8 @@ SIGNATURES = {
     "hlm_selftest_math": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hlm_selftest_rhs": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_void_p]),
+    "hlm_selftest_attempt": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "hlm_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

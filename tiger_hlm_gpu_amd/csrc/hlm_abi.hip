@@ -234,7 +234,7 @@ RefillFn pick_refill(int uid, int math, bool fixed)
 }
 
 // the persistent kernels over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): no dense output
-using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int);
+using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int, const hlm::QueueRuns);
 template <class Model>
 QueueFn pick_queue(int math, bool fixed)
 {
@@ -316,6 +316,7 @@ int validate_job(const hlm_device_job* j)
     // (the queue kernel numbers its (piece, tile) items with 32 bits)
     if (j->time_pieces > 1 && ((long long)j->num_systems + 63) / 64 * (long long)j->time_pieces >= (1ll << 32) - 1)
         return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces %d x %d hillslopes: more than 2^32 (piece, tile) items", j->time_pieces, j->num_systems);
+    if (j->queue_run_pieces < 0) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_run_pieces must be >= 0 (0 = automatic)");
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
@@ -417,8 +418,40 @@ char* g_debug_queue_pool = nullptr;
 size_t g_debug_queue_rbytes = 0, g_debug_queue_qbytes = 0;
 #endif
 
-// Persistent launch over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): as many one-wave workgroups as
-// the device holds at once; the lane states between the pieces live in a stream-ordered scratch allocation.
+// The runs of pieces a queue launch hands out (hlm_device_job.queue_run_pieces; hlm_rk45_queue_kernel.h "RUNS").
+// Automatic: a launch with no more tiles than resident waves has no tail to remove -- one run, the pieces only re-align
+// the lanes; else every run takes half of what is left of the window, down to a sixteenth of it (32 pieces: 16, 8, 4,
+// 2, 2): the launch's tail is that of its last items, and 16 pieces were where round 3's sweep reached the asymptote.
+hlm::QueueRuns make_queue_runs(int pieces, long long tiles, long long resident, int run_pieces)
+{
+    hlm::QueueRuns r;
+    std::memset(&r, 0, sizeof(r));
+    if (run_pieces > 0) {
+        r.uniform = run_pieces < pieces ? run_pieces : pieces;
+        r.nruns = (pieces + r.uniform - 1) / r.uniform;
+        return r;
+    }
+    if (tiles <= resident) {
+        r.nruns = 1;
+        r.begin_[1] = pieces;
+        return r;
+    }
+    const int least = pieces / 16 > 1 ? pieces / 16 : 1;
+    int b = 0;
+    while (b < pieces && r.nruns < hlm::QUEUE_MAX_RUNS - 1) {
+        const int rem = pieces - b;
+        int len = rem / 2 > least ? rem / 2 : least;
+        if (len > rem) len = rem;
+        r.begin_[r.nruns++] = b;
+        b += len;
+    }
+    if (b < pieces) r.begin_[r.nruns++] = b;   // (never with least = pieces / 16: at most 6 runs)
+    r.begin_[r.nruns] = pieces;
+    return r;
+}
+
+// Persistent launch over a queue of (run of time pieces, tile) items (hlm_rk45_queue_kernel.h): as many one-wave
+// workgroups as the device holds at once; the lane states between the runs live in a stream-ordered scratch allocation.
 int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
 {
     const bool fixed = j->fixed_step > 0.0;
@@ -451,7 +484,8 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
     g_debug_queue_rbytes = rbytes;
     g_debug_queue_qbytes = qbytes;
 #endif
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, pieces);
+    const hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, j->queue_run_pieces);
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, pieces, runs);
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(pool, stream));  // stream-ordered: after the kernel
     HLM_HIP_TRY(launched);
@@ -1301,6 +1335,32 @@ int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, c
             hipLaunchKernelGGL((selftest_rhs_kernel<M, MATH_FAST>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, M::HAS_FASTPATH ? fast_path : 0, n);
         else
             hipLaunchKernelGGL((selftest_rhs_kernel<M, MATH_STRICT>), grid, block, 0, s, d_y, d_sp, d_F, d_out, d_broke, M::HAS_FASTPATH ? fast_path : 0, n);
+        return true;
+    });
+    if (!known) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    HLM_HIP_TRY(hipGetLastError());
+    return HLM_SUCCESS;
+}
+
+int hlm_selftest_attempt(int uid, int math_mode, int path, int closed, const double* d_y, const void* d_sp, const float* d_F,
+                         const double* d_h, double rtol, double atol, double* d_ynew, double* d_err_jump, int32_t* d_broke, int n,
+                         void* hip_stream)
+{
+    if (n < 0 || (n > 0 && (!d_y || !d_F || !d_h || !d_ynew || !d_err_jump))) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest_attempt buffers");
+    if (math_mode != HLM_MATH_STRICT && math_mode != HLM_MATH_FAST) return fail(HLM_ERR_INVALID_ARGUMENT, "math mode %d", math_mode);
+    if (path < HLM_ATTEMPT_SELECT_DENSE || path > 3) return fail(HLM_ERR_INVALID_ARGUMENT, "attempt path %d", path);
+    if (!(rtol >= 0.0) || !(atol >= 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest_attempt tolerances");
+    if (model_needs_sp(uid) && n > 0 && !d_sp) return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs d_sp");
+    if (n == 0) return HLM_SUCCESS;
+    hipStream_t s = static_cast<hipStream_t>(hip_stream);
+    const dim3 grid((unsigned)((n + 63) / 64)), block(64);
+    using namespace hlm;
+    const bool known = with_model<bool>(uid, [&](auto m) {
+        using M = decltype(m);
+        if (math_mode == HLM_MATH_FAST)
+            hipLaunchKernelGGL((selftest_attempt_kernel<M, MATH_FAST>), grid, block, 0, s, d_y, d_sp, d_F, d_h, rtol, atol, path, closed, d_ynew, d_err_jump, d_broke, n);
+        else
+            hipLaunchKernelGGL((selftest_attempt_kernel<M, MATH_STRICT>), grid, block, 0, s, d_y, d_sp, d_F, d_h, rtol, atol, path, closed, d_ynew, d_err_jump, d_broke, n);
         return true;
     });
     if (!known) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);

@@ -941,11 +941,74 @@ __global__ void selftest_rhs_kernel(const double* __restrict__ y, const void* sp
 #pragma unroll
     for (int c = 0; c < NEQ; ++c) yy[c] = y[(size_t)i * NEQ + c];
     bool b = false;
-    if (fast_path == 2) b = Model::template rhs_norain<MATH>(P, FV, yy, d);
+    if (fast_path == 3) {
+        if constexpr (Model::HAS_NORAINPATH && Model::NORAIN_LINEAR > 0 && MATH == MATH_FAST) b = Model::template rhs_wetu<MATH>(P, FV, yy, d);
+        else Model::template rhs<MATH>(P, FV, yy, d);
+    }
+    else if (fast_path == 2) b = Model::template rhs_norain<MATH>(P, FV, yy, d);
     else if (fast_path) b = Model::template rhs_fast<MATH>(P, FV, yy, d);
     else Model::template rhs<MATH>(P, FV, yy, d);
 #pragma unroll
     for (int c = 0; c < NEQ; ++c) out[(size_t)i * NEQ + c] = d[c];
+    if (broke) broke[i] = b ? 1 : 0;
+}
+
+// ---- single attempts (hlm_selftest_attempt): one rk45_step (rk45_step_dense.cuh:33-145) per (state, parameters,
+// forcing, h) on a chosen RHS path, from a cold start (k0 evaluated inside) -- the unit under the integrator's loop.
+// path = HLM_ATTEMPT_SELECT_NODENSE (-1): what a launch WITHOUT dense output executes per attempt
+//        (attempt_on_cheapest_path<.., NEED_K = false>: per-lane choice of the unsaturated path in closed form, dry /
+//        general otherwise -- the headline kernel's attempt);
+//        HLM_ATTEMPT_SELECT_DENSE (-2): what the dense kernels execute (NEED_K = true, wave-uniform choice, stage arithmetic);
+//        0..3 = PATH_GENERAL / PATH_DRY / PATH_NORAIN / PATH_WETU forced for every lane, `closed` = the linear stores in
+//        closed form (paths 2 and 3, FAST).  A forced path is valid where its precondition holds and `broke` is 0.
+// out: ynew[n][NEQ] = the 5th-order solution, en[n][2] = {scaled error norm, slope-jump norm |k0 - k1|_inf}.
+template <class Model, int MATH>
+__global__ void __launch_bounds__(WAVE) selftest_attempt_kernel(const double* __restrict__ y, const void* sp, const float* __restrict__ F,
+                                                                const double* __restrict__ hs, double rtol, double atol, int path, int closed,
+                                                                double* __restrict__ ynew, double* __restrict__ en, int* __restrict__ broke, int n)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    constexpr int NEQ = Model::N_EQ, NFA = Model::NF > 0 ? Model::NF : 1;
+    const typename Model::Local P = Model::template load<MATH>(sp, i);
+    double held[NFA];
+#pragma unroll
+    for (int j = 0; j < NFA; ++j) held[j] = j < 2 ? (double)F[2 * i + j] : 0.0;
+    const typename Model::Forc FV = Model::prep_forcing(P, held);
+    Rk45Args A{};
+    A.rtol = rtol;
+    A.atol = atol;
+    double yy[NEQ], k0[NEQ], k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
+#pragma unroll
+    for (int c = 0; c < NEQ; ++c) yy[c] = y[(size_t)i * NEQ + c];
+    const double h = hs[i];
+    double err = 0.0, jump = 0.0;
+    bool have_k0 = false, b = false;
+    constexpr bool CHEAP = Model::HAS_NORAINPATH && Model::HAS_FASTPATH;
+    constexpr bool CLOSABLE = CHEAP && Model::NORAIN_LINEAR > 0 && MATH == MATH_FAST;
+    if (path == -1) attempt_on_cheapest_path<Model, MATH, false, false>(P, FV, A, yy, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+    else if (path == -2) attempt_on_cheapest_path<Model, MATH, false, true>(P, FV, A, yy, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+    else if (path == PATH_DRY && CHEAP) {
+        if constexpr (CHEAP) b = rk_attempt<Model, MATH, PATH_DRY, false>(P, FV, A, yy, h, false, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+    } else if (path == PATH_NORAIN && CHEAP) {
+        if constexpr (CLOSABLE) {
+            if (closed) b = rk_attempt<Model, MATH, PATH_NORAIN, false, true>(P, FV, A, yy, h, false, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        }
+        if constexpr (CHEAP) {
+            if (!(closed && CLOSABLE)) b = rk_attempt<Model, MATH, PATH_NORAIN, false>(P, FV, A, yy, h, false, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        }
+    } else if (path == PATH_WETU && CLOSABLE) {
+        if constexpr (CLOSABLE) {
+            if (closed) b = rk_attempt<Model, MATH, PATH_WETU, false, true>(P, FV, A, yy, h, false, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+            else b = rk_attempt<Model, MATH, PATH_WETU, false, false>(P, FV, A, yy, h, false, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        }
+    } else {
+        rk_attempt<Model, MATH, PATH_GENERAL, false>(P, FV, A, yy, h, false, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+    }
+#pragma unroll
+    for (int c = 0; c < NEQ; ++c) ynew[(size_t)i * NEQ + c] = yt[c];
+    en[(size_t)2 * i] = err;
+    en[(size_t)2 * i + 1] = jump;
     if (broke) broke[i] = b ? 1 : 0;
 }
 

@@ -22,6 +22,17 @@
 // all its waves included: 22.8 GB of HBM writes per headline launch, measured, and 3 % of its time.)  The awaited piece was drawn earlier (the queue is chunk-major), so it is finished or running on a
 // resident wave: the wait cannot deadlock, and with more tiles than resident waves it never waits at all.
 //
+// RUNS (round 4).  What the queue hands out is a RUN of consecutive pieces of a tile, not a single piece: the wave
+// that draws (run r, tile) integrates the pieces run_begin(r) .. run_begin(r + 1) - 1 of that tile one after the
+// other with the lane states in its registers -- the lanes still pause at every piece's end (that is what re-aligns
+// them in simulated time), but only the END of a run passes through the record in HBM.  Handing every piece over (round
+// 3) re-read the 136-byte parameter record and moved 76 bytes of lane state out and back in 31 times per hillslope:
+// 16.9 GB of HBM traffic per headline launch against 3.2 GB algorithmic.  What removes the launch's tail is the
+// granularity of its LAST items only, so the runs shrink towards the end of the window (QueueRuns: by default each
+// run takes half of what is left, down to a sixteenth of the window) -- and a launch with no more tiles than resident
+// waves has no tail to remove: ONE run, no hand-over at all, the pieces only re-align.  Same bits whatever the runs
+// (hlm_set_queue_runs, tests).
+//
 // Every wave reaches the end of the grid whatever happens: the wait is bounded by a wall-clock watchdog
 // (QUEUE_WAIT_LIMIT_TICKS of the 100 MHz real-time counter).  A wait that outlasts it -- a lost wave; never seen --
 // gives the tile up: its unfinished hillslopes come back flagged HLM_SYS_CAPPED with zero finals, the channel of
@@ -49,7 +60,20 @@ __device__ unsigned int* g_queue_marks = nullptr;
 #endif
 constexpr unsigned long long QUEUE_WAIT_LIMIT_TICKS = HLM_QUEUE_WAIT_LIMIT_TICKS;
 
-// queue[0]: next item; queue[1 + tile]: pieces of `tile` finished so far; queue[1 + ntiles]: abort word.  The resume record (A.resume, SoA as in
+// The runs of a launch (kernel argument): run r covers the pieces [begin(r), begin(r + 1)).
+constexpr int QUEUE_MAX_RUNS = 15;
+struct QueueRuns {
+    int nruns;
+    int uniform;                      // > 0: every run has this many pieces (the last one what is left); else begin_[]
+    int begin_[QUEUE_MAX_RUNS + 1];   // begin_[nruns] = the number of pieces
+    __host__ __device__ int begin(int r, int npieces) const
+    {
+        if (uniform > 0) { const long long b = (long long)r * uniform; return b < npieces ? (int)b : npieces; }
+        return begin_[r];
+    }
+};
+
+// queue[0]: next item; queue[1 + tile]: RUNS of `tile` finished so far; queue[1 + ntiles]: abort word.  The resume record (A.resume, SoA as in
 // the RESUMABLE kernels: y[N_EQ], t, h | reject_count, n_attempt, n_accept, next_q, status) carries the lanes.
 // device-coherent accesses to the lane states between the pieces (any wave of any XCD may continue a tile)
 __device__ __forceinline__ double coherent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -66,12 +90,12 @@ __global__ void queue_init_kernel(unsigned int* __restrict__ queue, unsigned int
 
 template <class Model, int MATH, bool FIXED>
 __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
-    rk45_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nchunk)
+    rk45_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nchunk, const QueueRuns R)
 {
     using namespace dp;
     constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
     const int lane = (int)threadIdx.x;
-    const unsigned ntiles = ((unsigned)A.ns + WAVE - 1u) / WAVE, nitems = ntiles * (unsigned)nchunk;
+    const unsigned ntiles = ((unsigned)A.ns + WAVE - 1u) / WAVE, nitems = ntiles * (unsigned)R.nruns;
     unsigned int* const done = queue + 1;
     int* const resume_i = reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns);
     const double tf = A.tf;
@@ -89,17 +113,18 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         HLM_QMARK(1, item);
         HLM_QMARK(2, 1);
         if (item >= nitems) break;
-        const unsigned c = item / ntiles, tile = item - c * ntiles;
+        const unsigned r = item / ntiles, tile = item - r * ntiles;   // run r of this tile:
+        const unsigned c_begin = (unsigned)R.begin((int)r, nchunk), c_end = (unsigned)R.begin((int)r + 1, nchunk);   // its pieces
         const int sys = (int)(tile * WAVE) + lane;
         bool lost = false;  // the watchdog fired: this tile is given up
-        if (c > 0) {
-            // the previous piece of this tile: finished long ago when there are more tiles than resident waves
+        if (r > 0) {
+            // the previous run of this tile: finished long ago when there are more tiles than resident waves
             auto finished = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
-            if (finished() < c) {
+            if (finished() < r) {
                 const unsigned long long since = wall_clock64();
                 HLM_QMARK(2, 2);
                 [[maybe_unused]] unsigned polls = 0;
-                while (finished() < c) {
+                while (finished() < r) {
                     __builtin_amdgcn_s_sleep(16);
                     HLM_QMARK(4, ++polls);
                     const unsigned aborted = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -114,9 +139,6 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
             HLM_QMARK(2, 3);
             asm volatile("" ::: "memory");  // (the record is loaded after the counter, also as the compiler sees it)
         }
-        // lanes pause the first time t reaches the end of their piece (the last piece runs to tf)
-        const double t_end = c + 1u < (unsigned)nchunk ? fmin(tf, A.t0 + (double)(c + 1u) * piece) : tf;
-
         if (sys < A.ns && lost) {
             // (watchdog) whatever this hillslope's record says, nobody continues it: flagged, zero finals
             if (coherent_load(&resume_i[(size_t)4 * A.ns + sys]) == SYS_PAUSED) {
@@ -130,7 +152,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         } else if (sys < A.ns) {
             int status = HLM_SYS_OK;
             bool runs = true;
-            if (c > 0) {
+            if (r > 0) {
                 status = coherent_load(&resume_i[(size_t)4 * A.ns + sys]);
                 runs = status == SYS_PAUSED;  // else: finished or flagged in an earlier piece, its outputs were written then
                 if (runs) status = HLM_SYS_OK;
@@ -142,7 +164,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 double h = FIXED ? A.fixed_step : A.h0;
                 int reject_count = 0;
                 uint32_t n_attempt = 0, n_accept = 0;
-                if (c == 0) {
+                if (r == 0) {
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
                 } else {
@@ -160,47 +182,53 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 bool have_k0 = false;  // k0 = rhs(t, y, F) is a pure function: recomputed, it has the bits of the carried one
                 double k0[NEQ];
 
-                // ---- the loop of rk45_multi_kernel --------------------------------------------------------
-                while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
-                    if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
-                    if (held.refresh(A, P, t, FV)) have_k0 = false;
-                    ++n_attempt;
-                    double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
-                    [[maybe_unused]] double err = 0.0, jump = 0.0;
-                    attempt_on_cheapest_path<Model, MATH, FIXED, false>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
-                    [[maybe_unused]] double fac = 1.0;
-                    if constexpr (!FIXED) {
-                        fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);  // rk45_kernel.cu:151,156
-                        if (err <= 1.0) {
-                            reject_count = 0;
-                            if (jump > SLOPE_JUMP_THRESH) {  // rk45_kernel.cu:132-136
-                                h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
+                // ---- the loop of rk45_multi_kernel, piece by piece --------------------------------------------
+                // lanes pause the first time t reaches the end of their piece (the last piece runs to tf) and go on
+                // together with the next piece of the run: the protocol of a hand-over, without the hand-over
+                double t_end = tf;
+                for (unsigned c = c_begin; c < c_end; ++c) {
+                    t_end = c + 1u < (unsigned)nchunk ? fmin(tf, A.t0 + (double)(c + 1u) * piece) : tf;
+                    while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
+                        if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
+                        if (held.refresh(A, P, t, FV)) have_k0 = false;
+                        ++n_attempt;
+                        double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
+                        [[maybe_unused]] double err = 0.0, jump = 0.0;
+                        attempt_on_cheapest_path<Model, MATH, FIXED, false>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                        [[maybe_unused]] double fac = 1.0;
+                        if constexpr (!FIXED) {
+                            fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);  // rk45_kernel.cu:151,156
+                            if (err <= 1.0) {
+                                reject_count = 0;
+                                if (jump > SLOPE_JUMP_THRESH) {  // rk45_kernel.cu:132-136
+                                    h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
+                                    continue;
+                                }
+                            } else {  // rk45_kernel.cu:153-163
+                                ++reject_count;
+                                double f = fmin(fac, 1.0);
+                                f = fmin(fmax(f, A.min_scale), A.max_scale);
+                                h *= f;
+                                if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) status = HLM_SYS_STIFF;
                                 continue;
                             }
-                        } else {  // rk45_kernel.cu:153-163
-                            ++reject_count;
-                            double f = fmin(fac, 1.0);
-                            f = fmin(fmax(f, A.min_scale), A.max_scale);
-                            h *= f;
-                            if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) status = HLM_SYS_STIFF;
-                            continue;
                         }
-                    }
 #pragma unroll
-                    for (int i = 0; i < NEQ; ++i) {
-                        y[i] = yt[i];
-                        k0[i] = k6[i];  // = rhs(t1, y_new, F): next attempt's k0 unless the forcing moves
+                        for (int i = 0; i < NEQ; ++i) {
+                            y[i] = yt[i];
+                            k0[i] = k6[i];  // = rhs(t1, y_new, F): next attempt's k0 unless the forcing moves
+                        }
+                        t += h;
+                        ++n_accept;
+                        if constexpr (FIXED) h = A.fixed_step;
+                        else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
                     }
-                    t += h;
-                    ++n_accept;
-                    if constexpr (FIXED) h = A.fixed_step;
-                    else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
                 }
 
                 HLM_QMARK(2, 4);
                 if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
                 if (status == HLM_SYS_OK && t < tf) {
-                    // paused at the end of its piece: the next piece continues exactly here
+                    // paused at the end of its run's last piece: the next run continues exactly here
                     coherent_store(&resume_i[(size_t)4 * A.ns + sys], SYS_PAUSED);
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) coherent_store(&A.resume[(size_t)i * A.ns + sys], y[i]);
@@ -221,11 +249,11 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 }
             }
         }
-        // publish the piece: the state record's stores complete (acknowledged at device scope), then the tile's counter
+        // publish the run: the state record's stores complete (acknowledged at device scope), then the tile's counter
         HLM_QMARK(2, 5);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         HLM_QMARK(2, 6);
-        __hip_atomic_store(&done[tile], c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
+        __hip_atomic_store(&done[tile], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
         HLM_QMARK(2, 7);
     }
 }

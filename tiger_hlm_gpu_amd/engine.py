@@ -15,7 +15,7 @@ from .models import Parameters, SP_DTYPE
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
                  math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
-                 dense_tiled=2, lane_refill=False, dense_states=None, time_pieces=None):
+                 dense_tiled=2, lane_refill=False, dense_states=None, time_pieces=None, queue_run_pieces=0):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -29,6 +29,9 @@ class ShardEngine:
         # instead of one wave per tile; None = the host API's automatic rule (from 4 096 hillslopes on, one piece per
         # twelve simulated hours, at most 32, none below 8)
         self.time_pieces = time_pieces
+        # hlm_device_job.queue_run_pieces: 0 = automatic runs of pieces per queue item, n = runs of n pieces (1 = every
+        # piece handed over through HBM)
+        self.queue_run_pieces = int(queue_run_pieces)
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
         self.ns = y0.shape[0]
         dev = self.device
@@ -104,6 +107,7 @@ class ShardEngine:
         j.lane_refill = self.lane_refill
         tp = self.time_pieces
         j.time_pieces = -1 if tp is None else int(tp)
+        j.queue_run_pieces = self.queue_run_pieces
         if self.dense is not None or self.nq:
             j.time_pieces = 0
         return j

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """After `make -C tiger_hlm_gpu_amd/csrc asm`: every instance of rk45_queue_kernel must keep the loop over queue items
-wave-uniform.  A compiler that threads lanes != 0 past the draw (seen once, with `if (lane == 0)` around the atomics)
-shows up as a third loop level and as an exec-masked back-edge of the item loop; both are checked here from the
-assembler's own loop comments.  usage: tools/check_queue_isa.py [build/...gfx950.s]"""
+wave-uniform -- and, since round 4, the loop over the pieces of a run inside it (item loop -> piece loop -> attempt
+loop: three levels).  A compiler that threads lanes != 0 past the draw (seen once, with `if (lane == 0)` around the
+atomics) shows up as one loop level more and as an exec-masked back-edge of the item loop; both are checked here from
+the assembler's own loop comments, and the piece loop's back-edges must be scalar branches too.
+usage: tools/check_queue_isa.py [build/...gfx950.s]"""
 import glob
 import os
 import re
@@ -23,7 +25,7 @@ while i < len(text):
         j += 1
     body = text[i:j]
     seen += 1
-    depth3 = [k for k, ln in enumerate(body) if re.search(r"Depth[= ]3", ln)]
+    depth3 = [k for k, ln in enumerate(body) if re.search(r"Depth[= ]4", ln)]   # (one level more than the three the source has)
     atom = [k for k, ln in enumerate(body) if "global_atomic_add" in ln]
     # the item loop: the Depth=1 header; its latch must be a scalar or unconditional branch back to the header
     hdr = None
@@ -33,8 +35,20 @@ while i < len(text):
             break
     back = [ln.strip() for ln in body if hdr and re.search(r"s_c?branch\w*\s+%s$" % re.escape(hdr), ln.strip())]
     masked = [b for b in back if "execz" in b or "execnz" in b or "vcc" in b]
-    ok = not depth3 and len(atom) == 1 and hdr is not None and back and not masked
-    print(("ok  " if ok else "BAD ") + name, "loops<=2" if not depth3 else "DEPTH 3", f"draws={len(atom)}", "item-loop latch:", back)
+    # the piece loop: the Depth=2 header that has an inner loop (not an "Inner Loop Header"); scalar back-edges only
+    phdr = []
+    for k, ln in enumerate(body):
+        if "=>  This Loop Header: Depth=2" in ln:   # its label: on the same line or a comment line or two above
+            for u in range(k, max(k - 4, -1), -1):
+                mm = re.match(r"^(\.LBB\d+_\d+):", body[u])
+                if mm:
+                    phdr.append(mm.group(1))
+                    break
+    pback = [ln.strip() for ln in body for h in phdr if re.search(r"s_c?branch\w*\s+%s$" % re.escape(h), ln.strip())]
+    pmasked = [b for b in pback if "execz" in b or "execnz" in b or "vcc" in b]
+    ok = not depth3 and len(atom) == 1 and hdr is not None and back and not masked and len(phdr) == 1 and pback and not pmasked
+    print(("ok  " if ok else "BAD ") + name, "loops<=3" if not depth3 else "DEPTH 4", f"draws={len(atom)}", "item-loop latch:", back,
+          "piece-loop latch:", pback)
     if not ok:
         bad.append(name)
     i = j
