@@ -154,6 +154,35 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
     return eng, total
 
 
+def _issue_profile(per_gpu_key):
+    """Instruction-level PMC figures of the launch with this per-GPU key from the committed rocprofv3 passes
+    (profiles/r*_pmc_issue.json, tools/pmc_issue.sh; the newest round that has the key) -- not measured in this run:
+    (dict, source string) or (None, None)."""
+    import glob
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_issue.json")), reverse=True):
+        try:
+            prof = json.load(open(path))
+        except Exception:
+            continue
+        for name, w in prof.get("workloads", {}).items():
+            if w.get("bench_line_under_pmc", {}).get("per_gpu_key") == per_gpu_key and "derived" in w:
+                d = w["derived"]
+                keep = {k: d[k] for k in ("issue_busy", "valu_insts_per_wave_attempt", "salu_insts_per_wave_attempt",
+                                          "active_lanes_per_valu_inst", "wave_time_split") if k in d}
+                keep["kernel_ms_under_pmc"] = w["bench_line_under_pmc"].get("kernel_ms")
+                return keep, ("not measured in this run: rocprofv3 --pmc passes committed as profiles/%s (workload '%s'; "
+                              "issue_busy = SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x shader cycles), a wave-attempt = 64 "
+                              "lane-attempts)" % (os.path.basename(path), name))
+    return None, None
+
+
+def _issue_fields(per_gpu_key):
+    prof, src = _issue_profile(per_gpu_key)
+    if prof is None:
+        return {"issue_busy": None, "valu_insts_per_wave_attempt": None, "issue_source": None}
+    return {**prof, "issue_source": src}
+
+
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
     extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
@@ -777,8 +806,10 @@ def main():
         "roofline_valu_fp64": {"bound": "valu_fp64", "achieved": valu_tf, "peak": PEAK_FP64_VALU_TFLOPS,
                                "unit": "TFLOP/s", "frac": valu_tf / PEAK_FP64_VALU_TFLOPS,
                                "algorithmic_flops_per_step": F_STEP_204,
-                               "note": "606 flop/step is the reference algorithm's count (SURVEY 8d): the kernel executes fewer -- "
-                                       "FSAL reuse, cheap RHS paths between storms, two stores in closed form -- for the same steps"},
+                               "note": "frac prices every attempt at the REFERENCE algorithm's 606 flop (SURVEY 8d); the kernel executes fewer "
+                                       "-- FSAL reuse, cheap RHS forms between storms, two stores in closed form -- for the same steps: "
+                                       "issue_busy and valu_insts_per_wave_attempt say what the SIMDs actually did",
+                               **_issue_fields(_per_gpu_key(args, nq, eng.ns))},
         "attempts_per_pass": attempts_all, "attempts_per_hillslope": attempts_all / total,
         "flagged_fraction": float(flagged.item()) / total, "kernel_ms_each": kernel_ms,
     }
@@ -817,6 +848,11 @@ def main():
                    "attempts_per_hillslope": av / engv.ns,
                    "flagged_fraction": float((engv.stiff != 0).sum().item()) / engv.ns,
                    "valu_fp64_frac": av * F_STEP_204 / (kms[0] * 1e-3) / 1e12 / PEAK_FP64_VALU_TFLOPS}
+            if math == args.math:
+                import copy
+                va = copy.copy(args)
+                va.wet_surface = wet
+                res.update(_issue_fields(_per_gpu_key(va, 0, engv.ns)))
             del engv
             return res
         for name, wet, math in (("variant_wet_surface", True, args.math),
@@ -863,6 +899,20 @@ def main():
         def _cold():
             e, _ = build_engine(args, rank, world, wet=False, tmin=-5.0)
             res = {"workload": f"C3 as SURVEY 8d writes it: Model 204, {e.ns} hillslopes, {args.days} days, T in [-5, 15], math={args.math}"}
+            # the automatic launch shape first (runs of pieces shrinking towards the end of the window) ...
+            e.integrate()
+            torch.cuda.synchronize()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            e.integrate()
+            b.record()
+            torch.cuda.synchronize()
+            res["rk45_default_launch_shape"] = {"ms": a.elapsed_time(b), "time_pieces": H.api.time_pieces_for(e.job()), "queue_run_pieces": "automatic"}
+            # ... then what this workload wants (hlm_device_job.queue_run_pieces = 1, every piece handed over): hillslopes
+            # dropping out with stiff flags make a few tiles cost several times the mean, and long runs start late tiles late
+            e.queue_run_pieces = 1
+            res["launch_shape"] = {"time_pieces": H.api.time_pieces_for(e.job()), "queue_run_pieces": 1,
+                                   "note": "same bits; all rows below use it (tools/queue_prof_probe.py, profiles/r04_queue_runs_probe.txt)"}
             for tag, radau in (("rk45", False), ("rk45_plus_radau", True), ("rk45_plus_radau_continue", "continue")):
                 e.integrate(radau=radau)
                 torch.cuda.synchronize()
@@ -891,8 +941,10 @@ def main():
                 res[tag]["implicit_attempts"] = res[tag]["attempts"] - res["rk45"]["attempts"]
             res["rk45_plus_radau_continue"]["note"] = ("build option: every flagged hillslope continues from the state RK45 reached "
                                                        "(the reference's kernel, and rk45_plus_radau, restart it at t0)")
-            res["lane_utilisation_rk45_source"] = ("not measured in this run: 40.6 of 64 lanes active per VALU instruction in "
-                                                   "profiles/r02_cold_pmc.json (rocprofv3 SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU, round 2)")
+            import copy
+            ca = copy.copy(args)
+            ca.tmin = -5.0
+            res["rk45"].update(_issue_fields(_per_gpu_key(ca, 0, e.ns)))   # active lanes per VALU instruction of the RK45 pass etc.
             return res
         out["variant_survey_c3_cold_cells"] = _optional(_cold)
         torch.cuda.empty_cache()

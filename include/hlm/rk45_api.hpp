@@ -257,6 +257,47 @@ FinalType run_rk45_streamed(const std::vector<double>& h_y0, double t0, double t
     return h_final;
 }
 
+// ---- one process, the GPUs of a node ----------------------------------------------------------------------------
+// The reference splits the parameter rows over MPI worker ranks (main.cpp:258-309, 357-368) and each rank writes its
+// own files; here one call takes the whole domain as host arrays, splits it by the same rule over `num_shards` shards
+// on `devices`, and gathers final states, flags and step counters to devices[0] over RCCL (gather_rccl) or by one copy
+// per device (hlm_run_rk45_sharded).  No dense output.  h_sp: the whole domain's SpatialParams (host); tables[j]:
+// host float [nT[j]][ld]; col: host column index per hillslope (per-cell tables) or nullptr (per-stream, ld == ns).
+struct ShardedStats : hlm_sharded_stats {};
+template <class Model>
+FinalType run_rk45_sharded(const std::vector<double>& h_y0, double t0, double tf, const typename Model::SP_TYPE* h_sp,
+                           const std::vector<const float*>& tables, const std::vector<double>& dt_hours,
+                           const std::vector<size_t>& nT, long long ld, const int32_t* col, int num_shards,
+                           const std::vector<int>& devices, bool gather_rccl, ShardedStats* stats = nullptr)
+{
+    constexpr int N_EQ = Model::N_EQ;
+    if (dt_hours.size() != nT.size() || tables.size() != nT.size() || nT.size() > HLM_MAX_FORCINGS)
+        throw std::runtime_error("run_rk45_sharded: forcing tables / dt / nT size mismatch");
+    hlm_sharded_run r{};
+    r.uid = Model::UID;
+    r.num_systems = int(h_y0.size() / N_EQ);
+    r.t0 = t0;
+    r.tf = tf;
+    r.h_y0 = h_y0.data();
+    r.h_sp = h_sp;
+    r.h_forc_tables = tables.empty() ? nullptr : tables.data();
+    for (size_t k = 0; k < nT.size(); ++k) { r.forc_dt_hours[k] = dt_hours[k]; r.forc_nT[k] = nT[k]; }
+    r.nforc = int(nT.size());
+    r.forc_ld = ld;
+    r.h_forc_col = col;
+    FinalType h_final((size_t)r.num_systems * N_EQ);
+    RunInfo info;
+    info.stiff.resize(r.num_systems);
+    info.n_attempt.resize(r.num_systems);
+    info.n_accept.resize(r.num_systems);
+    detail::check(hlm_run_rk45_sharded(&r, num_shards, devices.empty() ? nullptr : devices.data(), devices.empty() ? 1 : int(devices.size()),
+                                       gather_rccl ? HLM_GATHER_RCCL : HLM_GATHER_HOST, h_final.data(), info.stiff.data(),
+                                       info.n_attempt.data(), info.n_accept.data(), stats),
+                  "run_rk45_sharded");
+    detail::last_info() = std::move(info);
+    return h_final;
+}
+
 // flags / step counters of the most recent retrieve_and_free on the calling thread
 inline RunInfo last_run_info() { return detail::last_info(); }
 

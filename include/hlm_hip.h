@@ -277,10 +277,13 @@ typedef struct hlm_device_job {
     int time_pieces;
     /* (ABI 4) What the queue hands out is a RUN of consecutive pieces of a tile; only the end of a run passes the
      * lane states through HBM to whichever wave draws the tile's next run, inside a run they stay in registers (the
-     * lanes still pause at every piece's end: that re-aligns them in simulated time).  0 = automatic: one run (no
-     * hand-over at all) when the launch has no more tiles than the device holds waves, else each run takes half of
-     * what is left of the window, down to a sixteenth of it -- the granularity the end of the launch needs.  n >= 1:
-     * runs of n pieces each (1 = every piece handed over, round 3's protocol).  Same results bit for bit. */
+     * lanes still pause at every piece's end: that re-aligns them in simulated time).  0 = automatic: with more tiles
+     * than the device holds waves each run takes half of what is left of the window, down to a sixteenth of it -- the
+     * granularity the end of the launch needs, a third of the HBM traffic; smaller launches hand every piece over (the
+     * queue then evens out how the waves sit on the SIMDs).  n >= 1: runs of n pieces each (1 = every piece handed
+     * over, round 3's protocol: the better choice when a few tiles cost several times the mean -- hillslopes dropping
+     * out with stiff flags --, because long runs start the tiles late in the queue order late).  Same results bit for
+     * bit. */
     int queue_run_pieces;
 } hlm_device_job;
 
@@ -389,6 +392,59 @@ int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void*
  * d_broke[n] (nullable). */
 int hlm_selftest_rhs(int uid, int math_mode, int fast_path, const double* d_y, const void* d_sp,
                      const float* d_F, double* d_out, int32_t* d_broke, int n, void* hip_stream);
+
+/* ---- one process, the GPUs of a node (ABI 4) -----------------------------------------------------------------
+ * Replaces the reference's rank-0 split over worker ranks (main.cpp:258-309: contiguous chunks, base = ns / G, the
+ * first ns % G of them one hillslope longer; 2 x MPI_Send / MPI_Recv per worker, :300-303, :357-368) by a single
+ * process driving `num_shards` shards on `num_devices` HIP devices (shard s on devices[s % num_devices]; one HIP
+ * stream per device, shards of a device one after the other), and adds what the reference does not have: an
+ * end-of-run GATHER of the results -- final states, stiff flags and both step counters, 52 bytes per hillslope for
+ * N_EQ = 5 -- to devices[0] over RCCL (one group of ncclSend / ncclRecv pairs: xGMI point-to-point between the GPUs
+ * of a node), from where one copy per array delivers them to the host arrays in hillslope order.
+ * Everything is a HOST buffer of the whole domain; solver parameters, math mode, attempt cap and launch shape are the
+ * registered ones (hlm_set_model_parameters ...); no dense output (each GPU streams its own dense rows: the host API
+ * above, per device).  Forcings: nforc tables h_forc_tables[j] = float [forc_nT[j]][forc_ld] and either
+ * h_forc_col[ns] (column of each hillslope in the tables: compact per-grid-cell tables, every device gets the tables
+ * and its slice of the index) or NULL with forc_ld == num_systems (the reference's per-stream expansion,
+ * main.cpp:527-549: every device gets its columns). */
+typedef struct hlm_sharded_run {
+    int uid;
+    int num_systems;
+    double t0, tf;
+    const double* h_y0;               /* [ns][N_EQ] */
+    const void* h_sp;                 /* [ns] hlm_spatial_params (136 B each); NULL for a model without parameters */
+    const float* const* h_forc_tables;
+    double forc_dt_hours[HLM_MAX_FORCINGS];
+    uint64_t forc_nT[HLM_MAX_FORCINGS];
+    int nforc;
+    int64_t forc_ld;
+    const int32_t* h_forc_col;
+} hlm_sharded_run;
+
+#define HLM_GATHER_HOST 0 /* every device copies its shards' results to the host itself (no exchange between GPUs) */
+#define HLM_GATHER_RCCL 1 /* RCCL send / recv to devices[0], one copy per array from there */
+
+typedef struct hlm_sharded_stats {
+    double upload_ms;     /* host clock: inputs of all shards enqueued / copied */
+    double integrate_ms;  /* HIP events around each device's launches: the slowest device */
+    double wall_to_integrated_ms; /* host clock: first launch -> all devices finished (includes the communicator's start) */
+    double gather_ms;     /* HLM_GATHER_RCCL: the send / recv group on the root's stream (HIP events); else 0 */
+    double download_ms;   /* host clock: results in the host arrays */
+    double comm_init_ms;  /* HLM_GATHER_RCCL: getting the communicator, beside the running kernels (host clock; ~1 s the
+                           * first time RCCL comes up in a process, ~0 afterwards: one communicator per device list is kept) */
+    uint64_t gather_bytes; /* bytes that crossed the communicator (incl. the root's own shards) */
+    int rccl_version;     /* ncclGetVersion, 0 without RCCL */
+    int num_shards, num_devices;
+} hlm_sharded_stats;
+
+/* devices == NULL: devices 0 .. num_devices - 1.  The devices must be distinct.  num_shards >= 1 (more shards than
+ * devices rehearses a larger node's split on a smaller one).  h_stiff / h_n_attempt / h_n_accept / stats are optional.
+ * Results are bit-identical to hlm_run_rk45 of the whole domain on one device, whatever the split. */
+int hlm_run_rk45_sharded(const hlm_sharded_run* run, int num_shards, const int* devices, int num_devices,
+                         int gather_mode, double* h_y_final, int32_t* h_stiff, uint32_t* h_n_attempt,
+                         uint32_t* h_n_accept, hlm_sharded_stats* stats);
+/* The reference's split rule (main.cpp:275-307 with G shards): first hillslope and length of shard s. */
+int hlm_shard_bounds(int num_systems, int num_shards, int shard, int* start, int* count);
 
 /* One Dormand-Prince attempt (the reference's rk45_step, solver/rk45_step_dense.cuh:33-145, preceded by its
  * k0 = rhs(t, y, F), rk45_kernel.cu:114) per (state d_y[n][N_EQ], parameters d_sp[n], forcing pair d_F[n][2], step

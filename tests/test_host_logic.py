@@ -19,7 +19,7 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 45
+    assert len(names) == 47
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
@@ -36,7 +36,8 @@ def test_struct_layouts_match_header(hlm, tmp_path):
     assert hlm.SP_DTYPE.itemsize == 136  # parameters_loader.hpp:19-37
     assert [n for n in hlm.SP_DTYPE.names][:4] == ["stream", "next_stream", "c1", "infil"]
     structs = {"hlm_gpu_buffers": hlm._lib.GpuBuffers, "hlm_device_job": hlm._lib.DeviceJob,
-               "hlm_stream_stats": hlm._lib.StreamStats}
+               "hlm_stream_stats": hlm._lib.StreamStats, "hlm_sharded_run": hlm._lib.ShardedRun,
+               "hlm_sharded_stats": hlm._lib.ShardedStats}
     lines = ["#include <stdio.h>", "#include <stddef.h>", '#include "hlm_hip.h"', "int main(void) {",
              '  printf("abi %d\\n", HLM_ABI_VERSION);']
     for cname, ct in structs.items():
@@ -90,6 +91,45 @@ def test_compute_fails_loudly_without_device(hlm):
     from tiger_hlm_gpu_amd.engine import ShardEngine
     with pytest.raises(RuntimeError):
         ShardEngine(hlm.DummyModel, np.ones((1, 5)), 0.0, 1.0)
+
+
+def test_shard_split_rule_and_sharded_run_validation(hlm):
+    """hlm_shard_bounds = the reference's rank-0 split (main.cpp:275-307: base = ns / G, the first ns % G shards one
+    hillslope longer) = tiger_hlm_gpu_amd.shard.shard_bounds, and the shards tile [0, ns) in order; the argument checks
+    of hlm_run_rk45_sharded come before any device is touched, and without a device the call fails loudly."""
+    from tiger_hlm_gpu_amd import shard
+    api = hlm.api
+    for ns, G in ((10, 3), (1_000_000, 8), (4_000_000, 8), (7, 8), (0, 2), (64, 1), (1_000_001, 7)):
+        nxt = 0
+        for s in range(G):
+            assert api.shard_bounds(ns, G, s) == shard.shard_bounds(ns, G, s)
+            a, n = api.shard_bounds(ns, G, s)
+            assert a == nxt
+            nxt += n
+        assert nxt == ns
+    with pytest.raises(hlm.HlmError):
+        api.shard_bounds(10, 0, 0)
+    with pytest.raises(hlm.HlmError):
+        api.shard_bounds(10, 2, 2)
+    y0 = np.ones((8, 5))
+    for kw in (dict(num_shards=0), dict(num_devices=0), dict(num_shards=-1), dict(gather="host", num_devices=-3)):
+        with pytest.raises(hlm.HlmError) as e:
+            api.run_rk45_sharded(hlm.DummyModel, y0, 0.0, 1.0, **kw)
+        assert e.value.code == 1, kw
+    with pytest.raises(hlm.HlmError) as e:   # Model 204 without its parameter records
+        api.run_rk45_sharded(hlm.Model204, y0, 0.0, 1.0)
+    assert e.value.code == 1 and "h_sp" in str(e.value)
+    sp = np.zeros(8, dtype=hlm.SP_DTYPE)
+    with pytest.raises(hlm.HlmError) as e:   # per-stream tables must have one column per hillslope
+        api.run_rk45_sharded(hlm.Model204, y0, 0.0, 1.0, sp=sp, tables=[np.zeros((4, 5), np.float32)], dt_hours=[1.0])
+    assert e.value.code == 1 and "forc_ld" in str(e.value)
+    with pytest.raises(hlm.HlmError) as e:   # NULL run
+        hlm._lib.check(hlm._lib.lib().hlm_run_rk45_sharded(None, 1, None, 1, 1, None, None, None, None, None))
+    assert e.value.code == 1
+    if api.device_count() == 0:
+        with pytest.raises(hlm.HlmError) as e:
+            api.run_rk45_sharded(hlm.DummyModel, y0, 0.0, 1.0, num_shards=2)
+        assert e.value.code in (3, 4)
 
 
 def test_product_never_imports_the_oracle():

@@ -1,0 +1,109 @@
+"""hlm_run_rk45_sharded: one process, the hillslopes split by the reference's rule over several shards / devices, the
+end-of-run gather over RCCL (csrc/hlm_gather_rccl.h) -- on the one-GPU box: a communicator of one rank, every shard's
+results sent to and received by that rank through ncclSend / ncclRecv (the grouped pairs a node's 8 GPUs would use), and
+more shards than devices to rehearse the split.  Reference: src/main.cpp:258-309, 357-368 (rank-0 split over MPI; no
+gather exists there).  Results must be bit-identical to the whole domain integrated as one launch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu(hlm):
+    import torch
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    return hlm
+
+
+def _whole(H, model, y0, tf, sp, forcing, per_cell):
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    eng = ShardEngine(model, y0, 0.0, tf, sp=sp)
+    if forcing is not None:
+        pr, t2m, cells, dt, nT = forcing
+        if per_cell:
+            eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+        else:
+            eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    eng.integrate()
+    return eng.results()
+
+
+@pytest.mark.parametrize("layout", ["per-cell", "per-stream"])
+def test_sharded_run_rccl_gather_equals_the_whole_domain_bitwise(gpu, layout):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 20_011, 3      # ragged: the shards differ in length and none is a multiple of 64
+    sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns)
+    y0[::3, 2] = 0.01
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)   # some hillslopes get flagged: the flags travel too
+    tf = days * 1440.0
+    per_cell = layout == "per-cell"
+    ref = _whole(H, H.Model204, y0, tf, sp, (pr, t2m, cells, dt, nT), per_cell)
+    assert 0 < (ref["stiff"] == 1).sum() < ns
+    tables = (pr, t2m) if per_cell else (pr[:, cells], t2m[:, cells])
+    for shards, gather in ((1, "rccl"), (3, "rccl"), (8, "rccl"), (8, "host")):
+        got, st = H.api.run_rk45_sharded(H.Model204, y0, 0.0, tf, sp=sp, tables=tables, dt_hours=dt,
+                                         cells=cells if per_cell else None, num_shards=shards, num_devices=1, gather=gather)
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(got[k], ref[k]), (layout, shards, gather, k)
+        assert st["num_shards"] == shards and st["num_devices"] == 1
+        if gather == "rccl":
+            assert st["gather_bytes"] == 52 * ns and st["rccl_version"] > 0 and st["gather_ms"] > 0.0
+        else:
+            assert st["gather_bytes"] == 0 and st["rccl_version"] == 0
+        print(f"{layout}, {shards} shard(s), gather {gather}: upload {st['upload_ms']:.1f} ms, integrate {st['integrate_ms']:.1f} ms, "
+              f"communicator {st['comm_init_ms']:.1f} ms, gather {st['gather_ms']:.3f} ms ({st['gather_bytes']} B), download {st['download_ms']:.2f} ms, "
+              f"RCCL {st['rccl_version']}")
+
+
+def test_sharded_run_models_without_parameters_or_forcings_and_bad_devices(gpu):
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    ns = 1000
+    y0 = synth.dummy_y0(0, ns)
+    ref = _whole(H, H.DummyModel, y0, 50.0, None, None, False)
+    got, st = H.api.run_rk45_sharded(H.DummyModel, y0, 0.0, 50.0, num_shards=5, num_devices=1)
+    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(got[k], ref[k]), k
+    # more shards than hillslopes: empty shards are skipped
+    got, _ = H.api.run_rk45_sharded(H.DummyModel, y0[:3], 0.0, 50.0, num_shards=8, num_devices=1)
+    assert np.array_equal(got["y_final"], ref["y_final"][:3])
+    with pytest.raises(H.HlmError) as e:   # a device the box does not have
+        H.api.run_rk45_sharded(H.DummyModel, y0, 0.0, 50.0, num_shards=2, devices=[0, 63])
+    assert e.value.code == 1
+    with pytest.raises(H.HlmError) as e:   # one device listed twice: RCCL wants distinct devices
+        H.api.run_rk45_sharded(H.DummyModel, y0, 0.0, 50.0, num_shards=2, devices=[0, 0])
+    assert e.value.code == 1
+
+
+def test_cpp_driver_gather_rccl_equals_host_threads(gpu, golden, tmp_path):
+    """rk45_solver --gpus N --gather rccl: the driver's single-thread multi-device route (rk45_api::run_rk45_sharded,
+    the RCCL gather inside the library) writes the same final.csv as the one-thread-per-shard route and as one GPU;
+    its result line names the communicator it used.  Dense output is not gathered: asking for it is a usage error."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "rk45_solver")
+    assert os.path.exists(exe), "tools/rk45_solver not built (python -c 'import __graft_entry__ as g; g.build()')"
+    base = [exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "2880", "--nq", "0", "--rain", "0.0004", "--temp", "3.5"]
+    outs, lines = {}, {}
+    for tag, extra in (("one", []), ("threads3", ["--gpus", "3", "--oversubscribe"]),
+                       ("rccl3", ["--gpus", "3", "--oversubscribe", "--gather", "rccl"]),
+                       ("host4", ["--gpus", "4", "--oversubscribe", "--gather", "host"]),
+                       ("rccl1-expanded", ["--gather", "rccl", "--expand-forcings"])):
+        f = str(tmp_path / f"final_{tag}.csv")
+        p = subprocess.run(base + ["--out-final", f, "--out-dense", str(tmp_path / f"dense_{tag}.csv")] + extra, check=True, timeout=300,
+                           capture_output=True, text=True)
+        outs[tag] = open(f).read()
+        lines[tag] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert len(outs["one"].splitlines()) == 11
+    assert all(o == outs["one"] for o in outs.values()), {k: v == outs["one"] for k, v in outs.items()}
+    g = lines["rccl3"]["gather"]
+    assert g["mode"] == "rccl" and g["devices"] == 1 and g["shards"] == 3 and g["gather_bytes"] == 52 * 10 and g["rccl_version"] > 0
+    assert lines["threads3"]["gather"] == "threads" and lines["host4"]["gather"]["mode"] == "host"
+    assert lines["rccl3"]["attempted_steps"] == lines["one"]["attempted_steps"] > 0
+    p = subprocess.run(base[:-6] + ["--tf", "2880", "--query-stride", "60", "--gather", "rccl"], capture_output=True, text=True)
+    assert p.returncode == 2 and "--nq 0" in p.stderr

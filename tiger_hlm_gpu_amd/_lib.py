@@ -70,6 +70,23 @@ class StreamStats(C.Structure):
                 ("windows", C.c_int), ("dense_bytes", C.c_uint64)]
 
 
+class ShardedRun(C.Structure):
+    """hlm_sharded_run"""
+    _fields_ = [("uid", C.c_int), ("num_systems", C.c_int), ("t0", C.c_double), ("tf", C.c_double),
+                ("h_y0", C.c_void_p), ("h_sp", C.c_void_p), ("h_forc_tables", C.POINTER(C.c_void_p)),
+                ("forc_dt_hours", C.c_double * HLM_MAX_FORCINGS), ("forc_nT", C.c_uint64 * HLM_MAX_FORCINGS),
+                ("nforc", C.c_int), ("forc_ld", C.c_int64), ("h_forc_col", C.c_void_p)]
+
+
+class ShardedStats(C.Structure):
+    """hlm_sharded_stats"""
+    _fields_ = [("upload_ms", C.c_double), ("integrate_ms", C.c_double), ("wall_to_integrated_ms", C.c_double), ("gather_ms", C.c_double), ("download_ms", C.c_double),
+                ("comm_init_ms", C.c_double), ("gather_bytes", C.c_uint64), ("rccl_version", C.c_int), ("num_shards", C.c_int),
+                ("num_devices", C.c_int)]
+
+
+GATHER_HOST, GATHER_RCCL = 0, 1
+
 # hlm_window_sink: int (*)(void* user, int query_begin, int query_end, const double* h_rows)
 WINDOW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double))
 
@@ -129,6 +146,9 @@ SIGNATURES = {
                                    C.c_void_p, C.c_int, C.c_void_p]),
     "hlm_selftest_attempt": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                        C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "hlm_run_rk45_sharded": (C.c_int, [C.POINTER(ShardedRun), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.POINTER(ShardedStats)]),
+    "hlm_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "hlm_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

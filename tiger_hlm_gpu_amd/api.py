@@ -430,3 +430,59 @@ def kernel_info(model, dense=False, math_mode=_lib.MATH_FAST):
     v, s, l, m = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(0)
     check(lib().hlm_kernel_info(_uid(model), int(dense), int(math_mode), C.byref(v), C.byref(s), C.byref(l), C.byref(m)))
     return {"vgprs": v.value, "scratch_bytes": s.value, "lds_bytes": l.value, "max_threads": m.value}
+
+
+# ---- one process, the GPUs of a node ---------------------------------------------------------------------
+def shard_bounds(num_systems, num_shards, shard):
+    """(start, count) of shard ``shard``: the reference's split rule (main.cpp:275-307), hlm_shard_bounds."""
+    a, b = C.c_int(0), C.c_int(0)
+    check(lib().hlm_shard_bounds(int(num_systems), int(num_shards), int(shard), C.byref(a), C.byref(b)))
+    return a.value, b.value
+
+
+def run_rk45_sharded(model, y0, t0, tf, sp=None, tables=(), dt_hours=(), cells=None, num_shards=1, devices=None,
+                     num_devices=None, gather="rccl"):
+    """hlm_run_rk45_sharded: the whole domain from host arrays, split by the reference's rule over ``num_shards`` shards
+    on ``devices`` (default: 0 .. num_devices - 1) in THIS process, end-of-run gather over RCCL (``gather`` = "rccl")
+    or by per-device copies ("host").  ``tables``: one float32 array [nT_j][ld] per forcing; ``cells``: int32 column of
+    each hillslope (per-cell tables), None = per-stream tables (ld == ns).  Returns (results dict, stats dict)."""
+    uid, neq = _uid(model), model.N_EQ
+    y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, neq)
+    ns = y0.shape[0]
+    r = _lib.ShardedRun()
+    r.uid, r.num_systems, r.t0, r.tf = uid, ns, float(t0), float(tf)
+    r.h_y0 = _ptr(y0)
+    keep = [y0]
+    if sp is not None:
+        sp = np.ascontiguousarray(sp, dtype=SP_DTYPE)
+        assert sp.shape == (ns,)
+        r.h_sp = _ptr(sp)
+        keep.append(sp)
+    tabs = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
+    if tabs:
+        ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+        r.h_forc_tables = C.cast(ptrs, C.POINTER(C.c_void_p))
+        r.nforc, r.forc_ld = len(tabs), int(tabs[0].shape[1])
+        for k, t in enumerate(tabs):
+            assert t.shape[1] == r.forc_ld
+            r.forc_dt_hours[k], r.forc_nT[k] = float(dt_hours[k]), int(t.shape[0])
+        keep += [tabs, ptrs]
+    if cells is not None:
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        assert cells.shape == (ns,)
+        r.h_forc_col = _ptr(cells)
+        keep.append(cells)
+    if devices is None:
+        nd, dev_arr = int(num_devices if num_devices is not None else 1), None
+    else:
+        nd = len(devices)
+        dev_arr = (C.c_int * nd)(*[int(d) for d in devices])
+    yf = np.empty((ns, neq))
+    stiff = np.empty(ns, dtype=np.int32)
+    na, nacc = np.empty(ns, dtype=np.uint32), np.empty(ns, dtype=np.uint32)
+    st = _lib.ShardedStats()
+    mode = {"rccl": _lib.GATHER_RCCL, "host": _lib.GATHER_HOST}[gather]
+    check(lib().hlm_run_rk45_sharded(C.byref(r), int(num_shards), dev_arr, nd, mode, _ptr(yf), _ptr(stiff), _ptr(na), _ptr(nacc), C.byref(st)))
+    del keep
+    stats = {f: getattr(st, f) for f, _ in _lib.ShardedStats._fields_}
+    return {"y_final": yf, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "dense": None}, stats

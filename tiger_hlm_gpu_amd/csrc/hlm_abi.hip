@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -18,6 +19,7 @@
 #include "hlm_rk45_dense_kernel.h"
 #include "hlm_rk45_kernel.h"
 #include "hlm_rk45_queue_kernel.h"
+#include "hlm_gather_rccl.h"
 #include "hlm_rk45_refill_kernel.h"
 
 namespace {
@@ -419,21 +421,43 @@ size_t g_debug_queue_rbytes = 0, g_debug_queue_qbytes = 0;
 #endif
 
 // The runs of pieces a queue launch hands out (hlm_device_job.queue_run_pieces; hlm_rk45_queue_kernel.h "RUNS").
-// Automatic: a launch with no more tiles than resident waves has no tail to remove -- one run, the pieces only re-align
-// the lanes; else every run takes half of what is left of the window, down to a sixteenth of it (32 pieces: 16, 8, 4,
-// 2, 2): the launch's tail is that of its last items, and 16 pieces were where round 3's sweep reached the asymptote.
+// Automatic: with more tiles than resident waves every run takes half of what is left of the window, down to a
+// sixteenth of it (32 pieces: 16, 8, 4, 2, 2): the launch's tail is that of its last items, and 16 pieces were where
+// round 3's sweep reached the asymptote -- headline 129.3 ms and 5.5 GB of HBM traffic against 129.6 ms and 16.9 GB
+// with every piece handed over (profiles/r04_queue_runs_probe.txt).  A launch with no more tiles than resident waves
+// hands every piece over: its waves sit unevenly on the SIMDs (1 563 waves on 1 024 SIMDs), the queue evens that out
+// piece by piece, and its bytes are few (100 000 hillslopes, cold cells: 20.8 ms against 23.1 ms as one run per tile).
+// What long runs cost: tiles whose cost is far from the mean (cold cells: a few lanes grinding towards their stiff
+// flag with tiny steps).  A tile late in the queue order starts its long first run late and its pieces are serial:
+// SURVEY's cold C3 takes 124.5 ms with these runs, 113.0 ms with queue_run_pieces = 1 -- the knob for such workloads.
 hlm::QueueRuns make_queue_runs(int pieces, long long tiles, long long resident, int run_pieces)
 {
     hlm::QueueRuns r;
     std::memset(&r, 0, sizeof(r));
+#ifdef HLM_QUEUE_PROF
+    if (const char* e = std::getenv("HLM_QUEUE_RUNS")) {   // experiment builds: run lengths "16,8,4,2,2"
+        int b = 0;
+        for (const char* q = e; *q && r.nruns < hlm::QUEUE_MAX_RUNS;) {
+            const int len = std::atoi(q);
+            if (len <= 0 || b >= pieces) break;
+            r.begin_[r.nruns++] = b;
+            b += len;
+            while (*q && *q != ',') ++q;
+            if (*q == ',') ++q;
+        }
+        if (b < pieces && r.nruns < hlm::QUEUE_MAX_RUNS) r.begin_[r.nruns++] = b;
+        r.begin_[r.nruns] = pieces;
+        return r;
+    }
+#endif
     if (run_pieces > 0) {
         r.uniform = run_pieces < pieces ? run_pieces : pieces;
         r.nruns = (pieces + r.uniform - 1) / r.uniform;
         return r;
     }
     if (tiles <= resident) {
-        r.nruns = 1;
-        r.begin_[1] = pieces;
+        r.uniform = 1;
+        r.nruns = pieces;
         return r;
     }
     const int least = pieces / 16 > 1 ? pieces / 16 : 1;
@@ -1396,6 +1420,14 @@ int hlm_debug_queue_marks(unsigned int** host, size_t words)
     return HLM_SUCCESS;
 }
 #endif
+#ifdef HLM_QUEUE_PROF
+// experiment builds only: device buffer of 8 x 64-bit words per block for the waves' accounting (NULL: none)
+int hlm_debug_queue_prof(unsigned long long* d_words)
+{
+    HLM_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(hlm::g_queue_prof), &d_words, sizeof(d_words)));
+    return HLM_SUCCESS;
+}
+#endif
 #ifdef HLM_QUEUE_DEBUG
 int hlm_debug_queue_pool(void** pool, size_t* rbytes, size_t* qbytes)
 {
@@ -1691,6 +1723,275 @@ int hlm_run_rk45(int uid, const double* h_y0, int ns, double t0, double tf, cons
         return rc;
     }
     return hlm_retrieve_and_free(&b, h_final, h_dense, h_stiff, h_n_attempt, h_n_accept);
+}
+
+
+int hlm_shard_bounds(int ns, int G, int s, int* start, int* count)
+{
+    if (ns < 0 || G < 1 || s < 0 || s >= G) return fail(HLM_ERR_INVALID_ARGUMENT, "shard %d of %d over %d hillslopes", s, G, ns);
+    const int base = ns / G, rem = ns % G;  // main.cpp:275-307
+    if (start) *start = s * base + (s < rem ? s : rem);
+    if (count) *count = base + (s < rem ? 1 : 0);
+    return HLM_SUCCESS;
+}
+
+int hlm_run_rk45_sharded(const hlm_sharded_run* run, int num_shards, const int* devices, int num_devices, int gather_mode,
+                         double* h_y_final, int32_t* h_stiff, uint32_t* h_n_attempt, uint32_t* h_n_accept,
+                         hlm_sharded_stats* stats)
+{
+    using clk = std::chrono::steady_clock;
+    auto ms_since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    if (stats) std::memset(stats, 0, sizeof(*stats));
+    if (!run) return fail(HLM_ERR_INVALID_ARGUMENT, "run is NULL");
+    const int uid = run->uid, ns = run->num_systems, neq = model_neq(uid);
+    if (neq == 0) return fail(HLM_ERR_UNKNOWN_MODEL, "unknown model UID %d", uid);
+    if (ns < 0) return fail(HLM_ERR_INVALID_ARGUMENT, "negative num_systems");
+    if (num_shards < 1 || num_devices < 1) return fail(HLM_ERR_INVALID_ARGUMENT, "num_shards and num_devices must be >= 1");
+    if (gather_mode != HLM_GATHER_HOST && gather_mode != HLM_GATHER_RCCL) return fail(HLM_ERR_INVALID_ARGUMENT, "gather_mode %d", gather_mode);
+    if (ns > 0 && (!run->h_y0 || !h_y_final)) return fail(HLM_ERR_INVALID_ARGUMENT, "h_y0 / h_y_final must not be NULL");
+    if (ns > 0 && model_needs_sp(uid) && !run->h_sp) return fail(HLM_ERR_INVALID_ARGUMENT, "Model 204 needs h_sp (SpatialParams)");
+    if (run->nforc < 0 || run->nforc > HLM_MAX_FORCINGS) return fail(HLM_ERR_INVALID_ARGUMENT, "nforc %d outside [0,%d]", run->nforc, HLM_MAX_FORCINGS);
+    const bool reads_forcings = model_nf(uid) > 0 && run->nforc > 0;
+    size_t table_rows = 0;
+    if (reads_forcings) {
+        if (!run->h_forc_tables || run->forc_ld <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "nforc > 0 needs h_forc_tables and forc_ld > 0");
+        if (!run->h_forc_col && run->forc_ld != ns)
+            return fail(HLM_ERR_INVALID_ARGUMENT, "forc_ld (%lld) != num_systems (%d) without a column index", (long long)run->forc_ld, ns);
+        for (int k = 0; k < run->nforc; ++k) {
+            if (!run->h_forc_tables[k] || run->forc_nT[k] == 0 || !(run->forc_dt_hours[k] > 0.0))
+                return fail(HLM_ERR_INVALID_ARGUMENT, "forcing %d: table / nT / dt_hours", k);
+            table_rows += (size_t)run->forc_nT[k];
+        }
+    }
+    int visible = 0;
+    HLM_HIP_TRY(hipGetDeviceCount(&visible));
+    if (visible <= 0) return fail(HLM_ERR_NO_DEVICE, "no HIP device");
+    std::vector<int> devs((size_t)num_devices);
+    for (int i = 0; i < num_devices; ++i) {
+        devs[(size_t)i] = devices ? devices[i] : i;
+        if (devs[(size_t)i] < 0 || devs[(size_t)i] >= visible) return fail(HLM_ERR_INVALID_ARGUMENT, "device %d of %d visible", devs[(size_t)i], visible);
+        for (int k = 0; k < i; ++k)
+            if (devs[(size_t)k] == devs[(size_t)i]) return fail(HLM_ERR_INVALID_ARGUMENT, "device %d listed twice", devs[(size_t)i]);
+    }
+    if (stats) { stats->num_shards = num_shards; stats->num_devices = num_devices; }
+    if (ns == 0) return HLM_SUCCESS;
+    int prev_dev = 0;
+    HLM_HIP_TRY(hipGetDevice(&prev_dev));
+
+    // what every exit path releases, in one place
+    struct Shard {
+        int dev_rank = 0, start = 0, count = 0;
+        double* y0 = nullptr;
+        void* sp = nullptr;
+        float* forc = nullptr;      // per-stream layout: this shard's columns
+        int32_t* col = nullptr;     // per-cell layout: this shard's slice of the index
+        double* y_final = nullptr;
+        int32_t* stiff = nullptr;
+        uint32_t *n_attempt = nullptr, *n_accept = nullptr;
+    };
+    struct Device {
+        hipStream_t stream = nullptr;
+        float* tables = nullptr;    // per-cell layout: the tables, once per device
+        hipEvent_t begin = nullptr, done = nullptr;   // around this device's integrations
+    };
+    std::vector<Shard> shards((size_t)num_shards);
+    std::vector<Device> dv((size_t)num_devices);
+    double* g_y = nullptr;          // the gathered arrays on devices[0] (HLM_GATHER_RCCL)
+    int32_t* g_stiff = nullptr;
+    uint32_t *g_att = nullptr, *g_acc = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hlm::RcclGather* comm = nullptr;   // the process's communicator over these devices (cached: hlm_gather_rccl.h)
+    auto cleanup = [&](int rc) {
+        for (Shard& s : shards) {
+            (void)hipSetDevice(devs[(size_t)s.dev_rank]);
+            for (void* p : {(void*)s.y0, s.sp, (void*)s.forc, (void*)s.col, (void*)s.y_final, (void*)s.stiff, (void*)s.n_attempt, (void*)s.n_accept})
+                if (p) (void)hipFree(p);
+        }
+        for (size_t d = 0; d < dv.size(); ++d) {
+            (void)hipSetDevice(devs[d]);
+            if (dv[d].tables) (void)hipFree(dv[d].tables);
+            if (dv[d].done) (void)hipEventDestroy(dv[d].done);
+            if (dv[d].begin) (void)hipEventDestroy(dv[d].begin);
+            if (dv[d].stream) { (void)hipStreamSynchronize(dv[d].stream); (void)hipStreamDestroy(dv[d].stream); }
+        }
+        (void)hipSetDevice(devs[0]);
+        for (void* p : {(void*)g_y, (void*)g_stiff, (void*)g_att, (void*)g_acc})
+            if (p) (void)hipFree(p);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        (void)hipSetDevice(prev_dev);
+        return rc;
+    };
+#define HLM_SH_TRY(expr)                                                                                  \
+    do {                                                                                                  \
+        const hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return cleanup(fail(HLM_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_))); \
+    } while (0)
+
+    // ---- inputs: split by the reference's rule, one stream per device ---------------------------------------
+    clk::time_point tp = clk::now();
+    for (int d = 0; d < num_devices; ++d) {
+        HLM_SH_TRY(hipSetDevice(devs[(size_t)d]));
+        HLM_SH_TRY(hipStreamCreateWithFlags(&dv[(size_t)d].stream, hipStreamNonBlocking));
+        HLM_SH_TRY(hipEventCreate(&dv[(size_t)d].begin));
+        HLM_SH_TRY(hipEventCreate(&dv[(size_t)d].done));
+        if (reads_forcings && run->h_forc_col && d < num_shards) {
+            HLM_SH_TRY(hipMalloc((void**)&dv[(size_t)d].tables, sizeof(float) * table_rows * (size_t)run->forc_ld));
+            size_t row = 0;
+            for (int k = 0; k < run->nforc; ++k) {
+                HLM_SH_TRY(hipMemcpyAsync(dv[(size_t)d].tables + row * (size_t)run->forc_ld, run->h_forc_tables[k],
+                                          sizeof(float) * (size_t)run->forc_nT[k] * (size_t)run->forc_ld, hipMemcpyHostToDevice, dv[(size_t)d].stream));
+                row += (size_t)run->forc_nT[k];
+            }
+        }
+    }
+    const size_t sp_bytes = sizeof(hlm_spatial_params);
+    for (int s = 0; s < num_shards; ++s) {
+        Shard& sh = shards[(size_t)s];
+        sh.dev_rank = s % num_devices;
+        (void)hlm_shard_bounds(ns, num_shards, s, &sh.start, &sh.count);
+        if (sh.count == 0) continue;
+        const size_t n = (size_t)sh.count;
+        hipStream_t st = dv[(size_t)sh.dev_rank].stream;
+        HLM_SH_TRY(hipSetDevice(devs[(size_t)sh.dev_rank]));
+        HLM_SH_TRY(hipMalloc((void**)&sh.y0, sizeof(double) * n * (size_t)neq));
+        HLM_SH_TRY(hipMalloc((void**)&sh.y_final, sizeof(double) * n * (size_t)neq));
+        HLM_SH_TRY(hipMalloc((void**)&sh.stiff, sizeof(int32_t) * n));
+        HLM_SH_TRY(hipMalloc((void**)&sh.n_attempt, sizeof(uint32_t) * n));
+        HLM_SH_TRY(hipMalloc((void**)&sh.n_accept, sizeof(uint32_t) * n));
+        HLM_SH_TRY(hipMemcpyAsync(sh.y0, run->h_y0 + (size_t)sh.start * (size_t)neq, sizeof(double) * n * (size_t)neq, hipMemcpyHostToDevice, st));
+        if (run->h_sp) {
+            HLM_SH_TRY(hipMalloc(&sh.sp, sp_bytes * n));
+            HLM_SH_TRY(hipMemcpyAsync(sh.sp, static_cast<const char*>(run->h_sp) + (size_t)sh.start * sp_bytes, sp_bytes * n, hipMemcpyHostToDevice, st));
+        }
+        if (reads_forcings && run->h_forc_col) {
+            HLM_SH_TRY(hipMalloc((void**)&sh.col, sizeof(int32_t) * n));
+            HLM_SH_TRY(hipMemcpyAsync(sh.col, run->h_forc_col + sh.start, sizeof(int32_t) * n, hipMemcpyHostToDevice, st));
+        } else if (reads_forcings) {
+            // the shard's columns of the per-stream tables: [rows][count] out of [rows][ns]
+            HLM_SH_TRY(hipMalloc((void**)&sh.forc, sizeof(float) * table_rows * n));
+            size_t row = 0;
+            for (int k = 0; k < run->nforc; ++k) {
+                HLM_SH_TRY(hipMemcpy2DAsync(sh.forc + row * n, sizeof(float) * n, run->h_forc_tables[k] + sh.start, sizeof(float) * (size_t)run->forc_ld,
+                                            sizeof(float) * n, (size_t)run->forc_nT[k], hipMemcpyHostToDevice, st));
+                row += (size_t)run->forc_nT[k];
+            }
+        }
+    }
+    if (stats) stats->upload_ms = ms_since(tp);
+
+    // ---- integrate: every shard on its device's stream (asynchronous: the devices run side by side) ---------
+    tp = clk::now();
+    for (int d = 0; d < num_devices; ++d) {
+        HLM_SH_TRY(hipSetDevice(devs[(size_t)d]));
+        HLM_SH_TRY(hipEventRecord(dv[(size_t)d].begin, dv[(size_t)d].stream));
+    }
+    for (int s = 0; s < num_shards; ++s) {
+        Shard& sh = shards[(size_t)s];
+        if (sh.count == 0) continue;
+        HLM_SH_TRY(hipSetDevice(devs[(size_t)sh.dev_rank]));
+        ForcingState F;
+        if (reads_forcings) {
+            F.d_forc = run->h_forc_col ? dv[(size_t)sh.dev_rank].tables : sh.forc;
+            F.d_col = sh.col;
+            F.ld = run->h_forc_col ? run->forc_ld : (int64_t)sh.count;
+            F.nforc = run->nforc;
+            std::memcpy(F.dt_h, run->forc_dt_hours, sizeof(F.dt_h));
+            std::memcpy(F.nT, run->forc_nT, sizeof(F.nT));
+        }
+        hlm_device_job j;
+        std::memset(&j, 0, sizeof(j));
+        {
+            std::lock_guard<std::mutex> lk(g_mu);
+            if (const int rc0 = fill_job_from_registry(&j, uid, F); rc0 != HLM_SUCCESS) return cleanup(rc0);
+        }
+        j.num_systems = sh.count;
+        j.t0 = run->t0;
+        j.tf = run->tf;
+        j.d_y0 = sh.y0;
+        j.d_sp = sh.sp;
+        j.d_y_final = sh.y_final;
+        j.d_stiff = sh.stiff;
+        j.d_n_attempt = sh.n_attempt;
+        j.d_n_accept = sh.n_accept;
+        if (const int rc1 = hlm_rk45_integrate_device(&j, dv[(size_t)sh.dev_rank].stream); rc1 != HLM_SUCCESS) return cleanup(rc1);
+    }
+    for (int d = 0; d < num_devices; ++d) {
+        HLM_SH_TRY(hipSetDevice(devs[(size_t)d]));
+        HLM_SH_TRY(hipEventRecord(dv[(size_t)d].done, dv[(size_t)d].stream));
+    }
+    // the communicator comes up while the kernels run (the first one of a process takes ~1 s, later ones are cached)
+    if (gather_mode == HLM_GATHER_RCCL) {
+        const clk::time_point tc = clk::now();
+        std::string err;
+        comm = hlm::rccl_gather_for(devs, &err);
+        if (!comm) return cleanup(fail(HLM_ERR_HIP, "%s", err.c_str()));
+        if (stats) { stats->comm_init_ms = ms_since(tc); stats->rccl_version = comm->version(); }
+    }
+    double slowest = 0.0;
+    for (int d = 0; d < num_devices; ++d) {
+        HLM_SH_TRY(hipSetDevice(devs[(size_t)d]));
+        HLM_SH_TRY(hipStreamSynchronize(dv[(size_t)d].stream));
+        float ms = 0.0f;
+        HLM_SH_TRY(hipEventElapsedTime(&ms, dv[(size_t)d].begin, dv[(size_t)d].done));
+        if (ms > slowest) slowest = ms;
+    }
+    if (stats) { stats->integrate_ms = slowest; stats->wall_to_integrated_ms = ms_since(tp); }
+
+    // ---- gather -------------------------------------------------------------------------------------------
+    tp = clk::now();
+    if (gather_mode == HLM_GATHER_RCCL) {
+        HLM_SH_TRY(hipSetDevice(devs[0]));
+        HLM_SH_TRY(hipMalloc((void**)&g_y, sizeof(double) * (size_t)ns * (size_t)neq));
+        HLM_SH_TRY(hipMalloc((void**)&g_stiff, sizeof(int32_t) * (size_t)ns));
+        HLM_SH_TRY(hipMalloc((void**)&g_att, sizeof(uint32_t) * (size_t)ns));
+        HLM_SH_TRY(hipMalloc((void**)&g_acc, sizeof(uint32_t) * (size_t)ns));
+        HLM_SH_TRY(hipEventCreate(&ev0));
+        HLM_SH_TRY(hipEventCreate(&ev1));
+        std::vector<hlm::GatherPiece> pieces;
+        uint64_t bytes = 0;
+        for (const Shard& sh : shards) {
+            if (sh.count == 0) continue;
+            const size_t n = (size_t)sh.count, o = (size_t)sh.start;
+            pieces.push_back({sh.dev_rank, sh.y_final, g_y + o * (size_t)neq, sizeof(double) * n * (size_t)neq});
+            pieces.push_back({sh.dev_rank, sh.stiff, g_stiff + o, sizeof(int32_t) * n});
+            pieces.push_back({sh.dev_rank, sh.n_attempt, g_att + o, sizeof(uint32_t) * n});
+            pieces.push_back({sh.dev_rank, sh.n_accept, g_acc + o, sizeof(uint32_t) * n});
+            bytes += (sizeof(double) * (size_t)neq + 12u) * n;
+        }
+        std::vector<hipStream_t> streams((size_t)num_devices);
+        for (int d = 0; d < num_devices; ++d) streams[(size_t)d] = dv[(size_t)d].stream;
+        HLM_SH_TRY(hipEventRecord(ev0, streams[0]));
+        if (const std::string err = comm->gather(pieces, 0, streams); !err.empty()) return cleanup(fail(HLM_ERR_HIP, "%s", err.c_str()));
+        HLM_SH_TRY(hipSetDevice(devs[0]));
+        HLM_SH_TRY(hipEventRecord(ev1, streams[0]));
+        for (int d = 0; d < num_devices; ++d) {
+            HLM_SH_TRY(hipSetDevice(devs[(size_t)d]));
+            HLM_SH_TRY(hipStreamSynchronize(streams[(size_t)d]));
+        }
+        float gms = 0.0f;
+        HLM_SH_TRY(hipEventElapsedTime(&gms, ev0, ev1));
+        if (stats) { stats->gather_ms = gms; stats->gather_bytes = bytes; }
+        tp = clk::now();
+        HLM_SH_TRY(hipSetDevice(devs[0]));
+        HLM_SH_TRY(hipMemcpy(h_y_final, g_y, sizeof(double) * (size_t)ns * (size_t)neq, hipMemcpyDeviceToHost));
+        if (h_stiff) HLM_SH_TRY(hipMemcpy(h_stiff, g_stiff, sizeof(int32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+        if (h_n_attempt) HLM_SH_TRY(hipMemcpy(h_n_attempt, g_att, sizeof(uint32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+        if (h_n_accept) HLM_SH_TRY(hipMemcpy(h_n_accept, g_acc, sizeof(uint32_t) * (size_t)ns, hipMemcpyDeviceToHost));
+    } else {
+        for (const Shard& sh : shards) {
+            if (sh.count == 0) continue;
+            const size_t n = (size_t)sh.count, o = (size_t)sh.start;
+            HLM_SH_TRY(hipSetDevice(devs[(size_t)sh.dev_rank]));
+            HLM_SH_TRY(hipMemcpy(h_y_final + o * (size_t)neq, sh.y_final, sizeof(double) * n * (size_t)neq, hipMemcpyDeviceToHost));
+            if (h_stiff) HLM_SH_TRY(hipMemcpy(h_stiff + o, sh.stiff, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+            if (h_n_attempt) HLM_SH_TRY(hipMemcpy(h_n_attempt + o, sh.n_attempt, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+            if (h_n_accept) HLM_SH_TRY(hipMemcpy(h_n_accept + o, sh.n_accept, sizeof(uint32_t) * n, hipMemcpyDeviceToHost));
+        }
+    }
+    if (stats) stats->download_ms = ms_since(tp);
+#undef HLM_SH_TRY
+    return cleanup(HLM_SUCCESS);
 }
 
 }  // extern "C"

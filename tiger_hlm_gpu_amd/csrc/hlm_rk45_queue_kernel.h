@@ -29,9 +29,9 @@
 // 3) re-read the 136-byte parameter record and moved 76 bytes of lane state out and back in 31 times per hillslope:
 // 16.9 GB of HBM traffic per headline launch against 3.2 GB algorithmic.  What removes the launch's tail is the
 // granularity of its LAST items only, so the runs shrink towards the end of the window (QueueRuns: by default each
-// run takes half of what is left, down to a sixteenth of the window) -- and a launch with no more tiles than resident
-// waves has no tail to remove: ONE run, no hand-over at all, the pieces only re-align.  Same bits whatever the runs
-// (hlm_set_queue_runs, tests).
+// run takes half of what is left, down to a sixteenth of the window; launches with no more tiles than resident waves
+// keep handing every piece over: make_queue_runs in hlm_abi.hip has the measurements).  Same bits whatever the runs
+// (hlm_device_job.queue_run_pieces, tests).
 //
 // Every wave reaches the end of the grid whatever happens: the wait is bounded by a wall-clock watchdog
 // (QUEUE_WAIT_LIMIT_TICKS of the 100 MHz real-time counter).  A wait that outlasts it -- a lost wave; never seen --
@@ -54,6 +54,20 @@ __device__ unsigned int* g_queue_marks = nullptr;
     } while (0)
 #else
 #define HLM_QMARK(k, v) do { } while (0)
+#endif
+#ifdef HLM_QUEUE_PROF
+// experiment builds: per-wave accounting of a queue launch in 100 MHz wall-clock ticks, [block * 8 + k]:
+// 0 first item drawn at, 1 last item finished at, 2 ticks inside item bodies, 3 ticks waiting for a predecessor,
+// 4 items drawn, 5 items with at least one running lane, 6 sum over items of the lanes that ran
+__device__ unsigned long long* g_queue_prof = nullptr;
+#define HLM_QPROF(k, expr)                                                                \
+    do {                                                                                  \
+        if (g_queue_prof && lane == 0) { unsigned long long& w_ = g_queue_prof[blockIdx.x * 8 + (k)]; w_ = (expr); } \
+    } while (0)
+#define HLM_QPROF_ADD(k, v) HLM_QPROF(k, w_ + (unsigned long long)(v))
+#else
+#define HLM_QPROF(k, expr) do { } while (0)
+#define HLM_QPROF_ADD(k, v) do { } while (0)
 #endif
 #ifndef HLM_QUEUE_WAIT_LIMIT_TICKS
 #define HLM_QUEUE_WAIT_LIMIT_TICKS 2000000000ull  // 20 s of wall_clock64() (100 MHz)
@@ -113,6 +127,9 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         HLM_QMARK(1, item);
         HLM_QMARK(2, 1);
         if (item >= nitems) break;
+        [[maybe_unused]] const unsigned long long prof_t0 = wall_clock64();
+        if (drawn == 0) HLM_QPROF(0, prof_t0);
+        HLM_QPROF_ADD(4, 1);
         const unsigned r = item / ntiles, tile = item - r * ntiles;   // run r of this tile:
         const unsigned c_begin = (unsigned)R.begin((int)r, nchunk), c_end = (unsigned)R.begin((int)r + 1, nchunk);   // its pieces
         const int sys = (int)(tile * WAVE) + lane;
@@ -139,6 +156,8 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
             HLM_QMARK(2, 3);
             asm volatile("" ::: "memory");  // (the record is loaded after the counter, also as the compiler sees it)
         }
+        [[maybe_unused]] const unsigned long long prof_t1 = wall_clock64();
+        HLM_QPROF_ADD(3, prof_t1 - prof_t0);
         if (sys < A.ns && lost) {
             // (watchdog) whatever this hillslope's record says, nobody continues it: flagged, zero finals
             if (coherent_load(&resume_i[(size_t)4 * A.ns + sys]) == SYS_PAUSED) {
@@ -157,6 +176,15 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 runs = status == SYS_PAUSED;  // else: finished or flagged in an earlier piece, its outputs were written then
                 if (runs) status = HLM_SYS_OK;
             }
+#ifdef HLM_QUEUE_PROF
+            {
+                const int nrun = __builtin_popcountll(__builtin_amdgcn_ballot_w64(runs));
+                if (runs && nrun > 0 && g_queue_prof && (int)__builtin_amdgcn_readfirstlane(lane) == lane) {
+                    g_queue_prof[blockIdx.x * 8 + 5] += 1ull;
+                    g_queue_prof[blockIdx.x * 8 + 6] += (unsigned long long)nrun;
+                }
+            }
+#endif
             if (runs) {
                 const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
                 double y[NEQ];
@@ -253,6 +281,8 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         HLM_QMARK(2, 5);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         HLM_QMARK(2, 6);
+        HLM_QPROF_ADD(2, wall_clock64() - prof_t1);
+        HLM_QPROF(1, wall_clock64());
         __hip_atomic_store(&done[tile], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
         HLM_QMARK(2, 7);
     }

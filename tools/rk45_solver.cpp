@@ -74,6 +74,9 @@ struct Options {
     bool radau_continue = false; // ... continuing from the state RK45 reached instead of restarting at t0
     int time_pieces = -1;        // launch shape of runs without dense output (-1 automatic, 0 one wave per tile)
     bool oversubscribe = false; // allow --gpus > visible devices (shards share GPUs round-robin)
+    std::string gather = "threads"; // threads: one host thread per shard writes its rows (dense output too); rccl | host: ONE
+                                    // host thread drives all devices (hlm_run_rk45_sharded), final states gathered to the first
+                                    // device over RCCL / copied per device -- runs without dense output (--nq 0)
     bool quiet = false;
 };
 
@@ -86,7 +89,7 @@ struct Options {
                  "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau | --radau-continue] [--time-pieces P]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
                  "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L] [--states I,J,..] [--stream-dense QUERIES_PER_WINDOW]\n"
-                 "                   [--device D] [--gpus N [--oversubscribe]] [--quiet]\n");
+                 "                   [--device D] [--gpus N [--oversubscribe] [--gather threads|rccl|host]] [--quiet]\n");
     std::exit(msg ? 2 : 0);
 }
 
@@ -184,6 +187,7 @@ Options parse(int argc, char** argv)
         else if (a == "--device") o.device = std::atoi(val());
         else if (a == "--gpus") o.gpus = std::atoi(val());
         else if (a == "--oversubscribe") o.oversubscribe = true;
+        else if (a == "--gather") o.gather = val();
         else if (a == "--quiet") o.quiet = true;
         else if (a == "-h" || a == "--help") usage(nullptr);
         else usage(("unknown option " + a).c_str());
@@ -526,7 +530,51 @@ int run(const Options& o, hlm_io::CsvStyle style)
         }
     };
     const auto w0 = std::chrono::steady_clock::now();
-    if (G == 1) {
+    std::string gather_note = "\"threads\"";
+    if (o.gather == "rccl" || o.gather == "host") {
+        // One host thread, all devices: the reference's rank-0 split (main.cpp:275-307) inside the library and the
+        // end-of-run gather over RCCL (hlm_run_rk45_sharded) -- final states, flags and step counters only.
+        if (nq > 0 || o.radau || o.stream_forcings > 0 || stream_dense)
+            usage("--gather rccl|host gathers final states only: needs --nq 0 and none of --radau / --stream-forcings / --stream-dense");
+        const int nd = std::min(G, std::max(ndev, 1));
+        std::vector<int> devices((size_t)nd);
+        for (int i = 0; i < nd; ++i) devices[(size_t)i] = (o.device + i) % std::max(ndev, 1);
+        std::vector<const float*> tables;
+        std::vector<float> expanded;   // --expand-forcings: the reference's per-stream block of the whole domain
+        long long ld = fb.ld;
+        const int32_t* col = col_of_stream.data();
+        if (!fb.nT.empty()) {
+            size_t rows = 0;
+            for (size_t n : fb.nT) rows += n;
+            const float* base = fb.data.data();
+            if (o.expand_forcings) {
+                expanded.resize(rows * (size_t)ns);
+                for (size_t t = 0; t < rows; ++t)
+                    for (int s = 0; s < ns; ++s) expanded[t * (size_t)ns + s] = fb.data[t * (size_t)fb.ld + (size_t)col_of_stream[s]];
+                base = expanded.data();
+                ld = ns;
+                col = nullptr;
+            }
+            size_t row = 0;
+            for (size_t n : fb.nT) { tables.push_back(base + row * (size_t)ld); row += n; }
+        }
+        rk45_api::ShardedStats st;
+        h_y_final = rk45_api::run_rk45_sharded<Model>(h_y0, t0, tf, spatial.data(), tables, fb.dt_hours, fb.nT, ld, fb.nT.empty() ? nullptr : col,
+                                                      G, devices, o.gather == "rccl", &st);
+        const rk45_api::RunInfo info = rk45_api::last_run_info();
+        stiff = info.stiff;
+        n_attempt = info.n_attempt;
+        t_h2d[0] = st.upload_ms * 1e-3;
+        t_integrate[0] = st.integrate_ms * 1e-3;
+        t_d2h[0] = (st.gather_ms + st.download_ms) * 1e-3;
+        char buf[256];
+        std::snprintf(buf, sizeof(buf), "{\"mode\": \"%s\", \"devices\": %d, \"shards\": %d, \"gather_ms\": %.4f, \"gather_bytes\": %llu, "
+                      "\"comm_init_ms\": %.3f, \"rccl_version\": %d}", o.gather.c_str(), st.num_devices, st.num_shards, st.gather_ms,
+                      (unsigned long long)st.gather_bytes, st.comm_init_ms, st.rccl_version);
+        gather_note = buf;
+    } else if (o.gather != "threads") {
+        usage("--gather must be threads, rccl or host");
+    } else if (G == 1) {
         run_shard(0);
     } else {
         std::vector<std::thread> th;
@@ -592,11 +640,11 @@ int run(const Options& o, hlm_io::CsvStyle style)
                     "\"initial_step\": %g, \"gpus\": %d, \"attempted_steps\": %llu, \"flagged\": %d, \"radau\": %s, \"unsolved\": %d, "
                     "\"run_rk45_seconds\": %.6f, \"dense_row_width\": %d, \"device_output_selection\": %s, "
                     "\"phases\": {\"params_csv_s\": %.6f, \"forcing_read_s\": %.6f, \"h2d_s\": %.6f, \"integrate_s\": %.6f, "
-                    "\"d2h_s\": %.6f, \"write_s\": %.6f, \"window_sink_s\": %.6f}, \"streamed_dense_window\": %d, \"final\": \"%s\", \"dense\": \"%s\"}\n",
+                    "\"d2h_s\": %.6f, \"write_s\": %.6f, \"window_sink_s\": %.6f}, \"streamed_dense_window\": %d, \"gather\": %s, \"final\": \"%s\", \"dense\": \"%s\"}\n",
                     (int)Model::UID, ns, nq, t0, tf, hp.initialStep, G, attempts, flagged, o.radau ? "true" : "false", unsolved, secs,
                     width, device_select ? "true" : "false", t_params, t_forcing_read,
                     *std::max_element(t_h2d.begin(), t_h2d.end()), *std::max_element(t_integrate.begin(), t_integrate.end()),
-                    *std::max_element(t_d2h.begin(), t_d2h.end()), t_write, t_sink, stream_dense ? o.stream_dense : 0, o.out_final.c_str(),
+                    *std::max_element(t_d2h.begin(), t_d2h.end()), t_write, t_sink, stream_dense ? o.stream_dense : 0, gather_note.c_str(), o.out_final.c_str(),
                     o.out_dense.c_str());
     return 0;
 }
