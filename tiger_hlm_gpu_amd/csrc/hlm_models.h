@@ -351,6 +351,71 @@ struct Model204Dev {
         J[4][1] = c * b * a;
     }
 
+    // rhs and jacobian of the same state in one pass (the Radau pass's set-up evaluates both): the shared
+    // sub-expressions -- snowmelt, x1, the overflow, Emax, and above all h_surf^(2/3) -- are formed once.  Same
+    // expressions as rhs<MATH> and jacobian<MATH>, hence the same values.
+    static constexpr bool HAS_RHS_JACOBIAN = true;
+    template <int MATH>
+    static __device__ __forceinline__ void rhs_jacobian(const Local& P, const Forc& F, const double (&y)[N_EQ], double (&dydt)[N_EQ],
+                                                        double (&J)[N_EQ][N_EQ])
+    {
+#pragma unroll
+        for (int i = 0; i < N_EQ; ++i)
+#pragma unroll
+            for (int j = 0; j < N_EQ; ++j) J[i][j] = 0.0;
+        const double h_snow = y[0], h_stat = y[1], h_surf = y[2], h_grav = y[3], h_aq = y[4];
+        const bool warm = F.warm_mask != 0ull;
+        const double snowmelt = __longlong_as_double(__double_as_longlong(vmin(h_snow, F.melt_pot)) & (long long)F.warm_mask);
+        const double m = (warm && h_snow < F.melt_pot) ? 1.0 : 0.0;
+        const double x1 = F.rain + snowmelt;
+        dydt[0] = F.rain - snowmelt;
+        const double over = x1 + h_stat - P.Hu;
+        const double x2 = vmax(0.0, over);
+        const double a = over > 0.0 ? 1.0 : 0.0;
+        const double d1 = x1 - x2;
+        const double Emax = vmin(F.e_pot, h_stat);
+        const double e = h_stat < F.e_pot ? 1.0 : 0.0;
+        const double x3 = vmin(x2, P.infil);
+        const double b = x2 < P.infil ? 1.0 : 0.0;
+        const double c = x3 < P.perco ? 1.0 : 0.0;
+        const double d2 = x2 - x3;
+        const double x4 = vmin(x3, P.perco);
+        const double d3 = x3 - x4;
+        const double p23 = pow_two_thirds<MATH>(h_surf);
+        double w_lin, s, dEmax;
+        if constexpr (MATH == MATH_FAST) {
+            w_lin = P.manning * p23;
+            s = h_stat * P.inv_Hu;
+            dEmax = Emax * P.inv_Hu;
+            J[3][3] = -P.inv_alpha3;
+            J[4][4] = -P.inv_alpha4;
+            dydt[3] = d3 - h_grav * P.inv_alpha3;
+            dydt[4] = x4 - h_aq * P.inv_alpha4;
+            dydt[2] = d2 - h_surf * vmin(1.0, w_lin);
+        } else {
+            const double alfa2 = P.inv_n * p23 * P.sqrt_slope;
+            w_lin = alfa2 * P.L / P.A_h * 60.0;   // (the Jacobian's form, as jacobian<STRICT> writes it)
+            s = strict_div(h_stat, P.Hu, P.inv_Hu, P.div_ok);
+            dEmax = Emax / P.Hu;
+            J[3][3] = -(P.alpha3 >= 1.0 ? 1.0 / P.alpha3 : 0.0);
+            J[4][4] = -(P.alpha4 >= 1.0 ? 1.0 / P.alpha4 : 0.0);
+            dydt[3] = d3 - (P.alpha3 >= 1.0 ? strict_div(h_grav, P.alpha3, P.inv_alpha3, P.div_ok) : 0.0);
+            dydt[4] = x4 - (P.alpha4 >= 1.0 ? strict_div(h_aq, P.alpha4, P.inv_alpha4, P.div_ok) : 0.0);
+            dydt[2] = d2 - h_surf * vmin(1.0, strict_div(alfa2 * P.L, P.A_h, P.inv_A_h, P.div_ok) * 60.0);   // (the RHS's form)
+        }
+        dydt[1] = d1 - s * Emax;
+        J[0][0] = -m;
+        J[1][0] = m - a * m;
+        J[1][1] = -a - (dEmax + s * e);
+        J[2][0] = (1.0 - b) * a * m;
+        J[2][1] = (1.0 - b) * a;
+        J[2][2] = -(w_lin < 1.0 ? (5.0 / 3.0) * w_lin : 1.0);
+        J[3][0] = (1.0 - c) * b * a * m;
+        J[3][1] = (1.0 - c) * b * a;
+        J[4][0] = c * b * a * m;
+        J[4][1] = c * b * a;
+    }
+
     template <int MATH, bool DRY>
     static __device__ __forceinline__ bool rhs_impl(const Local& P, const Forc& F, const double (&y)[N_EQ],
                                                     double (&dydt)[N_EQ])
@@ -434,6 +499,7 @@ struct DummyDev {
     static __device__ __forceinline__ bool rhs_fast(const Local&, const Forc&, const double (&)[N_EQ],
                                                     double (&)[N_EQ]) { return true; }
     static constexpr bool HAS_JACOBIAN = true;  // constant: the system is linear
+    static constexpr bool HAS_RHS_JACOBIAN = false;
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;
     template <int MATH>
     static __device__ __forceinline__ void jacobian(const Local&, const Forc&, const double (&)[N_EQ],
@@ -492,6 +558,7 @@ struct ToyDev {
     static constexpr bool HAS_FASTPATH = false;
     static constexpr bool HAS_NORAINPATH = false;
     static constexpr bool HAS_JACOBIAN = false;
+    static constexpr bool HAS_RHS_JACOBIAN = false;
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = false;
     static constexpr int FAST_ZERO_COMP = 0;
     static constexpr int NORAIN_LINEAR = 0;

@@ -51,6 +51,27 @@ __device__ __forceinline__ double recip(double x)
     if constexpr (MATH == MATH_FAST) return fast_rcp(x); else return 1.0 / x;
 }
 
+// (1 / x)^(1/4) for the step-size controller.  STRICT: pow as the oracle writes it.  FAST: as inv_fifth_root of the RK45
+// loop -- an f32 exp2 / log2 seed z ~ x^(-1/4), residual e = 1 - x z^4, exact root z (1 - e)^(-1/4) =
+// z (1 + e/4 + 5/32 e^2 + ...) -- a dozen instructions instead of two double-precision square roots and a reciprocal
+// (~45).  x = err + 1e-16 >= 1e-16; beyond 1e30 the factor is clamped to minScale whatever its value, so x is capped
+// there (keeps the f32 seed finite, an infinite estimate included).
+template <int MATH>
+__device__ __forceinline__ double inv_fourth_root(double x)
+{
+    if constexpr (MATH == MATH_STRICT) {
+        return pow(1.0 / x, 0.25);
+    } else {
+        const double xc = fmin(x, 1e30);
+        double z = (double)__builtin_amdgcn_exp2f(-0.25f * __builtin_amdgcn_logf((float)xc));
+        const double z2 = z * z;
+        const double e = __builtin_fma(-xc, z2 * z2, 1.0);
+        const double p = __builtin_fma(e, 5.0 / 32.0, 0.25);
+        z = __builtin_fma(z * e, p, z);
+        return z;
+    }
+}
+
 constexpr int NEWTON_MAXITER = 10;
 constexpr double NEWTON_TOL = 1e-3;
 constexpr double FD_EPS = 1e-8;
@@ -235,7 +256,8 @@ __device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], con
 // SIMD.  With a triangular Jacobian they are gone and two waves fit.
 #ifdef HLM_RADAU_COUNTERS
 // experiment builds: where the lanes of a wave wait for each other.  [2k] wave-level trips through section k,
-// [2k + 1] lane-level trips (sum of the active lanes): k = 0 step attempts, 1 Newton iterations, 2 accepted-step tails
+// [2k + 1] lane-level trips (sum of the active lanes): k = 0 step attempts (set-ups), 1 Newton iterations, 2 converged-attempt
+// tails, 3 trips of the state machine's loop (lanes not yet done)
 __device__ unsigned long long g_radau_ctr[8];
 #define HLM_RCOUNT(k)                                                                    \
     do {                                                                                 \
@@ -251,6 +273,14 @@ __device__ unsigned long long g_radau_ctr[8];
 #ifndef HLM_RADAU_TRI_WAVES
 #define HLM_RADAU_TRI_WAVES 2
 #endif
+// the finish + set-up section of the state machine runs when this fraction of the wave's live lanes waits for it
+#ifndef HLM_RADAU_SETUP_NUM
+#define HLM_RADAU_SETUP_NUM 6
+#endif
+#ifndef HLM_RADAU_SETUP_DEN
+#define HLM_RADAU_SETUP_DEN 8
+#endif
+constexpr int RADAU_SETUP_NUM = HLM_RADAU_SETUP_NUM, RADAU_SETUP_DEN = HLM_RADAU_SETUP_DEN;
 template <class Model, int MATH>
 __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR) ? HLM_RADAU_TRI_WAVES : 1) radau_fallback_kernel(const Rk45Args A, const int* __restrict__ list,
                                                                  const int* __restrict__ count)
@@ -318,110 +348,239 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         return (double)A.forc[A.forc_base[j] + (size_t)idx * (size_t)A.forc_ld + fcol];
     };
 
+    // ---- the attempts, as a state machine whose trip is ONE simplified-Newton iteration (round 4) ----------------------
+    // Written as "for each attempt: set-up, Newton loop, tail" (round 2/3) the wave runs every attempt's Newton loop
+    // until its slowest lane has converged: a lane needs 2.49 iterations per attempt, its wave ran 4.82 -- 29 of 64
+    // lanes active in the loop that is three quarters of the pass (DESIGN.md "Radau-IIA fallback").  Here every lane
+    // is in one of two phases.  PH_NEWTON: it takes part in the trip's Newton iteration (3 RHS + two triangular
+    // solves) and, when that iteration ends its attempt (converged / diverging / out of iterations), moves to
+    // PH_SETUP and waits.  PH_SETUP: it waits for the wave's next finish + set-up section, which runs once enough
+    // lanes wait (RADAU_SETUP_NUM / RADAU_SETUP_DEN of the live ones) or nobody is iterating: there the lane finishes
+    // the attempt it came from (error estimate, accept / reject, dense rows, commit -- or h / 2 after a failed
+    // iteration) and sets up its next one (forcing samples, clipping, f0, Jacobian, the 15 reciprocals), then iterates
+    // again.  Each lane executes exactly the operation sequence of the nested loops, so every result is the same bit
+    // for bit; only WHEN a lane does what differs, and the Newton iterations run with the lanes that need them.
+    enum : int { PH_NEWTON = 0, PH_SETUP = 1, PH_DONE = 2 };
+    enum : int { END_NONE = 0, END_CONVERGED = 1, END_FAILED = 2 };
     bool capped = false;
+    int phase = t < tf ? PH_SETUP : PH_DONE, ended = END_NONE;
+    // state of the attempt a lane is in
+    constexpr bool TRI = Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR;
+    double f0[NEQ], Jm[NEQ][NEQ];
+    [[maybe_unused]] double Mr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Cr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Ci[TRI ? 1 : NEQ][TRI ? 1 : NEQ];
+    double inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
+    [[maybe_unused]] int piv_r[NEQ], piv_c[NEQ];
+    double Z[NS][NEQ], W[NS][NEQ], inv_sc[NEQ];
+    double inv_h = 0.0, g_h = 0.0, a_h = 0.0, b_h = 0.0, h_ctl = h, t_end = t, prev = __builtin_inf();
+    bool clipped = false;
+    int it = 0;
+#pragma unroll
+    for (int i = 0; i < NEQ; ++i) {
+        f0[i] = inv_r[i] = inv_cr[i] = inv_ci[i] = inv_sc[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < NEQ; ++j) Jm[i][j] = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = W[s2][i] = 0.0;
+    }
+    auto solve_r = [&](double (&b)[NEQ]) {
+        if constexpr (TRI) solve_real_tri(Jm, inv_r, b); else solve_real(Mr, piv_r, inv_r, b);
+    };
+    auto solve_c = [&](double (&br)[NEQ], double (&bi)[NEQ]) {
+        if constexpr (TRI) solve_cplx_tri(Jm, inv_cr, inv_ci, br, bi); else solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, br, bi);
+    };
+
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no prologue load is waited for inside the loop, behind the row stores
 #pragma unroll 1
-    while (t < tf) {
-        if (n_attempt >= A.cap) { capped = true; break; }
-        HLM_RCOUNT(0);
-        double t_b = __builtin_inf();  // the next sample boundary of any stream
-        if constexpr (Model::NF > 0) {
-            bool moved = false;
+    while (true) {
+        const unsigned long long m_setup = __builtin_amdgcn_ballot_w64(phase == PH_SETUP);
+        const unsigned long long m_newton = __builtin_amdgcn_ballot_w64(phase == PH_NEWTON);
+        if ((m_setup | m_newton) == 0ull) break;
+        HLM_RCOUNT(3);
+        const int n_setup = __builtin_popcountll(m_setup), n_newton = __builtin_popcountll(m_newton);
+        if (n_setup > 0 && (n_newton == 0 || n_setup * RADAU_SETUP_DEN >= (n_setup + n_newton) * RADAU_SETUP_NUM)) {
+            if (phase == PH_SETUP) {
+                // ---- finish the attempt this lane came from -------------------------------------------------------
+                if (ended == END_FAILED) {
+                    h *= 0.5;
+                } else if (ended == END_CONVERGED) {
+                    HLM_RCOUNT(2);
+                    double y_new[NEQ], ev[NEQ];
 #pragma unroll
-            for (int j = 0; j < Model::NF; ++j) {
-                if (j < A.nforc) {
-                    if (!(t < tb[j])) { F[j] = sample(j, tb[j]); moved = true; }
-                    t_b = fmin(t_b, tb[j]);
+                    for (int i = 0; i < NEQ; ++i) {
+                        y_new[i] = y[i] + Z[2][i];
+                        ev[i] = f0[i] + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) * inv_h;
+                    }
+                    solve_r(ev);
+                    double err = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) {
+                        const double r = fabs(ev[i]) * recip<MATH>(A.atol + A.rtol * fmax(fabs(y[i]), fabs(y_new[i])));
+                        if (r > err) err = r;
+                    }
+                    if (!(err == err)) {
+                        h *= 0.5;  // NaN estimate: treat like a failed Newton
+                    } else {
+                        const double root4 = inv_fourth_root<MATH>(err + 1e-16);
+                        const double fac = A.safety * root4;
+                        if (err <= 1.0) {
+                            while (next_q < A.nq) {
+                                const double tq = A.query[next_q];
+                                if (!(tq <= t_end)) break;
+                                const double th = (tq - t) * inv_h;
+                                double* o = dense_row + (size_t)next_q * q_stride;
+#pragma unroll
+                                for (int c = 0; c < NEQ; ++c) {
+                                    const int pc = pos(c);
+                                    if (pc < 0) continue;  // component not selected
+                                    double acc = y[c], thp = th;
+#pragma unroll
+                                    for (int m = 0; m < 3; ++m) {
+                                        acc += (PD[0][m] * Z[0][c] + PD[1][m] * Z[1][c] + PD[2][m] * Z[2][c]) * thp;
+                                        thp *= th;
+                                    }
+                                    o[(size_t)pc * c_stride] = acc;
+                                }
+                                ++next_q;
+                            }
+#pragma unroll
+                            for (int i = 0; i < NEQ; ++i) y[i] = y_new[i];
+                            t = t_end;
+                            ++n_accept;
+                            h *= fmin(fmax(fac, A.min_scale), A.max_scale);
+                            if (clipped && h < h_ctl) h = h_ctl;
+                        } else {
+                            h *= fmin(fmax(fmin(fac, 1.0), A.min_scale), A.max_scale);
+                        }
+                    }
+                }
+                ended = END_NONE;
+                // ---- set up the next attempt -----------------------------------------------------------------------
+                if (!(t < tf)) {
+                    phase = PH_DONE;
+                } else if (n_attempt >= A.cap) {
+                    capped = true;
+                    phase = PH_DONE;
+                } else {
+                    HLM_RCOUNT(0);
+                    double t_b = __builtin_inf();  // the next sample boundary of any stream
+                    if constexpr (Model::NF > 0) {
+                        bool moved = false;
+#pragma unroll
+                        for (int j = 0; j < Model::NF; ++j) {
+                            if (j < A.nforc) {
+                                if (!(t < tb[j])) { F[j] = sample(j, tb[j]); moved = true; }
+                                t_b = fmin(t_b, tb[j]);
+                            }
+                        }
+                        if (moved) FV = Model::prep_forcing(P, F);
+                    }
+                    h_ctl = h;
+                    t_end = t + h;
+                    clipped = false;
+                    if (t_end > tf) { t_end = tf; clipped = true; }
+                    if (t_end > t_b) { t_end = t_b; clipped = true; }
+                    if (clipped) h = t_end - t;
+                    ++n_attempt;
+
+                    // f0 and the Jacobian: the model's exact one-sided derivative where it supplies one, else the
+                    // reference's finite differences (approx_jacobian, radau_step_dense.cuh:13-31: 5 more RHS calls)
+                    if constexpr (Model::HAS_RHS_JACOBIAN) {
+                        Model::template rhs_jacobian<MATH>(P, FV, y, f0, Jm);  // both in one pass: shared sub-expressions once
+                    } else if constexpr (Model::HAS_JACOBIAN) {
+                        Model::template rhs<MATH>(P, FV, y, f0);
+                        Model::template jacobian<MATH>(P, FV, y, Jm);
+                    } else {
+                        Model::template rhs<MATH>(P, FV, y, f0);
+#pragma unroll
+                        for (int j = 0; j < NEQ; ++j) {
+                            double yp[NEQ], f1[NEQ];
+                            const double d = FD_EPS * fmax(1.0, fabs(y[j]));
+#pragma unroll
+                            for (int i = 0; i < NEQ; ++i) yp[i] = y[i];
+                            yp[j] += d;
+                            Model::template rhs<MATH>(P, FV, yp, f1);
+#pragma unroll
+                            for (int i = 0; i < NEQ; ++i) Jm[i][j] = (f1[i] - f0[i]) / d;
+                        }
+                    }
+                    // (g/h) I - J (Newton's real block and the error estimator) and ((a - ib)/h) I - J: LU with partial
+                    // pivoting in general; for a lower-triangular J just the reciprocals of the diagonals
+                    inv_h = recip<MATH>(h);
+                    g_h = MU_REAL * inv_h;
+                    a_h = MU_CRE * inv_h;
+                    b_h = MU_CIM * inv_h;
+                    bool ok = true;
+                    if constexpr (TRI) {
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i) {
+                            const double dr = g_h - Jm[i][i], cr = a_h - Jm[i][i];
+                            inv_r[i] = recip<MATH>(dr);
+                            const double d = recip<MATH>(cr * cr + b_h * b_h);  // 1 / ((a/h - J_ii) - i b/h)
+                            inv_cr[i] = cr * d;
+                            inv_ci[i] = b_h * d;
+                            ok = ok && fabs(dr) > 1e-300;
+                        }
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i)
+#pragma unroll
+                            for (int j = 0; j < NEQ; ++j) {
+                                Mr[i][j] = ((i == j) ? g_h : 0.0) - Jm[i][j];
+                                Cr[i][j] = ((i == j) ? a_h : 0.0) - Jm[i][j];
+                                Ci[i][j] = (i == j) ? -b_h : 0.0;
+                            }
+                        ok = lu_real(Mr, piv_r, inv_r);
+                        ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci) && ok;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) inv_sc[i] = recip<MATH>(A.atol + A.rtol * fabs(y[i]));  // the Newton increment's units
+                    // Simplified Newton on W = (TI (x) I) Z,  Z_i = Y_i - y, from Z = W = 0 -- and its FIRST iteration
+                    // right here: with Z = 0 all three stage states are y, so the three RHS evaluations of that iteration
+                    // are f0 (the same function of the same bits): the iteration costs two triangular solves and no RHS
+                    // call, 1 of a lane's 2.5 iterations per attempt, and W, Z need no zeroing.
+                    if (ok) {
+                        double d0[NEQ], d1[NEQ], d2[NEQ];
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i) {   // (TI (x) I) F with F_1 = F_2 = F_3 = f0: TI's row sums
+                            d0[i] = (TI[0][0] + TI[0][1] + TI[0][2]) * f0[i];
+                            d1[i] = (TI[1][0] + TI[1][1] + TI[1][2]) * f0[i];
+                            d2[i] = (TI[2][0] + TI[2][1] + TI[2][2]) * f0[i];
+                        }
+                        solve_r(d0);
+                        solve_c(d1, d2);
+                        double nrm = 0.0, chk = 0.0;
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i) {
+                            chk += d0[i] + d1[i] + d2[i];
+                            W[0][i] = d0[i];
+                            W[1][i] = d1[i];
+                            W[2][i] = d2[i];
+                            const double r = fmax(fmax(fabs(d0[i]), fabs(d1[i])), fabs(d2[i])) * inv_sc[i];
+                            if (r > nrm) nrm = r;
+#pragma unroll
+                            for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = T[s2][0] * W[0][i] + T[s2][1] * W[1][i] + T[s2][2] * W[2][i];
+                        }
+                        HLM_RCOUNT(1);
+                        prev = nrm;
+                        it = 1;
+                        if (!(chk - chk == 0.0)) ended = END_FAILED;          // a NaN / Inf increment
+                        else if (nrm <= NEWTON_TOL) ended = END_CONVERGED;    // (stays in PH_SETUP: the next section finishes it)
+                        else phase = PH_NEWTON;
+                    } else {
+                        ended = END_FAILED;  // a singular block: as a Newton that did not converge (h / 2, next section)
+                    }
                 }
             }
-            if (moved) FV = Model::prep_forcing(P, F);
         }
-        const double h_ctl = h;
-        double t_end = t + h;
-        bool clipped = false;
-        if (t_end > tf) { t_end = tf; clipped = true; }
-        if (t_end > t_b) { t_end = t_b; clipped = true; }
-        if (clipped) h = t_end - t;
-        ++n_attempt;
-
-        // f0 and the Jacobian: the model's exact one-sided derivative where it supplies one, else the
-        // reference's finite differences (approx_jacobian, radau_step_dense.cuh:13-31: 5 more RHS calls)
-        double f0[NEQ], Jm[NEQ][NEQ];
-        Model::template rhs<MATH>(P, FV, y, f0);
-        if constexpr (Model::HAS_JACOBIAN) {
-            Model::template jacobian<MATH>(P, FV, y, Jm);
-        } else {
-#pragma unroll
-            for (int j = 0; j < NEQ; ++j) {
-                double yp[NEQ], f1[NEQ];
-                const double d = FD_EPS * fmax(1.0, fabs(y[j]));
-#pragma unroll
-                for (int i = 0; i < NEQ; ++i) yp[i] = y[i];
-                yp[j] += d;
-                Model::template rhs<MATH>(P, FV, yp, f1);
-#pragma unroll
-                for (int i = 0; i < NEQ; ++i) Jm[i][j] = (f1[i] - f0[i]) / d;
-            }
-        }
-        // (g/h) I - J (Newton's real block and the error estimator) and ((a - ib)/h) I - J: LU with partial
-        // pivoting in general; for a lower-triangular J just the reciprocals of the diagonals
-        constexpr bool TRI = Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR;
-        [[maybe_unused]] double Mr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Cr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Ci[TRI ? 1 : NEQ][TRI ? 1 : NEQ];
-        double inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
-        [[maybe_unused]] int piv_r[NEQ], piv_c[NEQ];
-        const double inv_h = recip<MATH>(h);
-        const double g_h = MU_REAL * inv_h, a_h = MU_CRE * inv_h, b_h = MU_CIM * inv_h;
-        bool ok = true;
-        if constexpr (TRI) {
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) {
-                const double dr = g_h - Jm[i][i], cr = a_h - Jm[i][i];
-                inv_r[i] = recip<MATH>(dr);
-                const double d = recip<MATH>(cr * cr + b_h * b_h);  // 1 / ((a/h - J_ii) - i b/h)
-                inv_cr[i] = cr * d;
-                inv_ci[i] = b_h * d;
-                ok = ok && fabs(dr) > 1e-300;
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i)
-#pragma unroll
-                for (int j = 0; j < NEQ; ++j) {
-                    Mr[i][j] = ((i == j) ? g_h : 0.0) - Jm[i][j];
-                    Cr[i][j] = ((i == j) ? a_h : 0.0) - Jm[i][j];
-                    Ci[i][j] = (i == j) ? -b_h : 0.0;
-                }
-            ok = lu_real(Mr, piv_r, inv_r);
-            ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci) && ok;
-        }
-        auto solve_r = [&](double (&b)[NEQ]) {
-            if constexpr (TRI) solve_real_tri(Jm, inv_r, b); else solve_real(Mr, piv_r, inv_r, b);
-        };
-        auto solve_c = [&](double (&br)[NEQ], double (&bi)[NEQ]) {
-            if constexpr (TRI) solve_cplx_tri(Jm, inv_cr, inv_ci, br, bi); else solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, br, bi);
-        };
-
-        // simplified Newton on W = (TI (x) I) Z,  Z_i = Y_i - y
-        double Z[NS][NEQ], W[NS][NEQ];
-#pragma unroll
-        for (int s = 0; s < NS; ++s)
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) Z[s][i] = W[s][i] = 0.0;
-        double inv_sc[NEQ];  // 1 / (atol + rtol |y_i|): the Newton increment is measured in these units
-#pragma unroll
-        for (int i = 0; i < NEQ; ++i) inv_sc[i] = recip<MATH>(A.atol + A.rtol * fabs(y[i]));
-        bool converged = false;
-        double prev = __builtin_inf();
-#pragma unroll 1
-        for (int it = 0; ok && it < NEWTON_MAXITER; ++it) {
+        if (phase == PH_NEWTON) {
             HLM_RCOUNT(1);
             double Fs[NS][NEQ], d0[NEQ], d1[NEQ], d2[NEQ];
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
+            for (int s2 = 0; s2 < NS; ++s2) {
                 double Y[NEQ];
 #pragma unroll
-                for (int i = 0; i < NEQ; ++i) Y[i] = y[i] + Z[s][i];
-                Model::template rhs<MATH>(P, FV, Y, Fs[s]);
+                for (int i = 0; i < NEQ; ++i) Y[i] = y[i] + Z[s2][i];
+                Model::template rhs<MATH>(P, FV, Y, Fs[s2]);
             }
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) {
@@ -441,62 +600,22 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 const double r = fmax(fmax(fabs(d0[i]), fabs(d1[i])), fabs(d2[i])) * inv_sc[i];
                 if (r > nrm) nrm = r;
 #pragma unroll
-                for (int s = 0; s < NS; ++s) Z[s][i] = T[s][0] * W[0][i] + T[s][1] * W[1][i] + T[s][2] * W[2][i];
+                for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = T[s2][0] * W[0][i] + T[s2][1] * W[1][i] + T[s2][2] * W[2][i];
             }
-            if (!(chk - chk == 0.0)) break;          // a NaN / Inf increment
-            if (it > 0 && nrm > 2.0 * prev) break;   // diverging
-            prev = nrm;
-            if (nrm <= NEWTON_TOL) { converged = true; break; }
-        }
-        if (!converged) { h *= 0.5; continue; }
-
-        HLM_RCOUNT(2);
-        double y_new[NEQ], ev[NEQ];
-#pragma unroll
-        for (int i = 0; i < NEQ; ++i) {
-            y_new[i] = y[i] + Z[2][i];
-            ev[i] = f0[i] + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) * inv_h;
-        }
-        solve_r(ev);
-        double err = 0.0;
-#pragma unroll
-        for (int i = 0; i < NEQ; ++i) {
-            const double r = fabs(ev[i]) * recip<MATH>(A.atol + A.rtol * fmax(fabs(y[i]), fabs(y_new[i])));
-            if (r > err) err = r;
-        }
-        if (!(err == err)) { h *= 0.5; continue; }  // NaN estimate: treat like a failed Newton
-        // (1 / (err + 1e-16))^(1/4): two square roots in FAST, pow as the oracle writes it in STRICT
-        double root4;
-        if constexpr (MATH == MATH_FAST) root4 = sqrt(sqrt(recip<MATH>(err + 1e-16))); else root4 = pow(1.0 / (err + 1e-16), 0.25);
-        const double fac = A.safety * root4;
-        if (err <= 1.0) {
-            while (next_q < A.nq) {
-                const double tq = A.query[next_q];
-                if (!(tq <= t_end)) break;
-                const double th = (tq - t) * inv_h;
-                double* o = dense_row + (size_t)next_q * q_stride;
-#pragma unroll
-                for (int c = 0; c < NEQ; ++c) {
-                    const int pc = pos(c);
-                    if (pc < 0) continue;  // component not selected
-                    double acc = y[c], thp = th;
-#pragma unroll
-                    for (int m = 0; m < 3; ++m) {
-                        acc += (PD[0][m] * Z[0][c] + PD[1][m] * Z[1][c] + PD[2][m] * Z[2][c]) * thp;
-                        thp *= th;
-                    }
-                    o[(size_t)pc * c_stride] = acc;
-                }
-                ++next_q;
+            // the exits of the nested Newton loop, in its order
+            int end = END_NONE;
+            if (!(chk - chk == 0.0)) end = END_FAILED;                 // a NaN / Inf increment
+            else if (it > 0 && nrm > 2.0 * prev) end = END_FAILED;     // diverging
+            else {
+                prev = nrm;
+                if (nrm <= NEWTON_TOL) end = END_CONVERGED;
+                else if (it + 1 >= NEWTON_MAXITER) end = END_FAILED;   // out of iterations
             }
-#pragma unroll
-            for (int i = 0; i < NEQ; ++i) y[i] = y_new[i];
-            t = t_end;
-            ++n_accept;
-            h *= fmin(fmax(fac, A.min_scale), A.max_scale);
-            if (clipped && h < h_ctl) h = h_ctl;
-        } else {
-            h *= fmin(fmax(fmin(fac, 1.0), A.min_scale), A.max_scale);
+            ++it;
+            if (end != END_NONE) {
+                ended = end;
+                phase = PH_SETUP;
+            }
         }
     }
 

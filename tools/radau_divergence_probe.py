@@ -19,7 +19,7 @@ sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns)
 cells = synth.cell_of_system(0, ns)
 pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
 for mode in (True, "continue"):
-    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp)
+    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, queue_run_pieces=1)
     eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     eng.integrate(radau=mode)
     torch.cuda.synchronize()
@@ -29,7 +29,7 @@ for mode in (True, "continue"):
     e0.record(); eng.integrate(radau=mode); e1.record(); torch.cuda.synchronize()
     L.hlm_debug_radau_counters(out)
     w = list(out)
-    names = ("step attempts", "Newton iterations", "accepted-step tails")
+    names = ("step attempts", "Newton iterations", "accepted-step tails", "state-machine trips")
     print(f"mode {mode}: RK45 + Radau {e0.elapsed_time(e1):.1f} ms (with counters)")
     for k, n in enumerate(names):
         if w[2 * k]:
