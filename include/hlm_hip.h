@@ -135,7 +135,7 @@ int hlm_set_forcings(const float* d_forc, const double* dt_hours, const uint64_t
 /* Alternative registration for the host API: the forcing series stay in HOST memory
  * (h_tables[j]: float [nT[j]][ld]; the pointers must stay valid until hlm_clear_forcings) and
  * hlm_launch_rk45_kernel / hlm_run_rk45 stream them through HBM in chunks of chunk_minutes
- * (hlm_rk45_integrate_forcing_streamed). */
+ * (hlm_rk45_integrate_forcing_streamed; chunk_minutes < 0: its growing chunks). */
 int hlm_set_forcings_host(const float* const* h_tables, const double* dt_hours, const uint64_t* nT,
                           int nforc, int64_t ld, const int32_t* d_col, double chunk_minutes);
 int hlm_clear_forcings(void);
@@ -357,7 +357,11 @@ int hlm_run_rk45_streamed(int uid, const double* h_y0, int num_systems, double t
  * is cut into chunks of chunk_minutes; while chunk k integrates on `hip_stream` (hillslopes
  * pause at its end time), the sample rows chunk k+1 needs are uploaded on a second stream into
  * the other of two device buffers.  Results are bit-identical to the run with all forcings
- * resident.  Synchronous.  *chunks (nullable) receives the number of launches. */
+ * resident.  Synchronous.  *chunks (nullable) receives the number of launches.
+ * chunk_minutes < 0 (ABI 4): GROWING chunks -- the first |chunk_minutes| long, each next one twice as long up to 8 x
+ * (1, 2, 4, 8, 8, ... days for -1440): only the first, short upload is not hidden behind an integration, and the
+ * long chunks run in the queue kernel's launch shape (hlm_device_job.time_pieces, pieces cut from the chunk) instead
+ * of one launch per day.  The two device buffers then hold the longest chunk each. */
 int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* const* h_tables,
                                         double chunk_minutes, void* hip_stream, int* chunks);
 

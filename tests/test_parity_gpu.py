@@ -1461,7 +1461,13 @@ def test_streamed_forcings_keep_the_rows_of_lanes_that_finished_early(gpu, case,
         eng.y_final.zero_()
         eng.dense.fill_(-7.0)
         n = method((pr, t2m), dt, chunk, cells=cells)
-        assert n == int(np.ceil(tf / chunk))
+        if chunk > 0:
+            assert n == int(np.ceil(tf / chunk))
+        else:   # growing: 1, 2, 4, 8, 8, ... base chunks per launch
+            left, length, expect = int(np.ceil(tf / -chunk)), 1, 0
+            while left > 0:
+                left, expect, length = left - length, expect + 1, min(2 * length, 8)
+            assert n == expect, (n, expect)
         got = eng.results()
         for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
             assert np.array_equal(got[k], ref[k]), (method.__name__, k)
@@ -1474,19 +1480,24 @@ def test_streamed_forcings_keep_the_rows_of_lanes_that_finished_early(gpu, case,
 
 
 @pytest.mark.parametrize("layout", ["per-cell", "per-stream"])
-@pytest.mark.parametrize("case", ["hourly-chunks", "odd-chunks", "daily-chunks-cold", "two-chunks", "sub-wave"])
+@pytest.mark.parametrize("case", ["hourly-chunks", "odd-chunks", "daily-chunks-cold", "two-chunks", "sub-wave", "growing-cold", "growing-odd",
+                                  "four-day-chunks"])
 def test_streamed_forcings_without_dense_output(gpu, layout, case):
     """hlm_rk45_integrate_forcing_streamed without dense output (BASELINE config 3 as worded; what bench.py's
     variant_forcings_streamed times): finals, flags and counters equal the run with all forcings resident bit for
     bit -- 120 hourly chunks, chunk edges inside forcing hours on 70 001 hillslopes, cold cells (hillslopes flagged
     in different chunks, 66 000 of them), two chunks, fewer hillslopes than a wave; whatever launch shape the job
-    asks for (the chunk launches are RESUMABLE ones, one wave per tile: time_pieces does not apply to them)."""
+    asks for.  Short chunks are RESUMABLE launches, one wave per tile; chunks of four days and more run in the queue
+    kernel's shape with the lanes in the caller's state record (round 4) -- "growing" = chunk_minutes < 0: chunks of 1,
+    2, 4, 8, 8, ... times the base length (13 days of cold cells: 1 + 2 + 4 + 6 days; a base of 433 minutes that ends
+    chunks inside forcing hours), and uniform four-day chunks."""
     H = gpu
     from tiger_hlm_gpu_amd import synth
     from tiger_hlm_gpu_amd.engine import ShardEngine
     ns, days, chunk, tmin = {"hourly-chunks": (5000, 5, 60.0, 0.5), "odd-chunks": (70_001, 3, 433.0, 0.5),
                              "daily-chunks-cold": (66_000, 6, 1440.0, -5.0), "two-chunks": (3000, 2, 1500.0, 0.5),
-                             "sub-wave": (40, 3, 777.0, -5.0)}[case]
+                             "sub-wave": (40, 3, 777.0, -5.0), "growing-cold": (20_000, 13, -1440.0, -5.0),
+                             "growing-odd": (9000, 9, -433.0, 0.5), "four-day-chunks": (8000, 10, 5760.0, -5.0)}[case]
     tf = days * 1440.0
     sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns, wet_surface=(case == "odd-chunks"))
     cells = synth.cell_of_system(0, ns, run_len=64)
@@ -1499,7 +1510,13 @@ def test_streamed_forcings_without_dense_output(gpu, layout, case):
         eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, time_pieces=pieces)
         eng.y_final.fill_(-3.0)
         n = eng.integrate_forcing_streamed_abi(tables, dt, chunk, cells=cells if layout == "per-cell" else None)
-        assert n == int(np.ceil(tf / chunk))
+        if chunk > 0:
+            assert n == int(np.ceil(tf / chunk))
+        else:   # growing: 1, 2, 4, 8, 8, ... base chunks per launch
+            left, length, expect = int(np.ceil(tf / -chunk)), 1, 0
+            while left > 0:
+                left, expect, length = left - length, expect + 1, min(2 * length, 8)
+            assert n == expect, (n, expect)
         got = eng.results()
         for k in ("y_final", "stiff", "n_attempt", "n_accept"):
             assert np.array_equal(got[k], ref[k]), (case, layout, pieces, k)

@@ -475,12 +475,17 @@ hlm::QueueRuns make_queue_runs(int pieces, long long tiles, long long resident, 
 }
 
 // Persistent launch over a queue of (run of time pieces, tile) items (hlm_rk45_queue_kernel.h): as many one-wave
-// workgroups as the device holds at once; the lane states between the runs live in a stream-ordered scratch allocation.
-int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
+// workgroups as the device holds at once; the lane states between the runs live in a stream-ordered scratch allocation
+// -- or, for a launch that integrates the window [w0, w1] of a longer run (w1 < tf: lanes pause there; resume_in: they
+// come from an earlier window), in the caller's state record j->d_resume, where the next window's launch finds them.
+// forc_first: the forcing block holds the sample rows from forc_first[k] on (a time chunk of the series): the block's
+// base is biased so that the plain row arithmetic of the kernel lands in it.
+int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double w0, double w1, bool windowed)
 {
     const bool fixed = j->fixed_step > 0.0;
     QueueFn fn = pick_queue(j->uid, j->math_mode, fixed);
     if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
+    if (windowed && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "a window launch needs d_resume");
     int dev = 0, cus = 0, per_cu = 0;
     HLM_HIP_TRY(hipGetDevice(&dev));
     HLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -488,8 +493,8 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
     const long long resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
     const long long tiles = ((long long)j->num_systems + hlm::WAVE - 1) / hlm::WAVE;
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
-    const size_t rbytes = (hlm_resume_bytes_model(j->uid, j->num_systems) + 15u) & ~(size_t)15u;
-    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + 2);  // next item | finished pieces per tile | abort word
+    const size_t rbytes = windowed ? 0 : (hlm_resume_bytes_model(j->uid, j->num_systems) + 15u) & ~(size_t)15u;
+    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + 2);  // next item | finished runs per tile | abort word
     char* pool = nullptr;
     HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + qbytes, stream));
     unsigned int* queue = reinterpret_cast<unsigned int*>(pool + rbytes);
@@ -502,19 +507,36 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream)
         }
     }
     hlm::Rk45Args a = make_args(j);
-    a.resume = reinterpret_cast<double*>(pool);
+    if (windowed) {
+        a.resume = static_cast<double*>(j->d_resume);
+        a.resume_in = j->resume_in;
+        a.t_stop = w1 < j->tf ? w1 : __builtin_inf();
+        unsigned long long base = 0;   // the chunk's rows: bias every forcing's base by its first row (unsigned wrap-around)
+        for (int k = 0; k < j->nforc; ++k) {
+            const unsigned long long rows = j->forc_rows[k] ? j->forc_rows[k] : j->forc_nT[k];
+            if (k < hlm::HLM_KERNEL_MAX_NF) a.forc_base[k] = base - j->forc_first_index[k] * (unsigned long long)j->forc_ld;
+            base += rows * (unsigned long long)j->forc_ld;
+        }
+    } else {
+        a.resume = reinterpret_cast<double*>(pool);
+        a.resume_in = 0;
+        a.t_stop = __builtin_inf();
+    }
 #ifdef HLM_QUEUE_DEBUG
     g_debug_queue_pool = pool;
     g_debug_queue_rbytes = rbytes;
     g_debug_queue_qbytes = qbytes;
 #endif
-    const hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, j->queue_run_pieces);
+    hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, j->queue_run_pieces);
+    runs.t_begin = w0;
+    runs.piece_len = (w1 - w0) / (double)pieces;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, pieces, runs);
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(pool, stream));  // stream-ordered: after the kernel
     HLM_HIP_TRY(launched);
     return HLM_SUCCESS;
 }
+int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream) { return launch_queue(j, pieces, stream, j->t0, j->tf, false); }
 
 // pieces of the queue kernel this job launches with; 0 = the fixed map (or lane refill)
 int job_time_pieces(const hlm_device_job* j)
@@ -824,7 +846,7 @@ int hlm_set_forcings(const float* d_forc, const double* dt_hours, const uint64_t
 int hlm_set_forcings_host(const float* const* h_tables, const double* dt_hours, const uint64_t* nT, int nforc,
                           int64_t ld, const int32_t* d_col, double chunk_minutes)
 {
-    if (nforc <= 0 || nforc > HLM_MAX_FORCINGS || !h_tables || !dt_hours || !nT || ld <= 0 || !(chunk_minutes > 0.0))
+    if (nforc <= 0 || nforc > HLM_MAX_FORCINGS || !h_tables || !dt_hours || !nT || ld <= 0 || !(chunk_minutes > 0.0 || chunk_minutes < 0.0))
         return fail(HLM_ERR_INVALID_ARGUMENT, "set_forcings_host: need 1..%d host tables, dt, nT, ld > 0, chunk > 0", HLM_MAX_FORCINGS);
     ForcingState F;
     F.d_col = d_col;
@@ -1161,7 +1183,15 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
                                         double chunk_minutes, void* hip_stream, int* chunks)
 {
     if (!job || !h_tables) return fail(HLM_ERR_INVALID_ARGUMENT, "job / h_tables is NULL");
-    if (!(chunk_minutes > 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "chunk_minutes must be > 0");
+    // chunk_minutes < 0: GROWING chunks -- the first one |chunk_minutes| long, every next one twice as long up to eight
+    // times that (1, 2, 4, 8, 8, ... days for -1440): the first upload, which nothing overlaps, stays short, every later
+    // one (PCIe: ~1.8 ms per day of a 1 M-hillslope per-stream series) hides behind the previous chunk's integration
+    // (~4.3 ms per day), and the long chunks run as launches of the queue kernel (its pieces cut from the chunk)
+    // instead of one fixed-map launch per day: 6 launches instead of 30 for a 30-day window.  Device memory: two
+    // buffers of the longest chunk.
+    const bool growing = chunk_minutes < 0.0;
+    if (growing) chunk_minutes = -chunk_minutes;
+    if (!(chunk_minutes > 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "chunk_minutes must be > 0 (or < 0: growing chunks)");
     if (job->nforc <= 0) return fail(HLM_ERR_INVALID_ARGUMENT, "no forcings to stream");
     for (int k = 0; k < job->nforc; ++k)
         if (!h_tables[k]) return fail(HLM_ERR_INVALID_ARGUMENT, "h_tables[%d] is NULL", k);
@@ -1181,6 +1211,17 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
     // chunk edges and, per chunk and forcing, the sample rows any t in [ta, tb] can ask for
     std::vector<double> edge;
     if (const int rce = chunk_edges(job->t0, job->tf, chunk_minutes, &edge, "integrate_forcing_streamed"); rce != HLM_SUCCESS) return rce;
+    if (growing && edge.size() > 2) {  // keep the edges 0, 1, 3, 7, 15, 23, ... of the uniform grid
+        std::vector<double> g(1, edge[0]);
+        size_t at = 0, len = 1;
+        while (at + len < edge.size() - 1) {
+            at += len;
+            g.push_back(edge[at]);
+            if (len < 8) len *= 2;
+        }
+        g.push_back(edge.back());
+        edge.swap(g);
+    }
     const int nchunk = (int)edge.size() - 1;
     if (nchunk <= 0) return launch(&probe, static_cast<hipStream_t>(hip_stream)) /* tf <= t0: nothing to integrate */;
     auto span = [&](int j, double ta, double tb, uint64_t* first, uint64_t* rows) {
@@ -1230,7 +1271,17 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
         j.resume_in = k > 0;
         j.use_t_stop = edge[k + 1] < job->tf;
         j.t_stop = edge[k + 1];
-        if (e == hipSuccess) rc = launch(&j, compute);
+        // a chunk long enough for the queue kernel's pieces (the automatic rule on the chunk: from 4 096 hillslopes and
+        // four days on) runs in its shape, lanes from and to the same state record; shorter ones one wave per tile
+        // (growing chunks: every chunk, also the short first ones, in 16 pieces -- measured on the headline workload:
+        // 134.5 ms against 135.2 ms with the twelve-hour rule and 135.4 ms with 8; profiles/r04_streamed_probe.txt)
+        int pieces = 0;
+        if (j.num_queries == 0 && !j.lane_refill) {
+            if (j.time_pieces >= 0) pieces = growing ? j.time_pieces : 0;
+            else if (growing) pieces = j.num_systems >= 4096 ? 16 : 0;
+            else pieces = auto_time_pieces(j.num_systems, edge[k], edge[k + 1]);
+        }
+        if (e == hipSuccess) rc = pieces > 1 ? launch_queue(&j, pieces, compute, edge[k], edge[k + 1], true) : launch(&j, compute);
         ok(hipEventRecord(consumed[b], compute));
     }
     if (e == hipSuccess) ok(hipStreamSynchronize(compute));
@@ -1563,7 +1614,7 @@ int hlm_launch_rk45_kernel(int uid, const hlm_gpu_buffers* b, double t0, double 
     j.d_stiff = b->d_stiff;
     j.d_n_attempt = b->d_n_attempt;
     j.d_n_accept = b->d_n_accept;
-    const bool streamed = chunk_minutes > 0.0 && model_nf(uid) > 0;
+    const bool streamed = chunk_minutes != 0.0 && model_nf(uid) > 0;
     if (streamed && radau)
         return fail(HLM_ERR_INVALID_ARGUMENT, "the Radau fallback needs the forcing series resident in HBM "
                                               "(hlm_set_forcings), not streamed in time chunks");
@@ -1677,7 +1728,7 @@ int hlm_run_rk45_streamed(int uid, const double* h_y0, int ns, double t0, double
         if (slot->in_flight)
             return cleanup(fail(HLM_ERR_STATE, "another host-API integration is running on this device with the same forcing registration"));
         if (g_radau) return cleanup(fail(HLM_ERR_INVALID_ARGUMENT, "run_rk45_streamed cannot be combined with the Radau fallback"));
-        if (slot->f.chunk_minutes > 0.0 && model_nf(uid) > 0)
+        if (slot->f.chunk_minutes != 0.0 && model_nf(uid) > 0)
             return cleanup(fail(HLM_ERR_INVALID_ARGUMENT, "run_rk45_streamed needs the forcings resident in HBM (hlm_set_forcings)"));
         const int rc0 = fill_job_from_registry(&j, uid, slot->f);
         if (rc0 != HLM_SUCCESS) return cleanup(rc0);

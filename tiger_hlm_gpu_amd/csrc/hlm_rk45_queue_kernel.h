@@ -80,6 +80,10 @@ struct QueueRuns {
     int nruns;
     int uniform;                      // > 0: every run has this many pieces (the last one what is left); else begin_[]
     int begin_[QUEUE_MAX_RUNS + 1];   // begin_[nruns] = the number of pieces
+    // the pieces: piece c ends at t_begin + (c + 1) piece_len, the last one at min(tf, A.t_stop).  A plain launch cuts
+    // [t0, tf]; a launch that integrates a WINDOW of it (time chunks of streamed forcings: lanes come from and go back
+    // to the caller's state record, Rk45Args.resume / resume_in / t_stop) cuts the window
+    double t_begin, piece_len;
     __host__ __device__ int begin(int r, int npieces) const
     {
         if (uniform > 0) { const long long b = (long long)r * uniform; return b < npieces ? (int)b : npieces; }
@@ -113,7 +117,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
     unsigned int* const done = queue + 1;
     int* const resume_i = reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns);
     const double tf = A.tf;
-    const double piece = (tf - A.t0) / (double)nchunk;
+    const double w_end = fmin(tf, A.t_stop);   // (t_stop = +inf unless the launch integrates a window)
 
     // Every step of the queue protocol below is written WITHOUT a branch on the lane number: all 64 lanes issue the
     // draw (lane 0 adds 1, the others 0: one atomic per wave after the compiler's wave-level combining), all poll the
@@ -171,7 +175,8 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         } else if (sys < A.ns) {
             int status = HLM_SYS_OK;
             bool runs = true;
-            if (r > 0) {
+            const bool from_record = r > 0 || A.resume_in != 0;   // else: this launch starts the hillslopes at (t0, y0)
+            if (from_record) {
                 status = coherent_load(&resume_i[(size_t)4 * A.ns + sys]);
                 runs = status == SYS_PAUSED;  // else: finished or flagged in an earlier piece, its outputs were written then
                 if (runs) status = HLM_SYS_OK;
@@ -192,7 +197,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 double h = FIXED ? A.fixed_step : A.h0;
                 int reject_count = 0;
                 uint32_t n_attempt = 0, n_accept = 0;
-                if (r == 0) {
+                if (!from_record) {
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
                 } else {
@@ -213,9 +218,9 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 // ---- the loop of rk45_multi_kernel, piece by piece --------------------------------------------
                 // lanes pause the first time t reaches the end of their piece (the last piece runs to tf) and go on
                 // together with the next piece of the run: the protocol of a hand-over, without the hand-over
-                double t_end = tf;
+                double t_end = w_end;
                 for (unsigned c = c_begin; c < c_end; ++c) {
-                    t_end = c + 1u < (unsigned)nchunk ? fmin(tf, A.t0 + (double)(c + 1u) * piece) : tf;
+                    t_end = c + 1u < (unsigned)nchunk ? fmin(w_end, R.t_begin + (double)(c + 1u) * R.piece_len) : w_end;
                     while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
                         if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
                         if (held.refresh(A, P, t, FV)) have_k0 = false;

@@ -31,7 +31,7 @@ want = ref.results()
 del ref
 torch.cuda.empty_cache()
 for pieces in [int(x) if x != "auto" else None for x in os.environ.get("HLM_PROBE_PIECES", "auto").split(",")]:
-    for chunk in (1440.0,) if os.environ.get("HLM_PROBE_SHORT") else (1440.0, 2880.0, 720.0):
+    for chunk in (1440.0,) if os.environ.get("HLM_PROBE_SHORT") else (1440.0, -1440.0, -720.0, -2880.0, 5760.0, 11520.0):
         eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, time_pieces=pieces)
         for rep in range(3):
             torch.cuda.synchronize()
