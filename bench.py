@@ -93,6 +93,8 @@ def parse():
     ap.add_argument("--time-pieces", type=int, default=-1,
                     help="launch shape of the pass without dense output (hlm_device_job.time_pieces): > 1 = persistent grid "
                          "over (time piece, tile) items, 0 = one wave per tile (the reference's map), -1 = the library's automatic rule")
+    ap.add_argument("--queue-run-pieces", type=int, default=0,
+                    help="hlm_device_job.queue_run_pieces: 0 automatic runs of pieces per queue item, 1 every piece handed over")
     ap.add_argument("--lane-refill", action="store_true",
                     help="persistent grid with lane refill (a lane whose hillslope is finished or flagged takes the next one)")
     ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
@@ -146,7 +148,8 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
     eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q,
                       math_mode=H.MATH_FAST if (math or args.math) == "fast" else H.MATH_STRICT,
                       device=f"cuda:{torch.cuda.current_device()}", dense_tiled=args.dense_tiled,
-                      lane_refill=args.lane_refill, time_pieces=None if args.time_pieces < 0 else args.time_pieces)
+                      lane_refill=args.lane_refill, time_pieces=None if args.time_pieces < 0 else args.time_pieces,
+                      queue_run_pieces=args.queue_run_pieces)
     if args.layout == "per-stream":
         eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     else:
@@ -185,7 +188,7 @@ def _issue_fields(per_gpu_key):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
+    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (f";runs={args.queue_run_pieces}" if args.queue_run_pieces else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
     return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
@@ -934,6 +937,16 @@ def main():
                     res["flagged_fraction"] = float((e.stiff == 1).sum().item()) / e.ns
                 else:
                     res[tag]["unsolved_after"] = int((e.stiff == 2).sum().item())
+            for tag in ("rk45_plus_radau", "rk45_plus_radau_continue"):
+                res[tag]["implicit_attempts"] = res[tag]["attempts"] - res["rk45"]["attempts"]
+            res["rk45_plus_radau_continue"]["note"] = ("build option: every flagged hillslope continues from the state RK45 reached "
+                                                       "(the reference's kernel, and rk45_plus_radau, restart it at t0)")
+            import copy
+            ca = copy.copy(args)
+            ca.tmin, ca.queue_run_pieces = -5.0, 1
+            res["rk45"].update(_issue_fields(_per_gpu_key(ca, 0, e.ns)))   # active lanes per VALU instruction of the RK45 pass etc.
+            if not H.api.has_experimental_paths():   # (compaction between launches is a quarantined path: EXPERIMENTAL=1 builds)
+                return res
             # the same RK45 pass in one-day launches with the survivors compacted between them (bit-identical)
             e.integrate_compacting(1440.0)
             torch.cuda.synchronize()
@@ -944,14 +957,6 @@ def main():
             torch.cuda.synchronize()
             res["rk45_compacting"] = {"ms": a.elapsed_time(b), "launches": nl, "interval_minutes": 1440.0,
                                       "steps_per_s": res["rk45"]["attempts"] / (a.elapsed_time(b) * 1e-3)}
-            for tag in ("rk45_plus_radau", "rk45_plus_radau_continue"):
-                res[tag]["implicit_attempts"] = res[tag]["attempts"] - res["rk45"]["attempts"]
-            res["rk45_plus_radau_continue"]["note"] = ("build option: every flagged hillslope continues from the state RK45 reached "
-                                                       "(the reference's kernel, and rk45_plus_radau, restart it at t0)")
-            import copy
-            ca = copy.copy(args)
-            ca.tmin = -5.0
-            res["rk45"].update(_issue_fields(_per_gpu_key(ca, 0, e.ns)))   # active lanes per VALU instruction of the RK45 pass etc.
             return res
         out["variant_survey_c3_cold_cells"] = _optional(_cold)
         torch.cuda.empty_cache()

@@ -79,6 +79,13 @@ typedef struct hlm_spatial_params {
 
 /* ---- library / device ------------------------------------------------------------ */
 int hlm_abi_version(void);
+/* Bit mask of optional parts compiled into this library.  HLM_BUILD_EXPERIMENTAL_PATHS: the launch paths that lost on
+ * every workload measured so far and are quarantined by default (make -C tiger_hlm_gpu_amd/csrc EXPERIMENTAL=1):
+ * lane refill (hlm_set_lane_refill / hlm_device_job.lane_refill), compaction between launches
+ * (hlm_rk45_integrate_compacting), the tile-row dense layout (dense_tiled = 1, hlm_set_stream_path(1)).  Without the
+ * bit those entry points return HLM_ERR_INVALID_ARGUMENT. */
+#define HLM_BUILD_EXPERIMENTAL_PATHS 1
+int hlm_build_flags(void);
 const char* hlm_last_error(void);
 int hlm_device_count(int* count);
 int hlm_set_device(int device); /* main.cpp:314-319 cudaSetDevice */

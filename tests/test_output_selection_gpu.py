@@ -47,6 +47,9 @@ def _engine(H, case, days, **kw):
 @pytest.mark.parametrize("math_mode", [0, 1])
 @pytest.mark.parametrize("layout", [0, 1, 2])
 def test_selected_rows_in_every_device_layout_vs_oracle_and_vs_the_full_run(gpu, oracle, layout, math_mode):
+    if layout == 1:
+        from conftest import need_experimental_paths
+        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     days = 2
@@ -76,6 +79,9 @@ def test_selected_rows_in_every_device_layout_vs_oracle_and_vs_the_full_run(gpu,
 @pytest.mark.parametrize("path", ["copy-engine", "transfer-kernel", "transfer-kernel-tile-row", "pageable"])
 @pytest.mark.parametrize("window", [1, 37, 1000])
 def test_selected_rows_streamed_in_windows_equal_one_shot(gpu, window, path):
+    if path == "transfer-kernel-tile-row":
+        from conftest import need_experimental_paths
+        need_experimental_paths(gpu)
     H = gpu
     days = 2
     case = _case(H, ns=300, days=days)
@@ -319,6 +325,9 @@ def test_selection_on_the_three_state_model(gpu, layout):
     """The selecting kernels are templates over Model::N_EQ like everything else: ToyModel3 (N_EQ = 3, one forcing),
     every proper subset, all layouts and the Radau pass on its general (pivoted LU) route -- the selected columns of
     the full run, bit for bit."""
+    if layout == 1:
+        from conftest import need_experimental_paths
+        need_experimental_paths(gpu)
     H = gpu
     from test_parity_gpu import _toy_case
     from tiger_hlm_gpu_amd import synth

@@ -274,10 +274,17 @@ def engine(mode, atol):
 # default parameters, no mode chosen: the FAST kernel's bits
 a = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5)
 assert np.array_equal(a, engine(H.MATH_FAST, 1e-9)) and not np.array_equal(a, engine(H.MATH_STRICT, 1e-9))
-# lane refill through the host API: same bits
-H.api.set_lane_refill(True)
-assert np.array_equal(H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5), a)
-H.api.set_lane_refill(False)
+# lane refill through the host API (a quarantined path: only in EXPERIMENTAL=1 builds): same bits -- else refused
+if H.api.has_experimental_paths():
+    H.api.set_lane_refill(True)
+    assert np.array_equal(H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5), a)
+    H.api.set_lane_refill(False)
+else:
+    try:
+        H.api.set_lane_refill(True)
+        raise SystemExit("expected a refusal")
+    except H.HlmError as e:
+        assert "HLM_EXPERIMENTAL_PATHS" in str(e)
 # atol = 0: still no mode chosen -> STRICT by itself
 H.api.set_model_parameters(H.Model204, H.Parameters(0.01, 1e-6, 0.0, 0.9, 0.2, 10.0))
 b = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5)
@@ -671,6 +678,9 @@ def test_streamed_dense_equals_one_shot_bitwise(gpu, window, path):
     """The windowed run pauses a lane before it commits a step whose queries cross the
     window end and redoes that attempt in the next launch, so finals, flags, counters and
     every dense value equal the one-shot run bit for bit, for any window size."""
+    if path == "transfer-kernel-tile-row":
+        from conftest import need_experimental_paths
+        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     ns, days = 300, 2
@@ -942,6 +952,8 @@ def test_lane_refill_is_bit_identical_to_the_fixed_map(gpu, case):
     (rk45_kernel.cu:33) bit for bit -- with early-flagged cold cells (lanes refill at different times),
     on the benchmark workload (whole waves refill at once; 300 000 hillslopes = more than the 196 608 the
     persistent grid starts with), on fewer hillslopes than one wave, with the attempt cap, in fixed-step mode."""
+    from conftest import need_experimental_paths
+    need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     kw = {}
@@ -1152,6 +1164,9 @@ def test_toy_model_three_states_one_forcing_vs_oracle(gpu, oracle, math_mode, la
     the same kernels as Model 204 -- they are templates over Model::N_EQ and Model::NF like the reference's
     rk45_kernel_multi<Model> (solver/rk45.h:51-66): finals, dense rows in every device layout, flags and
     step counts against the CPU oracle; per-cell forcing table; ragged last wave."""
+    if layout == 1:
+        from conftest import need_experimental_paths
+        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     from tiger_hlm_gpu_amd.engine import ShardEngine
@@ -1254,6 +1269,8 @@ def test_compaction_between_launches_is_bit_identical(gpu, case):
     interval ends as with t_stop, so finals, flags and both counters equal the single launch bit for bit:
     cold cells (42 % drop out along the way), the benchmark workload (nobody drops out), a 3-state model on
     a ragged size, and the attempt cap (everybody drops out in the first launch)."""
+    from conftest import need_experimental_paths
+    need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     from tiger_hlm_gpu_amd.engine import ShardEngine
@@ -1757,6 +1774,9 @@ def test_dense_tile_layout_holds_the_same_rows(gpu, layout):
     with wave-synchronous stores) hold the same bits as the host layout of the free-running kernel
     for every (hillslope, query, state), flagged rows and tails zero alike, also after the Radau
     pass and for a ragged last tile."""
+    if layout == 1:
+        from conftest import need_experimental_paths
+        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd.engine import ShardEngine
     sp, y0, cells, pr, t2m, dt, nT, q, tf = _cold_case(ns=200, days=5)

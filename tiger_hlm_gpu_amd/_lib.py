@@ -93,6 +93,7 @@ WINDOW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_d
 # name -> (restype, argtypes); every symbol include/hlm_hip.h declares
 SIGNATURES = {
     "hlm_abi_version": (C.c_int, []),
+    "hlm_build_flags": (C.c_int, []),
     "hlm_last_error": (C.c_char_p, []),
     "hlm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "hlm_set_device": (C.c_int, [C.c_int]),

@@ -27,6 +27,12 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
+def has_experimental_paths():
+    """True when the library was built with HLM_EXPERIMENTAL_PATHS (lane refill, compaction between launches, the
+    tile-row dense layout: quarantined by default, hlm_build_flags)."""
+    return bool(lib().hlm_build_flags() & 1)
+
+
 # ---- device helpers ---------------------------------------------------------------------
 def device_count():
     n = C.c_int(0)

@@ -20,7 +20,14 @@
 #include "hlm_rk45_kernel.h"
 #include "hlm_rk45_queue_kernel.h"
 #include "hlm_gather_rccl.h"
+// Paths that lost on every workload measured in rounds 2-4 (lane refill, compaction between launches, the tile-row
+// dense layout) are quarantined: built only with -DHLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1), refused otherwise.
+#ifdef HLM_EXPERIMENTAL_PATHS
 #include "hlm_rk45_refill_kernel.h"
+constexpr bool kExperimentalPaths = true;
+#else
+constexpr bool kExperimentalPaths = false;
+#endif
 
 namespace {
 
@@ -221,6 +228,7 @@ KernelFn pick_dense_ring(int uid, int math, bool fixed, bool res)
     return with_model<KernelFn>(uid, [&](auto m) { return pick_dense_ring<decltype(m)>(math, fixed, res); });
 }
 
+#ifdef HLM_EXPERIMENTAL_PATHS
 // the kernels with lane refill (hlm_rk45_refill_kernel.h): no dense output, no resume state
 using RefillFn = void (*)(const hlm::Rk45Args, unsigned int*);
 template <class Model>
@@ -234,6 +242,8 @@ RefillFn pick_refill(int uid, int math, bool fixed)
 {
     return with_model<RefillFn>(uid, [&](auto m) { return pick_refill<decltype(m)>(math, fixed); });
 }
+
+#endif
 
 // the persistent kernels over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): no dense output
 using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int, const hlm::QueueRuns);
@@ -314,6 +324,9 @@ int validate_job(const hlm_device_job* j)
     if (j->dense_tiled < 0 || j->dense_tiled > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0, 1 or 2");
     if (const int rcs = validate_selection(j->uid, j->dense_ncomp, j->dense_comp); rcs != HLM_SUCCESS) return rcs;
     if (j->lane_refill != 0 && j->lane_refill != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane_refill must be 0 or 1");
+    if (!kExperimentalPaths && (j->lane_refill || j->dense_tiled == hlm::DENSE_TILE_ROW))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "%s: this library was built without HLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1)",
+                    j->lane_refill ? "lane_refill" : "dense_tiled = 1 (tile-row layout)");
     if (j->time_pieces > kMaxTimePieces) return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces must be at most %d (negative = automatic)", kMaxTimePieces);
     // (the queue kernel numbers its (piece, tile) items with 32 bits)
     if (j->time_pieces > 1 && ((long long)j->num_systems + 63) / 64 * (long long)j->time_pieces >= (1ll << 32) - 1)
@@ -385,6 +398,7 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     return a;
 }
 
+#ifdef HLM_EXPERIMENTAL_PATHS
 // Persistent launch with lane refill: as many one-wave workgroups as the device holds at once, the
 // rest of the hillslopes handed out through a device counter (hlm_rk45_refill_kernel.h).
 int launch_refill(const hlm_device_job* j, hipStream_t stream)
@@ -412,6 +426,8 @@ int launch_refill(const hlm_device_job* j, hipStream_t stream)
     HLM_HIP_TRY(launched);
     return HLM_SUCCESS;
 }
+
+#endif
 
 #ifdef HLM_QUEUE_DEBUG
 // experiment builds only (not in include/hlm_hip.h): where the last queue launch keeps its state, for a look at a
@@ -550,7 +566,9 @@ int launch(const hlm_device_job* j, hipStream_t stream)
 {
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
+#ifdef HLM_EXPERIMENTAL_PATHS
     if (!dense && j->lane_refill && !job_is_resumable(j)) return launch_refill(j, stream);
+#endif
     if (const int pieces = job_time_pieces(j); pieces > 1) return launch_queue(j, pieces, stream);
     KernelFn fn = dense && job_selects(j) ? pick_selecting(j->uid, j->math_mode, fixed, j->dense_tiled == hlm::DENSE_TILE_COMP)
                   : dense && j->dense_tiled == hlm::DENSE_TILE_COMP
@@ -600,12 +618,13 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     // the flagged systems, compacted IN ORDER: neighbours share a forcing cell and take similar numbers of
     // implicit attempts, so the lanes of a Radau wave finish together (an atomic append scatters them)
     const int nb = (ns + hlm::COMPACT_BLOCK - 1) / hlm::COMPACT_BLOCK;
-    int* scratch = nullptr;  // [0 .. ns) indices of flagged systems | [ns .. ns+nb) block counts | count | base | [ns] time bins
+    int* scratch = nullptr;  // [0 .. ns) indices of flagged systems | [ns .. ns+nb) block counts | count | base | next slot | [ns] time bins
     const bool by_flag_time = j->d_flag_state != nullptr;
-    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + (size_t)nb + 2 + (by_flag_time ? (size_t)ns : 0)), stream));
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + (size_t)nb + 3 + (by_flag_time ? (size_t)ns : 0)), stream));
     int* const list = scratch;
     int* const block_count = scratch + ns;
     int* const count = block_count + nb;
+    int* const next_slot = count + 2;   // (count + 1 = the appending passes' base)
     if (!by_flag_time) {
         hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count);
         hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, (int*)nullptr);
@@ -616,7 +635,7 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
         // within a bin -- kRadauBins stable compaction passes appending to one list, no host round trip
         constexpr int kRadauBins = 16;
         int* const base = count + 1;
-        int* const bin = base + 1;
+        int* const bin = next_slot + 1;
         HLM_HIP_TRY(hipMemsetAsync(count, 0, 2 * sizeof(int), stream));
         hipLaunchKernelGGL(hlm::radau_flag_bin_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, j->d_flag_state,
                            model_neq(j->uid), ns, j->t0, j->tf, kRadauBins, bin);
@@ -630,15 +649,24 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     // an implicit attempt costs ~30 us of a wave: the default cap of this pass is 2^20 attempts per
     // system (half a minute), not the RK45 loop's 2^24, so a hopeless system cannot hold a wave for long
     if (!j->attempt_cap) a.cap = 1u << 20;
-    const unsigned blocks = (unsigned)((ns + hlm::WAVE - 1) / hlm::WAVE);  // blocks past the count exit at once
-    using RadauFn = void (*)(const hlm::Rk45Args, const int*, const int*);
+    using RadauFn = void (*)(const hlm::Rk45Args, const int*, const int*, int*);
     const bool fast = j->math_mode == HLM_MATH_FAST;
     RadauFn rf = with_model<RadauFn>(j->uid, [&](auto m) -> RadauFn {
         using M = decltype(m);
         return fast ? hlm::radau_fallback_kernel<M, hlm::MATH_FAST> : hlm::radau_fallback_kernel<M, hlm::MATH_STRICT>;
     });
     if (!rf) { (void)hipFreeAsync(scratch, stream); return fail(HLM_ERR_UNKNOWN_MODEL, "no Radau kernel for UID %d", j->uid); }
-    hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, list, count);
+    // a persistent grid with lane refill: as many one-wave workgroups as the device holds (or as there could be full
+    // waves of flagged systems); the lanes draw further list slots from next_slot, which starts behind the grid's own
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t eq = hipGetDevice(&dev);
+    if (eq == hipSuccess) eq = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (eq == hipSuccess) eq = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rf), hlm::WAVE, 0);
+    const long long resident = (long long)cus * (per_cu > 0 ? per_cu : 1), waves = ((long long)ns + hlm::WAVE - 1) / hlm::WAVE;
+    const unsigned blocks = (unsigned)(waves < resident ? waves : resident);
+    if (eq == hipSuccess) eq = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(next_slot), (int)(blocks * (unsigned)hlm::WAVE), 1, stream);
+    if (eq != hipSuccess) { (void)hipFreeAsync(scratch, stream); return fail(HLM_ERR_HIP, "Radau launch set-up failed: %s", hipGetErrorString(eq)); }
+    hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, list, count, next_slot);
     const hipError_t launched = hipGetLastError();
     HLM_HIP_TRY(hipFreeAsync(scratch, stream));  // stream-ordered: after the kernels above
     HLM_HIP_TRY(launched);
@@ -705,6 +733,7 @@ int replace_forcings(const ForcingState& next)
 extern "C" {
 
 int hlm_abi_version(void) { return HLM_ABI_VERSION; }
+int hlm_build_flags(void) { return kExperimentalPaths ? HLM_BUILD_EXPERIMENTAL_PATHS : 0; }
 const char* hlm_last_error(void) { return g_err; }
 
 int hlm_device_count(int* count)
@@ -808,6 +837,7 @@ int hlm_set_attempt_cap(uint32_t cap)
 int hlm_set_stream_path(int path)
 {
     if (path < 0 || path > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "stream path %d", path);
+    if (path == 1 && !kExperimentalPaths) return fail(HLM_ERR_INVALID_ARGUMENT, "stream path 1 (tile-row layout): this library was built without HLM_EXPERIMENTAL_PATHS");
     std::lock_guard<std::mutex> lk(g_mu);
     g_stream_path = path ? 1 : 0;
     if (path) g_stream_layout = path == 2 ? hlm::DENSE_TILE_COMP : hlm::DENSE_TILE_ROW;
@@ -884,6 +914,7 @@ int hlm_radau_fallback_device(const hlm_device_job* job, void* hip_stream)
 int hlm_set_lane_refill(int enabled)
 {
     if (enabled != 0 && enabled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane refill flag %d (want 0 or 1)", enabled);
+    if (enabled && !kExperimentalPaths) return fail(HLM_ERR_INVALID_ARGUMENT, "lane refill: this library was built without HLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1)");
     std::lock_guard<std::mutex> lk(g_mu);
     g_refill = enabled;
     return HLM_SUCCESS;
@@ -1300,6 +1331,10 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
 
 int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_minutes, void* hip_stream, int* launches)
 {
+#ifndef HLM_EXPERIMENTAL_PATHS
+    (void)job; (void)interval_minutes; (void)hip_stream; (void)launches;
+    return fail(HLM_ERR_INVALID_ARGUMENT, "integrate_compacting: this library was built without HLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1)");
+#else
     if (!job) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
     if (!(interval_minutes > 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "interval_minutes must be > 0");
     int rc = validate_job(job);
@@ -1359,6 +1394,7 @@ int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_min
     HLM_HIP_TRY(ef);
     if (launches) *launches = done;
     return rc;
+#endif
 }
 
 int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms)

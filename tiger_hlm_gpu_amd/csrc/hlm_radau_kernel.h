@@ -275,7 +275,7 @@ __device__ unsigned long long g_radau_ctr[8];
 #endif
 // the finish + set-up section of the state machine runs when this fraction of the wave's live lanes waits for it
 #ifndef HLM_RADAU_SETUP_NUM
-#define HLM_RADAU_SETUP_NUM 6
+#define HLM_RADAU_SETUP_NUM 5
 #endif
 #ifndef HLM_RADAU_SETUP_DEN
 #define HLM_RADAU_SETUP_DEN 8
@@ -283,26 +283,13 @@ __device__ unsigned long long g_radau_ctr[8];
 constexpr int RADAU_SETUP_NUM = HLM_RADAU_SETUP_NUM, RADAU_SETUP_DEN = HLM_RADAU_SETUP_DEN;
 template <class Model, int MATH>
 __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR) ? HLM_RADAU_TRI_WAVES : 1) radau_fallback_kernel(const Rk45Args A, const int* __restrict__ list,
-                                                                 const int* __restrict__ count)
+                                                                 const int* __restrict__ count, int* __restrict__ next_slot)
 {
     using namespace radau;
     constexpr int NEQ = Model::N_EQ, NFA = Model::NF > 0 ? Model::NF : 1;
     const int lane = (int)threadIdx.x;
-    const int slot = (int)(blockIdx.x * WAVE) + lane;
-    if (slot >= *count) return;
-    const int sys = list[slot];
-
-    const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
-    double y[NEQ];
-#pragma unroll
-    for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
-
-    size_t fcol = 0;
-    if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
-    double tb[NFA], F[NFA];
-#pragma unroll
-    for (int j = 0; j < NFA; ++j) { tb[j] = -__builtin_inf(); F[j] = 0.0; }
-    typename Model::Forc FV = Model::prep_forcing(P, F);
+    const int nflagged = *count;
+    const double tf = A.tf;
 
     // dense layouts as in hlm_rk45_dense_kernel.h: 0 / 3 [sys][q][c], 1 [tile][q][lane][c], 2 [tile][q][c][lane]
     // output selection (hlm_device_job.dense_ncomp): rows of K components, component c at position pos(c) or absent
@@ -311,40 +298,87 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     auto pos = [&](int c) -> int { return A.dense_k > 0 ? A.dense_pos[c] : c; };  // wave-uniform
     const size_t q_stride = tiled ? (size_t)WAVE * (size_t)K : (size_t)K;
     const size_t c_stride = A.dense_tiled == 2 ? (size_t)WAVE : (size_t)1;
-    double* dense_row = nullptr;
-    if (A.nq > 0)
-        dense_row = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * (size_t)K
-                           : A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride +
-                                 (size_t)(sys % WAVE) * (A.dense_tiled == 2 ? (size_t)1 : (size_t)K);
 
+    // ---- the system a lane integrates.  LANE REFILL (round 4): the grid is persistent (as many one-wave workgroups as
+    // the device holds) and a lane that finishes its system takes the next flagged one from a device counter -- no wave
+    // idles behind its longest system and the launch does not end on a partial round of waves (6 547 waves of 64
+    // flagged systems on 2 048 slots are 3.2 rounds: a fifth of the last one's machine stood idle).  What made lane
+    // refill lose in the RK45 loop -- neighbours of different forcing cells in one wave defeat its wave-uniform cheap
+    // RHS paths -- does not exist here: every lane evaluates the general RHS with its own forcing samples.
+    int sys = 0;
+    typename Model::Local P{};
+    double y[NEQ];
+    size_t fcol = 0;
+    double tb[NFA], F[NFA];
+    typename Model::Forc FV{};
+    double* dense_row = nullptr;
     double t = A.t0, h = A.h0;
-    const double tf = A.tf;
     int next_q = 0;
     uint32_t n_attempt = 0, n_accept = 0;
-    if (A.flag_state) {
-        // "continue" mode (hlm_device_job.d_flag_state): take over from the state at which RK45 gave up; the rows
-        // it wrote up to there stay, the later ones (zero so far) are this pass's
-        const double* fs = A.flag_state + (size_t)sys * (NEQ + 1);
 #pragma unroll
-        for (int i = 0; i < NEQ; ++i) y[i] = fs[i];
-        t = fs[NEQ];
-        while (next_q < A.nq && A.query[next_q] <= t) ++next_q;
-    } else {
-        // restart at t0 (radau_kernel.cu:44-52); queries at or before t0 are never produced: zero rows
-        while (next_q < A.nq && A.query[next_q] <= t) {
+    for (int i = 0; i < NEQ; ++i) y[i] = 0.0;
+#pragma unroll
+    for (int j = 0; j < NFA; ++j) { tb[j] = -__builtin_inf(); F[j] = 0.0; }
+
+    auto load_system = [&](int slot) {
+        sys = list[slot];
+        P = Model::template load<MATH>(A.sp, sys);
+        if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
+#pragma unroll
+        for (int j = 0; j < NFA; ++j) { tb[j] = -__builtin_inf(); F[j] = 0.0; }
+        FV = Model::prep_forcing(P, F);
+        dense_row = nullptr;
+        if (A.nq > 0)
+            dense_row = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * (size_t)K
+                               : A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride +
+                                     (size_t)(sys % WAVE) * (A.dense_tiled == 2 ? (size_t)1 : (size_t)K);
+        t = A.t0;
+        h = A.h0;
+        next_q = 0;
+        n_attempt = n_accept = 0;
+        if (A.flag_state) {
+            // "continue" mode (hlm_device_job.d_flag_state): take over from the state at which RK45 gave up; the rows
+            // it wrote up to there stay, the later ones (zero so far) are this pass's
+            const double* fs = A.flag_state + (size_t)sys * (NEQ + 1);
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) y[i] = fs[i];
+            t = fs[NEQ];
+            while (next_q < A.nq && A.query[next_q] <= t) ++next_q;
+        } else {
+            // restart at t0 (radau_kernel.cu:44-52); queries at or before t0 are never produced: zero rows
+#pragma unroll
+            for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
+            while (next_q < A.nq && A.query[next_q] <= t) {
+#pragma unroll
+                for (int c = 0; c < NEQ; ++c)
+                    if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
+                ++next_q;
+            }
+        }
+    };
+    // the outputs of a finished system (capped: the attempt cap ended it before tf)
+    auto store_system = [&](bool capped) {
+        // both counters ACCUMULATE: after the fallback they hold the RK45 work spent on the system up to
+        // its flag plus the implicit attempts / accepted steps of this pass
+        if (A.n_attempt) A.n_attempt[sys] += n_attempt;
+        if (A.n_accept) A.n_accept[sys] += n_accept;
+        const bool failed = capped && t < tf;
+        if (failed) A.stiff[sys] = HLM_SYS_CAPPED;  // success leaves the RK45 flag in place (rk45_api.hpp:189-247 does)
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = failed ? 0.0 : y[i];
+        for (; next_q < A.nq; ++next_q) {  // rows never reached (later than tf, or after the cap): zero
 #pragma unroll
             for (int c = 0; c < NEQ; ++c)
                 if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
-            ++next_q;
         }
-    }
+    };
 
-    auto sample = [&](int j, double& tb) -> double {
+    auto sample = [&](int j, double& tbj) -> double {
         // zero-order hold (rk45_kernel.cu:90-98); the index is nudged so that its interval
         // really contains t (a step clipped to a boundary lands exactly on it)
         unsigned long long idx = forcing_index(t, A.forc_dtmin[j], A.forc_nT[j]);
         while (idx + 1ull < A.forc_nT[j] && (double)(idx + 1ull) * A.forc_dtmin[j] <= t) ++idx;
-        tb = (idx + 1ull < A.forc_nT[j]) ? (double)(idx + 1ull) * A.forc_dtmin[j] : __builtin_inf();
+        tbj = (idx + 1ull < A.forc_nT[j]) ? (double)(idx + 1ull) * A.forc_dtmin[j] : __builtin_inf();
         return (double)A.forc[A.forc_base[j] + (size_t)idx * (size_t)A.forc_ld + fcol];
     };
 
@@ -360,10 +394,17 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     // iteration) and sets up its next one (forcing samples, clipping, f0, Jacobian, the 15 reciprocals), then iterates
     // again.  Each lane executes exactly the operation sequence of the nested loops, so every result is the same bit
     // for bit; only WHEN a lane does what differs, and the Newton iterations run with the lanes that need them.
-    enum : int { PH_NEWTON = 0, PH_SETUP = 1, PH_DONE = 2 };
+    enum : int { PH_NEWTON = 0, PH_SETUP = 1, PH_DONE = 2, PH_FINISHED = 3 };
     enum : int { END_NONE = 0, END_CONVERGED = 1, END_FAILED = 2 };
-    bool capped = false;
-    int phase = t < tf ? PH_SETUP : PH_DONE, ended = END_NONE;
+    int phase = PH_DONE, ended = END_NONE;
+    {
+        const int slot0 = (int)(blockIdx.x * WAVE) + lane;
+        if (slot0 < nflagged) {
+            load_system(slot0);
+            phase = PH_SETUP;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(phase != PH_DONE) == 0ull) return;
     // state of the attempt a lane is in
     constexpr bool TRI = Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR;
     double f0[NEQ], Jm[NEQ][NEQ];
@@ -389,12 +430,29 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         if constexpr (TRI) solve_cplx_tri(Jm, inv_cr, inv_ci, br, bi); else solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, br, bi);
     };
 
-    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no prologue load is waited for inside the loop, behind the row stores
+    // Two loops.  The inner one is the state machine; it is left whenever a lane has finished its system (once per ~90
+    // trips of a wave), and the outer one's body -- results of the finished systems out, the next flagged systems in
+    // -- runs between: kept out of the hot loop so that its operands (the launch's pointers, the parameter record) are
+    // not live registers in there.
+#pragma unroll 1
+    while (true) {
+    if (phase == PH_FINISHED) {
+        store_system(t < tf);
+        const int slot = atomicAdd(next_slot, 1);
+        if (slot < nflagged) {
+            load_system(slot);
+            phase = PH_SETUP;
+        } else {
+            phase = PH_DONE;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(phase != PH_DONE) == 0ull) break;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load of the block above is waited for inside the loop, behind the row stores
 #pragma unroll 1
     while (true) {
         const unsigned long long m_setup = __builtin_amdgcn_ballot_w64(phase == PH_SETUP);
         const unsigned long long m_newton = __builtin_amdgcn_ballot_w64(phase == PH_NEWTON);
-        if ((m_setup | m_newton) == 0ull) break;
+        if ((m_setup | m_newton) == 0ull) break;   // (only finished lanes left)
         HLM_RCOUNT(3);
         const int n_setup = __builtin_popcountll(m_setup), n_newton = __builtin_popcountll(m_newton);
         if (n_setup > 0 && (n_newton == 0 || n_setup * RADAU_SETUP_DEN >= (n_setup + n_newton) * RADAU_SETUP_NUM)) {
@@ -454,12 +512,9 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                     }
                 }
                 ended = END_NONE;
-                // ---- set up the next attempt -----------------------------------------------------------------------
-                if (!(t < tf)) {
-                    phase = PH_DONE;
-                } else if (n_attempt >= A.cap) {
-                    capped = true;
-                    phase = PH_DONE;
+                // ---- the next attempt -- of this system, or (in the section after this one) of the next one ----------
+                if (!(t < tf) || n_attempt >= A.cap) {
+                    phase = PH_FINISHED;   // (tf reached, or the attempt cap: the outer loop takes it from here)
                 } else {
                     HLM_RCOUNT(0);
                     double t_b = __builtin_inf();  // the next sample boundary of any stream
@@ -617,21 +672,10 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 phase = PH_SETUP;
             }
         }
+        if (__builtin_amdgcn_ballot_w64(phase == PH_FINISHED) != 0ull) break;
+    }
     }
 
-    // both counters ACCUMULATE: after the fallback they hold the RK45 work spent on the system up to
-    // its flag plus the implicit attempts / accepted steps of this pass
-    if (A.n_attempt) A.n_attempt[sys] += n_attempt;
-    if (A.n_accept) A.n_accept[sys] += n_accept;
-    const bool failed = capped && t < tf;
-    if (failed) A.stiff[sys] = HLM_SYS_CAPPED;  // success leaves the RK45 flag in place (rk45_api.hpp:189-247 does)
-#pragma unroll
-    for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = failed ? 0.0 : y[i];
-    for (; next_q < A.nq; ++next_q) {  // rows never reached (later than tf, or after the cap): zero
-#pragma unroll
-        for (int c = 0; c < NEQ; ++c)
-            if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
-    }
 }
 
 }  // namespace hlm

@@ -10,11 +10,13 @@ cd /tmp && export TMPDIR=/tmp
 BASE="--steps 3 --warmup 1 --no-variants --no-dense --no-cpu-baseline"
 PASS_A="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"
 PASS_B="SQ_WAVES SQ_INSTS_BRANCH SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
-for W in headline wet cold; do
+for W in headline wet cold cold_radau cold_radau_continue; do
   case $W in
     headline) EXTRA="";;
     wet) EXTRA="--wet-surface";;
-    cold) EXTRA="--tmin -5";;
+    cold) EXTRA="--tmin -5 --queue-run-pieces 1";;
+    cold_radau) EXTRA="--tmin -5 --radau --queue-run-pieces 1";;
+    cold_radau_continue) EXTRA="--tmin -5 --radau --radau-continue --queue-run-pieces 1";;
   esac
   for P in A B; do
     if [ $P = A ]; then C="$PASS_A"; else C="$PASS_B"; fi

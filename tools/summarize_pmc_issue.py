@@ -23,13 +23,14 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"tag": tag, "source": "tools/pmc_issue.sh (rocprofv3 --pmc, two SQ passes per workload, bench.py --steps 3 --warmup 1)",
        "units": "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs",
        "workloads": {}}
-for w in ("headline", "wet", "cold"):
+for w in ("headline", "wet", "cold", "cold_radau", "cold_radau_continue"):
     counters, kname, meta = {}, None, {}
     for p in ("A", "B"):
         files = glob.glob(os.path.join(src, f"{w}_{p}", "*", "*_counter_collection.csv"))
         if not files:
             continue
-        rows = [r for r in csv.DictReader(open(files[0])) if "rk45_queue_kernel" in r["Kernel_Name"] or "rk45_multi_kernel" in r["Kernel_Name"]]
+        want = ("radau_fallback_kernel",) if w.startswith("cold_radau") else ("rk45_queue_kernel", "rk45_multi_kernel")
+        rows = [r for r in csv.DictReader(open(files[0])) if any(k in r["Kernel_Name"] for k in want)]
         if not rows:
             continue
         by = {}
@@ -55,6 +56,8 @@ for w in ("headline", "wet", "cold"):
     d = {"kernel": kname, **meta, "counters_per_launch_avg": counters}
     if line:
         att = float(line["attempts_per_pass"])
+        if w.startswith("cold_radau"):   # the pass's own (implicit) attempts: total minus the RK45 launch's (the "cold" workload)
+            att -= out["workloads"].get("cold", {}).get("derived", {}).get("lane_attempts", 0.0)
         wa = att / 64.0
         d["bench_line_under_pmc"] = {k: line[k] for k in ("value", "ms_per_step", "attempts_per_pass", "flagged_fraction") if k in line}
         d["bench_line_under_pmc"]["per_gpu_key"] = line["config"]["per_gpu_key"]
