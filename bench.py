@@ -95,6 +95,8 @@ def parse():
                          "over (time piece, tile) items, 0 = one wave per tile (the reference's map), -1 = the library's automatic rule")
     ap.add_argument("--queue-run-pieces", type=int, default=0,
                     help="hlm_device_job.queue_run_pieces: 0 automatic runs of pieces per queue item, 1 every piece handed over")
+    ap.add_argument("--group-tiles", type=int, default=0,
+                    help="hlm_device_job.queue_group_tiles: G > 1 = the survivors of G neighbouring tiles packed into full waves, piece by piece")
     ap.add_argument("--lane-refill", action="store_true",
                     help="persistent grid with lane refill (a lane whose hillslope is finished or flagged takes the next one)")
     ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
@@ -149,7 +151,7 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
                       math_mode=H.MATH_FAST if (math or args.math) == "fast" else H.MATH_STRICT,
                       device=f"cuda:{torch.cuda.current_device()}", dense_tiled=args.dense_tiled,
                       lane_refill=args.lane_refill, time_pieces=None if args.time_pieces < 0 else args.time_pieces,
-                      queue_run_pieces=args.queue_run_pieces)
+                      queue_run_pieces=args.queue_run_pieces, queue_group_tiles=args.group_tiles)
     if args.layout == "per-stream":
         eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     else:
@@ -188,7 +190,7 @@ def _issue_fields(per_gpu_key):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (f";runs={args.queue_run_pieces}" if args.queue_run_pieces else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
+    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (f";runs={args.queue_run_pieces}" if args.queue_run_pieces else "") + (f";group={args.group_tiles}" if args.group_tiles else "") + (";wet" if args.wet_surface else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
     return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
@@ -920,9 +922,11 @@ def main():
             res["rk45_default_launch_shape"] = {"ms": a.elapsed_time(b), "time_pieces": H.api.time_pieces_for(e.job()), "queue_run_pieces": "automatic"}
             # ... then what this workload wants (hlm_device_job.queue_run_pieces = 1, every piece handed over): hillslopes
             # dropping out with stiff flags make a few tiles cost several times the mean, and long runs start late tiles late
-            e.queue_run_pieces = 1
-            res["launch_shape"] = {"time_pieces": H.api.time_pieces_for(e.job()), "queue_run_pieces": 1,
-                                   "note": "same bits; all rows below use it (tools/queue_prof_probe.py, profiles/r04_queue_runs_probe.txt)"}
+            e.queue_group_tiles = 8
+            res["launch_shape"] = {"time_pieces": H.api.time_pieces_for(e.job()), "queue_group_tiles": 8,
+                                   "note": "same bits; all rows below use it: the survivors of 8 neighbouring tiles packed into full waves piece "
+                                           "by piece (flagged hillslopes stop costing lanes; every piece handed over, which a workload with a "
+                                           "few very slow tiles wants anyway); profiles/r04_queue_runs_probe.txt, profiles/r04_group_tiles_probe.txt"}
             for tag, radau in (("rk45", False), ("rk45_plus_radau", True), ("rk45_plus_radau_continue", "continue")):
                 e.integrate(radau=radau)
                 torch.cuda.synchronize()
@@ -943,7 +947,7 @@ def main():
                                                        "(the reference's kernel, and rk45_plus_radau, restart it at t0)")
             import copy
             ca = copy.copy(args)
-            ca.tmin, ca.queue_run_pieces = -5.0, 1
+            ca.tmin, ca.group_tiles = -5.0, 8
             res["rk45"].update(_issue_fields(_per_gpu_key(ca, 0, e.ns)))   # active lanes per VALU instruction of the RK45 pass etc.
             if not H.api.has_experimental_paths():   # (compaction between launches is a quarantined path: EXPERIMENTAL=1 builds)
                 return res

@@ -292,6 +292,12 @@ typedef struct hlm_device_job {
      * out with stiff flags --, because long runs start the tiles late in the queue order late).  Same results bit for
      * bit. */
     int queue_run_pieces;
+    /* (ABI 4) G > 1, for a job that launches in time pieces: an item of the queue is a GROUP of G neighbouring tiles
+     * and one piece; the wave packs the group's hillslopes that are still integrating into full passes of 64 lanes
+     * (on the device, piece by piece, from the status words of the state record) -- flagged hillslopes stop costing
+     * lanes without any global re-tiling, extra launch or drain.  Every piece is handed over through the record
+     * (queue_run_pieces is ignored).  Same results bit for bit.  0 / 1: an item is a tile.  At most 16. */
+    int queue_group_tiles;
 } hlm_device_job;
 
 /* The number of time pieces hlm_rk45_integrate_device(job) launches with (the automatic rule resolved; 0 = one wave

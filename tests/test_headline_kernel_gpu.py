@@ -307,3 +307,64 @@ def test_device_rhs_unsaturated_forms_with_rain_and_wet_surface_vs_oracle(gpu, o
         assert np.array_equal(got[ok], gen[ok]), tag     # bit-identical to the general RHS inside the regime
         assert np.all(np.abs(got[ok] - ref[ok]) <= 4e-15 * np.maximum(np.abs(ref[ok]), mag[ok]) * 8), tag
         assert np.all(got[ok][:, 0] == (rain - melt)[ok])   # the rain is in it
+
+
+# ---- groups of tiles packed per piece (hlm_device_job.queue_group_tiles) -----------------------------------------------
+@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "toy", "strict-wet-cold"])
+def test_group_tiles_packing_is_bit_identical(gpu, case):
+    """hlm_device_job.queue_group_tiles = G: item (piece, tile j) of the queue is pass j % G of group j / G -- the wave
+    packs the group's hillslopes that are still integrating into an LDS list (from the status words of the state
+    record) and integrates the 64 of its pass, so that flagged hillslopes stop costing lanes, with no global re-tiling.
+    Finals, flags and both counters of every hillslope equal the one-wave-per-tile launch bit for bit: cold cells
+    flagged in different pieces (later passes straddle tiles and forcing cells), a workload in which nobody drops out,
+    fewer hillslopes than a wave, every hillslope capped in the first piece (later pieces find empty groups), the
+    three-state model, STRICT arithmetic on wet cold cells; G = 2, 8, 16 (a ragged last group), 14 and 40 pieces."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    kw, t0 = {}, 0.0
+    if case in ("cold-cells", "strict-wet-cold"):
+        ns, days = (250_037, 6) if case == "cold-cells" else (9000, 4)
+        if case == "strict-wet-cold":
+            kw = dict(math_mode=H.MATH_STRICT)
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=(case != "cold-cells")), synth.model204_params(0, ns), days * 1440.0
+    elif case == "benchmark":
+        ns, days = 300_000, 2
+        pr, t2m, dt, nT = synth.forcing_tables(days=days)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
+    elif case == "ragged-small":
+        ns, days = 37, 3
+        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+        model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=True), synth.model204_params(0, ns), days * 1440.0
+    elif case == "dummy-capped":
+        ns = 1000
+        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 500.0, dict(attempt_cap=100)
+    else:
+        rng = np.random.default_rng(3)
+        ns, days = 1300, 3
+        sp = synth.model204_params(0, ns, seed=3)
+        sp["alpha3"] = rng.uniform(5.0, 60.0, ns)
+        sp["alpha4"] = rng.uniform(20.0, 400.0, ns)
+        y0 = np.stack([rng.uniform(0.0, 2.0, ns), rng.uniform(0.0, 1.0, ns), rng.uniform(0.0, 0.5, ns)], axis=1)
+        cells = synth.cell_of_system(0, ns, ncell=16, run_len=7)
+        inflow = (rng.random((24 * days, 16)) < 0.3) * rng.uniform(0.0, 0.2, (24 * days, 16))
+        model, tf = H.ToyModel3, days * 1440.0
+
+    def run(pieces, group):
+        eng = ShardEngine(model, y0, t0, tf, sp=sp, time_pieces=pieces, queue_group_tiles=group, **kw)
+        if case == "toy":
+            eng.set_forcings_per_cell((inflow.astype(np.float32),), cells, (1.0,), (inflow.shape[0],))
+        elif sp is not None:
+            eng.set_forcings_per_cell((pr, t2m), synth.cell_of_system(0, ns, run_len=64), dt, nT)
+        eng.integrate()
+        return eng.results()
+    a = run(0, 0)
+    for group, pieces in ((2, 14), (8, 14), (8, 40), (16, 14)):
+        b = run(pieces, group)
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(a[k], b[k]), (case, group, pieces, k)
+    if case == "cold-cells":
+        assert 0.05 < (a["stiff"] == 1).mean() < 0.95
+    if case == "dummy-capped":
+        assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()

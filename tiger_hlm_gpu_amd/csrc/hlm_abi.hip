@@ -248,15 +248,17 @@ RefillFn pick_refill(int uid, int math, bool fixed)
 // the persistent kernels over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): no dense output
 using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int, const hlm::QueueRuns);
 template <class Model>
-QueueFn pick_queue(int math, bool fixed)
+QueueFn pick_queue(int math, bool fixed, bool retile)
 {
     using namespace hlm;
+    if (retile && !fixed)   // (the re-tiling instances: adaptive steps only -- a fixed-step run never flags)
+        return math == HLM_MATH_FAST ? rk45_queue_kernel<Model, MATH_FAST, false, true> : rk45_queue_kernel<Model, MATH_STRICT, false, true>;
     if (math == HLM_MATH_FAST) return fixed ? rk45_queue_kernel<Model, MATH_FAST, true> : rk45_queue_kernel<Model, MATH_FAST, false>;
     return fixed ? rk45_queue_kernel<Model, MATH_STRICT, true> : rk45_queue_kernel<Model, MATH_STRICT, false>;
 }
-QueueFn pick_queue(int uid, int math, bool fixed)
+QueueFn pick_queue(int uid, int math, bool fixed, bool retile)
 {
-    return with_model<QueueFn>(uid, [&](auto m) { return pick_queue<decltype(m)>(math, fixed); });
+    return with_model<QueueFn>(uid, [&](auto m) { return pick_queue<decltype(m)>(math, fixed, retile); });
 }
 
 KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
@@ -332,6 +334,8 @@ int validate_job(const hlm_device_job* j)
     if (j->time_pieces > 1 && ((long long)j->num_systems + 63) / 64 * (long long)j->time_pieces >= (1ll << 32) - 1)
         return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces %d x %d hillslopes: more than 2^32 (piece, tile) items", j->time_pieces, j->num_systems);
     if (j->queue_run_pieces < 0) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_run_pieces must be >= 0 (0 = automatic)");
+    if (j->queue_group_tiles < 0 || j->queue_group_tiles > hlm::QUEUE_MAX_GROUP)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "queue_group_tiles must be within [0, %d]", hlm::QUEUE_MAX_GROUP);
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
@@ -499,7 +503,8 @@ hlm::QueueRuns make_queue_runs(int pieces, long long tiles, long long resident, 
 int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double w0, double w1, bool windowed)
 {
     const bool fixed = j->fixed_step > 0.0;
-    QueueFn fn = pick_queue(j->uid, j->math_mode, fixed);
+    const int group = j->queue_group_tiles > 1 && !fixed ? j->queue_group_tiles : 1;
+    QueueFn fn = pick_queue(j->uid, j->math_mode, fixed, group > 1);
     if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
     if (windowed && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "a window launch needs d_resume");
     int dev = 0, cus = 0, per_cu = 0;
@@ -510,7 +515,7 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
     const long long tiles = ((long long)j->num_systems + hlm::WAVE - 1) / hlm::WAVE;
     const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
     const size_t rbytes = windowed ? 0 : (hlm_resume_bytes_model(j->uid, j->num_systems) + 15u) & ~(size_t)15u;
-    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + 2);  // next item | finished runs per tile | abort word
+    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + hlm::QUEUE_MAX_GROUP + 2);  // next item | finished runs per tile (passes per group) | abort word (behind the padded tiles)
     char* pool = nullptr;
     HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + qbytes, stream));
     unsigned int* queue = reinterpret_cast<unsigned int*>(pool + rbytes);
@@ -543,7 +548,9 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
     g_debug_queue_rbytes = rbytes;
     g_debug_queue_qbytes = qbytes;
 #endif
-    hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, j->queue_run_pieces);
+    // groups of tiles packed piece by piece (queue_group_tiles): every piece is handed over, an item is a group
+    hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, group > 1 ? 1 : j->queue_run_pieces);
+    runs.group = group;
     runs.t_begin = w0;
     runs.piece_len = (w1 - w0) / (double)pieces;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, pieces, runs);

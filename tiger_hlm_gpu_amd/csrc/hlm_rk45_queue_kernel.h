@@ -33,6 +33,17 @@
 // keep handing every piece over: make_queue_runs in hlm_abi.hip has the measurements).  Same bits whatever the runs
 // (hlm_device_job.queue_run_pieces, tests).
 //
+// GROUPS (round 4; hlm_device_job.queue_group_tiles = G > 1).  For workloads in which hillslopes drop out early
+// (SURVEY's generator flags 42 % of them stiff; a flagged lane idles in its wave for the rest of the launch: 42 of 64
+// lanes active).  The tiles are taken in GROUPS of G neighbours: item (piece, tile j) is pass j % G of group j / G --
+// the wave reads the group's status words, packs the hillslopes that are still integrating into an LDS list (in their
+// order, by ballot and popcount; all G waves of a group build the same list) and integrates the 64 hillslopes of ITS
+// pass, or nothing when the group has fewer passes left.  A piece of a group starts when all G passes of its previous
+// piece are through (the group's counter counts passes).  Every piece is handed over through the record (runs of
+// one piece), which this mode needs anyway; there is no global re-tiling, no extra launch and no drain, and a group
+// of 8 tiles is one forcing cell's worth of neighbours, so the passes rarely mix forcing cells.  The results cannot depend on the
+// packing: lane states travel by hillslope number and no RHS form is chosen by a neighbour's values.
+//
 // Every wave reaches the end of the grid whatever happens: the wait is bounded by a wall-clock watchdog
 // (QUEUE_WAIT_LIMIT_TICKS of the 100 MHz real-time counter).  A wait that outlasts it -- a lost wave; never seen --
 // gives the tile up: its unfinished hillslopes come back flagged HLM_SYS_CAPPED with zero finals, the channel of
@@ -76,6 +87,7 @@ constexpr unsigned long long QUEUE_WAIT_LIMIT_TICKS = HLM_QUEUE_WAIT_LIMIT_TICKS
 
 // The runs of a launch (kernel argument): run r covers the pieces [begin(r), begin(r + 1)).
 constexpr int QUEUE_MAX_RUNS = 15;
+constexpr int QUEUE_MAX_GROUP = 16;   // tiles per item at most (LDS: 4 bytes x 64 x 16 per wave)
 struct QueueRuns {
     int nruns;
     int uniform;                      // > 0: every run has this many pieces (the last one what is left); else begin_[]
@@ -84,6 +96,10 @@ struct QueueRuns {
     // [t0, tf]; a launch that integrates a WINDOW of it (time chunks of streamed forcings: lanes come from and go back
     // to the caller's state record, Rk45Args.resume / resume_in / t_stop) cuts the window
     double t_begin, piece_len;
+    // tiles per item (hlm_device_job.queue_group_tiles; 1: an item is a tile).  G > 1: an item is a GROUP of G
+    // neighbouring tiles whose hillslopes still integrating are packed into full passes of 64, piece by piece; item
+    // (piece, tile j) is pass j % G of group j / G (see "GROUPS" below)
+    int group;
     __host__ __device__ int begin(int r, int npieces) const
     {
         if (uniform > 0) { const long long b = (long long)r * uniform; return b < npieces ? (int)b : npieces; }
@@ -106,14 +122,21 @@ __global__ void queue_init_kernel(unsigned int* __restrict__ queue, unsigned int
     if (i < words) queue[i] = 0u;
 }
 
-template <class Model, int MATH, bool FIXED>
+// RETILE: the instances that may change which hillslopes share a wave -- groups of tiles packed per piece
+// (hlm_device_job.queue_group_tiles).  The plain instances (RETILE = false) carry none of that code: the headline
+// kernel's register allocation is sensitive to it (+1 ... 5 % with it compiled in).
+template <class Model, int MATH, bool FIXED, bool RETILE = false>
 __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
     rk45_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nchunk, const QueueRuns R)
 {
     using namespace dp;
     constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
     const int lane = (int)threadIdx.x;
-    const unsigned ntiles = ((unsigned)A.ns + WAVE - 1u) / WAVE, nitems = ntiles * (unsigned)R.nruns;
+    const unsigned nsys = (unsigned)A.ns;
+    const unsigned G = RETILE && R.group > 1 ? (unsigned)R.group : 1u;   // tiles per item
+    const unsigned ntiles = ((nsys + WAVE - 1u) / WAVE + G - 1u) / G * G;   // items per run: the tiles (padded to whole groups)
+    const unsigned nitems = ntiles * (unsigned)R.nruns;
+    __shared__ int group_list[RETILE ? WAVE * QUEUE_MAX_GROUP : 1];   // (G > 1) the hillslopes of the item's group still integrating
     unsigned int* const done = queue + 1;
     int* const resume_i = reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns);
     const double tf = A.tf;
@@ -136,16 +159,19 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         HLM_QPROF_ADD(4, 1);
         const unsigned r = item / ntiles, tile = item - r * ntiles;   // run r of this tile:
         const unsigned c_begin = (unsigned)R.begin((int)r, nchunk), c_end = (unsigned)R.begin((int)r + 1, nchunk);   // its pieces
-        const int sys = (int)(tile * WAVE) + lane;
         bool lost = false;  // the watchdog fired: this tile is given up
+        // (G > 1) item `tile` is pass `tile % G` of group `tile / G`: the group's counter counts finished passes, and
+        // a piece of the group starts when all G passes of its previous piece are through (the packing of the next
+        // piece needs every status word of the group)
+        const unsigned dep = G > 1u ? tile / G : tile, dep_target = r * G;
         if (r > 0) {
             // the previous run of this tile: finished long ago when there are more tiles than resident waves
-            auto finished = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
-            if (finished() < r) {
+            auto finished = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&done[dep], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+            if (finished() < dep_target) {
                 const unsigned long long since = wall_clock64();
                 HLM_QMARK(2, 2);
                 [[maybe_unused]] unsigned polls = 0;
-                while (finished() < r) {
+                while (finished() < dep_target) {
                     __builtin_amdgcn_s_sleep(16);
                     HLM_QMARK(4, ++polls);
                     const unsigned aborted = (unsigned)__builtin_amdgcn_readfirstlane(
@@ -162,123 +188,145 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         }
         [[maybe_unused]] const unsigned long long prof_t1 = wall_clock64();
         HLM_QPROF_ADD(3, prof_t1 - prof_t0);
-        if (sys < A.ns && lost) {
-            // (watchdog) whatever this hillslope's record says, nobody continues it: flagged, zero finals
-            if (coherent_load(&resume_i[(size_t)4 * A.ns + sys]) == SYS_PAUSED) {
-                A.stiff[sys] = HLM_SYS_CAPPED;
-                if (A.n_attempt) A.n_attempt[sys] = 0u;
-                if (A.n_accept) A.n_accept[sys] = 0u;
+        const bool from_record = r > 0 || A.resume_in != 0;   // else: this launch starts the hillslopes at (t0, y0)
+        // the hillslopes of this item, 64 per pass: the tile's -- or (G > 1) the group's survivors, packed
+        unsigned n_listed = WAVE;   // (G == 1: one pass over the tile's slots; the lanes filter themselves below)
+        if (RETILE && G > 1u) {
+            n_listed = 0u;
+            for (unsigned k = 0; k < G; ++k) {
+                const unsigned slot = (dep * G + k) * WAVE + (unsigned)lane;
+                const bool in_range = slot < nsys;
+                const int s_k = in_range ? (int)slot : 0;
+                const bool alive = in_range && (!from_record || coherent_load(&resume_i[(size_t)4 * A.ns + s_k]) == SYS_PAUSED);
+                const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
+                if (alive) group_list[n_listed + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = s_k;
+                n_listed += (unsigned)__builtin_popcountll(m);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the list is read by other lanes of this wave
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        {
+            const unsigned slot = (G > 1u ? tile % G : tile) * WAVE + (unsigned)lane;   // (G > 1: this item's pass of the packed list)
+            const bool valid = G > 1u ? slot < n_listed : slot < nsys;
+            const int sys = !valid ? 0 : (G > 1u ? group_list[slot] : (int)slot);
+            if (valid && lost) {
+                // (watchdog) whatever this hillslope's record says, nobody continues it: flagged, zero finals
+                if (coherent_load(&resume_i[(size_t)4 * A.ns + sys]) == SYS_PAUSED) {
+                    A.stiff[sys] = HLM_SYS_CAPPED;
+                    if (A.n_attempt) A.n_attempt[sys] = 0u;
+                    if (A.n_accept) A.n_accept[sys] = 0u;
 #pragma unroll
-                for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = 0.0;
-            }
-            coherent_store(&resume_i[(size_t)4 * A.ns + sys], HLM_SYS_CAPPED);
-        } else if (sys < A.ns) {
-            int status = HLM_SYS_OK;
-            bool runs = true;
-            const bool from_record = r > 0 || A.resume_in != 0;   // else: this launch starts the hillslopes at (t0, y0)
-            if (from_record) {
-                status = coherent_load(&resume_i[(size_t)4 * A.ns + sys]);
-                runs = status == SYS_PAUSED;  // else: finished or flagged in an earlier piece, its outputs were written then
-                if (runs) status = HLM_SYS_OK;
-            }
+                    for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = 0.0;
+                }
+                coherent_store(&resume_i[(size_t)4 * A.ns + sys], HLM_SYS_CAPPED);
+            } else if (valid) {
+                int status = HLM_SYS_OK;
+                bool runs = true;
+                if (from_record) {
+                    status = coherent_load(&resume_i[(size_t)4 * A.ns + sys]);
+                    runs = status == SYS_PAUSED;  // else: finished or flagged in an earlier piece, its outputs were written then
+                    if (runs) status = HLM_SYS_OK;
+                }
 #ifdef HLM_QUEUE_PROF
-            {
-                const int nrun = __builtin_popcountll(__builtin_amdgcn_ballot_w64(runs));
-                if (runs && nrun > 0 && g_queue_prof && (int)__builtin_amdgcn_readfirstlane(lane) == lane) {
-                    g_queue_prof[blockIdx.x * 8 + 5] += 1ull;
-                    g_queue_prof[blockIdx.x * 8 + 6] += (unsigned long long)nrun;
-                }
-            }
-#endif
-            if (runs) {
-                const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
-                double y[NEQ];
-                double t = A.t0;
-                double h = FIXED ? A.fixed_step : A.h0;
-                int reject_count = 0;
-                uint32_t n_attempt = 0, n_accept = 0;
-                if (!from_record) {
-#pragma unroll
-                    for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
-                } else {
-#pragma unroll
-                    for (int i = 0; i < NEQ; ++i) y[i] = coherent_load(&A.resume[(size_t)i * A.ns + sys]);
-                    t = coherent_load(&A.resume[(size_t)NEQ * A.ns + sys]);
-                    h = coherent_load(&A.resume[(size_t)(NEQ + 1) * A.ns + sys]);
-                    reject_count = coherent_load(&resume_i[(size_t)0 * A.ns + sys]);
-                    n_attempt = (uint32_t)coherent_load(&resume_i[(size_t)1 * A.ns + sys]);
-                    n_accept = (uint32_t)coherent_load(&resume_i[(size_t)2 * A.ns + sys]);
-                }
-                HeldForcing<Model, false> held;  // the samples of the first attempt are fetched at its t (as a resumed lane does)
-                held.init(A, sys);
-                typename Model::Forc FV = Model::prep_forcing(P, held.F);
-                bool have_k0 = false;  // k0 = rhs(t, y, F) is a pure function: recomputed, it has the bits of the carried one
-                double k0[NEQ];
-
-                // ---- the loop of rk45_multi_kernel, piece by piece --------------------------------------------
-                // lanes pause the first time t reaches the end of their piece (the last piece runs to tf) and go on
-                // together with the next piece of the run: the protocol of a hand-over, without the hand-over
-                double t_end = w_end;
-                for (unsigned c = c_begin; c < c_end; ++c) {
-                    t_end = c + 1u < (unsigned)nchunk ? fmin(w_end, R.t_begin + (double)(c + 1u) * R.piece_len) : w_end;
-                    while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
-                        if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
-                        if (held.refresh(A, P, t, FV)) have_k0 = false;
-                        ++n_attempt;
-                        double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
-                        [[maybe_unused]] double err = 0.0, jump = 0.0;
-                        attempt_on_cheapest_path<Model, MATH, FIXED, false>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
-                        [[maybe_unused]] double fac = 1.0;
-                        if constexpr (!FIXED) {
-                            fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);  // rk45_kernel.cu:151,156
-                            if (err <= 1.0) {
-                                reject_count = 0;
-                                if (jump > SLOPE_JUMP_THRESH) {  // rk45_kernel.cu:132-136
-                                    h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
-                                    continue;
-                                }
-                            } else {  // rk45_kernel.cu:153-163
-                                ++reject_count;
-                                double f = fmin(fac, 1.0);
-                                f = fmin(fmax(f, A.min_scale), A.max_scale);
-                                h *= f;
-                                if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) status = HLM_SYS_STIFF;
-                                continue;
-                            }
-                        }
-#pragma unroll
-                        for (int i = 0; i < NEQ; ++i) {
-                            y[i] = yt[i];
-                            k0[i] = k6[i];  // = rhs(t1, y_new, F): next attempt's k0 unless the forcing moves
-                        }
-                        t += h;
-                        ++n_accept;
-                        if constexpr (FIXED) h = A.fixed_step;
-                        else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+                {
+                    const int nrun = __builtin_popcountll(__builtin_amdgcn_ballot_w64(runs));
+                    if (runs && nrun > 0 && g_queue_prof && (int)__builtin_amdgcn_readfirstlane(lane) == lane) {
+                        g_queue_prof[blockIdx.x * 8 + 5] += 1ull;
+                        g_queue_prof[blockIdx.x * 8 + 6] += (unsigned long long)nrun;
                     }
                 }
+#endif
+                if (runs) {
+                    const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
+                    double y[NEQ];
+                    double t = A.t0;
+                    double h = FIXED ? A.fixed_step : A.h0;
+                    int reject_count = 0;
+                    uint32_t n_attempt = 0, n_accept = 0;
+                    if (!from_record) {
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i) y[i] = A.y0[(size_t)sys * NEQ + i];
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i) y[i] = coherent_load(&A.resume[(size_t)i * A.ns + sys]);
+                        t = coherent_load(&A.resume[(size_t)NEQ * A.ns + sys]);
+                        h = coherent_load(&A.resume[(size_t)(NEQ + 1) * A.ns + sys]);
+                        reject_count = coherent_load(&resume_i[(size_t)0 * A.ns + sys]);
+                        n_attempt = (uint32_t)coherent_load(&resume_i[(size_t)1 * A.ns + sys]);
+                        n_accept = (uint32_t)coherent_load(&resume_i[(size_t)2 * A.ns + sys]);
+                    }
+                    HeldForcing<Model, false> held;  // the samples of the first attempt are fetched at its t (as a resumed lane does)
+                    held.init(A, sys);
+                    typename Model::Forc FV = Model::prep_forcing(P, held.F);
+                    bool have_k0 = false;  // k0 = rhs(t, y, F) is a pure function: recomputed, it has the bits of the carried one
+                    double k0[NEQ];
 
-                HLM_QMARK(2, 4);
-                if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
-                if (status == HLM_SYS_OK && t < tf) {
-                    // paused at the end of its run's last piece: the next run continues exactly here
-                    coherent_store(&resume_i[(size_t)4 * A.ns + sys], SYS_PAUSED);
+                    // ---- the loop of rk45_multi_kernel, piece by piece --------------------------------------------
+                    // lanes pause the first time t reaches the end of their piece (the last piece runs to tf) and go on
+                    // together with the next piece of the run: the protocol of a hand-over, without the hand-over
+                    double t_end = w_end;
+                    for (unsigned c = c_begin; c < c_end; ++c) {
+                        t_end = c + 1u < (unsigned)nchunk ? fmin(w_end, R.t_begin + (double)(c + 1u) * R.piece_len) : w_end;
+                        while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
+                            if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
+                            if (held.refresh(A, P, t, FV)) have_k0 = false;
+                            ++n_attempt;
+                            double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
+                            [[maybe_unused]] double err = 0.0, jump = 0.0;
+                            attempt_on_cheapest_path<Model, MATH, FIXED, false>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                            [[maybe_unused]] double fac = 1.0;
+                            if constexpr (!FIXED) {
+                                fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);  // rk45_kernel.cu:151,156
+                                if (err <= 1.0) {
+                                    reject_count = 0;
+                                    if (jump > SLOPE_JUMP_THRESH) {  // rk45_kernel.cu:132-136
+                                        h = fmax(h * 0.5, A.h0 * MIN_STEP_FRACTION);
+                                        continue;
+                                    }
+                                } else {  // rk45_kernel.cu:153-163
+                                    ++reject_count;
+                                    double f = fmin(fac, 1.0);
+                                    f = fmin(fmax(f, A.min_scale), A.max_scale);
+                                    h *= f;
+                                    if (reject_count > 5 || h < (tf - A.t0) * MIN_STEP_FRACTION) status = HLM_SYS_STIFF;
+                                    continue;
+                                }
+                            }
 #pragma unroll
-                    for (int i = 0; i < NEQ; ++i) coherent_store(&A.resume[(size_t)i * A.ns + sys], y[i]);
-                    coherent_store(&A.resume[(size_t)NEQ * A.ns + sys], t);
-                    coherent_store(&A.resume[(size_t)(NEQ + 1) * A.ns + sys], h);
-                    coherent_store(&resume_i[(size_t)0 * A.ns + sys], reject_count);
-                    coherent_store(&resume_i[(size_t)1 * A.ns + sys], (int)n_attempt);
-                    coherent_store(&resume_i[(size_t)2 * A.ns + sys], (int)n_accept);
-                } else {
-                    coherent_store(&resume_i[(size_t)4 * A.ns + sys], status);
-                    if (A.n_attempt) A.n_attempt[sys] = n_attempt;
-                    if (A.n_accept) A.n_accept[sys] = n_accept;
-                    const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170
-                    A.stiff[sys] = flagged ? status : HLM_SYS_OK;
+                            for (int i = 0; i < NEQ; ++i) {
+                                y[i] = yt[i];
+                                k0[i] = k6[i];  // = rhs(t1, y_new, F): next attempt's k0 unless the forcing moves
+                            }
+                            t += h;
+                            ++n_accept;
+                            if constexpr (FIXED) h = A.fixed_step;
+                            else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+                        }
+                    }
+
+                    HLM_QMARK(2, 4);
+                    if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
+                    if (status == HLM_SYS_OK && t < tf) {
+                        // paused at the end of its run's last piece: the next run continues exactly here
+                        coherent_store(&resume_i[(size_t)4 * A.ns + sys], SYS_PAUSED);
 #pragma unroll
-                    for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
-                    if (A.flag_state && flagged) record_flag_state<NEQ>(A.flag_state, sys, y, t);
+                        for (int i = 0; i < NEQ; ++i) coherent_store(&A.resume[(size_t)i * A.ns + sys], y[i]);
+                        coherent_store(&A.resume[(size_t)NEQ * A.ns + sys], t);
+                        coherent_store(&A.resume[(size_t)(NEQ + 1) * A.ns + sys], h);
+                        coherent_store(&resume_i[(size_t)0 * A.ns + sys], reject_count);
+                        coherent_store(&resume_i[(size_t)1 * A.ns + sys], (int)n_attempt);
+                        coherent_store(&resume_i[(size_t)2 * A.ns + sys], (int)n_accept);
+                    } else {
+                        coherent_store(&resume_i[(size_t)4 * A.ns + sys], status);
+                        if (A.n_attempt) A.n_attempt[sys] = n_attempt;
+                        if (A.n_accept) A.n_accept[sys] = n_accept;
+                        const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170
+                        A.stiff[sys] = flagged ? status : HLM_SYS_OK;
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
+                        if (A.flag_state && flagged) record_flag_state<NEQ>(A.flag_state, sys, y, t);
+                    }
                 }
             }
         }
@@ -288,7 +336,8 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         HLM_QMARK(2, 6);
         HLM_QPROF_ADD(2, wall_clock64() - prof_t1);
         HLM_QPROF(1, wall_clock64());
-        __hip_atomic_store(&done[tile], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
+        if (G > 1u) (void)__hip_atomic_fetch_add(&done[dep], lane == 0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // one more pass of the group
+        else __hip_atomic_store(&done[tile], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
         HLM_QMARK(2, 7);
     }
 }

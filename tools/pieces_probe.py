@@ -22,6 +22,7 @@ ap.add_argument("--wet", action="store_true")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--pieces", type=int, nargs="*", default=[0, 2, 4, 8, 16, 32, 0])
 ap.add_argument("--runs", type=int, nargs="*", default=[0], help="hlm_device_job.queue_run_pieces per piece count: 0 automatic, 1 every piece handed over, n runs of n pieces")
+ap.add_argument("--groups", type=int, nargs="*", default=[0], help="hlm_device_job.queue_group_tiles per piece count")
 a = ap.parse_args()
 sp = synth.model204_params(0, a.ns)
 y0 = synth.model204_y0(a.ns, wet_surface=a.wet)
@@ -29,8 +30,8 @@ cells = synth.cell_of_system(0, a.ns)
 pr, t2m, dt, nT = synth.forcing_tables(days=a.days, tmin=a.tmin)
 tf = a.days * 1440.0
 ref = None
-for p, rp in [(p, rp) for p in a.pieces for rp in (a.runs if p > 1 else [0])]:
-    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, math_mode=H.MATH_FAST, time_pieces=p, queue_run_pieces=rp)
+for p, rp, gt in [(p, rp, gt) for p in a.pieces for rp in (a.runs if p > 1 else [0]) for gt in (a.groups if p > 1 else [0])]:
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, math_mode=H.MATH_FAST, time_pieces=p, queue_run_pieces=rp, queue_group_tiles=gt)
     eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     eng.integrate()
     torch.cuda.synchronize()
@@ -47,6 +48,6 @@ for p, rp in [(p, rp) for p in a.pieces for rp in (a.runs if p > 1 else [0])]:
     if ref is None:
         ref = got
     att = eng.total_attempts()
-    print(f"time_pieces {p:3d} run_pieces {rp:2d}: ms {np.mean(ms):8.3f} (min {min(ms):8.3f})  steps/s {att / (np.mean(ms) * 1e-3):.4e}  bit-identical to the fixed map: {same}", flush=True)
+    print(f"time_pieces {p:3d} run_pieces {rp:2d} group_tiles {gt:2d}: ms {np.mean(ms):8.3f} (min {min(ms):8.3f})  steps/s {att / (np.mean(ms) * 1e-3):.4e}  bit-identical to the fixed map: {same}", flush=True)
     del eng
     torch.cuda.empty_cache()

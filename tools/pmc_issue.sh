@@ -14,9 +14,9 @@ for W in headline wet cold cold_radau cold_radau_continue; do
   case $W in
     headline) EXTRA="";;
     wet) EXTRA="--wet-surface";;
-    cold) EXTRA="--tmin -5 --queue-run-pieces 1";;
-    cold_radau) EXTRA="--tmin -5 --radau --queue-run-pieces 1";;
-    cold_radau_continue) EXTRA="--tmin -5 --radau --radau-continue --queue-run-pieces 1";;
+    cold) EXTRA="--tmin -5 --group-tiles 8";;
+    cold_radau) EXTRA="--tmin -5 --radau --group-tiles 8";;
+    cold_radau_continue) EXTRA="--tmin -5 --radau --radau-continue --group-tiles 8";;
   esac
   for P in A B; do
     if [ $P = A ]; then C="$PASS_A"; else C="$PASS_B"; fi

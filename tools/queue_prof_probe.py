@@ -21,6 +21,7 @@ ap.add_argument("--days", type=int, default=30)
 ap.add_argument("--tmin", type=float, default=0.5)
 ap.add_argument("--pieces", type=int, default=32)
 ap.add_argument("--sched", nargs="*", default=["1", "auto"])
+ap.add_argument("--group", type=int, default=0, help="hlm_device_job.queue_group_tiles")
 a = ap.parse_args()
 L = H._lib.lib()
 assert hasattr(L, "hlm_debug_queue_prof"), "needs a -DHLM_QUEUE_PROF build (HLM_HIP_LIB)"
@@ -40,7 +41,7 @@ for sched in a.sched:
         os.environ["HLM_QUEUE_RUNS"] = sched
     else:
         rp = int(sched)
-    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, math_mode=H.MATH_FAST, time_pieces=a.pieces, queue_run_pieces=rp)
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, math_mode=H.MATH_FAST, time_pieces=a.pieces, queue_run_pieces=rp, queue_group_tiles=a.group)
     eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     L.hlm_debug_queue_prof(C.c_void_p(0))
     eng.integrate()

@@ -17,7 +17,7 @@ days = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns)
 cells = synth.cell_of_system(0, ns)
 pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
-eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, queue_run_pieces=1)
+eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, time_pieces=int(os.environ.get('HLM_PROBE_PIECES', '32')), queue_group_tiles=int(os.environ.get('HLM_PROBE_GROUP', '8')))
 eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
 out = {"lib": os.path.basename(os.environ.get("HLM_HIP_LIB", "libhlm_hip.so")), "ns": ns, "days": days}
 for tag, radau in (("rk45", False), ("restart", True), ("continue", "continue")):
