@@ -59,12 +59,12 @@ def make_case(seed, ns, days, radau=False):
                 block=block, tf=days * 1440.0)
 
 
-def gpu_run(case, math_mode, params=DEFAULT_PARAMS, radau=False, query=None, time_pieces=None):
+def gpu_run(case, math_mode, params=DEFAULT_PARAMS, radau=False, query=None, time_pieces=None, group_tiles=0):
     """One GPU integration of a fuzz case through the engine (the C ABI underneath).  ``time_pieces`` given: without
-    dense output, in that launch shape (hlm_device_job.time_pieces)."""
+    dense output, in that launch shape (hlm_device_job.time_pieces; ``group_tiles``: queue_group_tiles)."""
     q = None if time_pieces is not None else (case["q"] if query is None else query)
     eng = ShardEngine(H.Model204, case["y0"], 0.0, case["tf"], sp=case["sp"], query=q, math_mode=math_mode,
-                      attempt_cap=2_000_000, params=H.Parameters(*params), time_pieces=time_pieces)
+                      attempt_cap=2_000_000, params=H.Parameters(*params), time_pieces=time_pieces, queue_group_tiles=group_tiles)
     if case["per_cell"]:
         eng.set_forcings_per_cell((case["pr"], case["t2m"]), case["cells"], case["dt"], case["nT"])
     else:
@@ -73,7 +73,47 @@ def gpu_run(case, math_mode, params=DEFAULT_PARAMS, radau=False, query=None, tim
     return eng.results()
 
 
+NODENSE = False  # argv[4] == "nodense": launches WITHOUT dense output (the kind bench.py times: queue kernel, per-lane RHS forms, closed form)
+
+
+def one_nodense(seed, ns, days):
+    """The no-dense launches against the oracle's finals: the queue kernel (6 pieces), bit-compared with one wave per
+    tile and with groups of 8 tiles packed per piece; same yardstick rule as one()."""
+    c = make_case(seed, ns, days)
+    kw = dict(sp=c["sp"], forc=c["block"], forc_dt_h=c["dt"], forc_nT=c["nT"], attempt_cap=2_000_000)
+    ref = O.run(O.UID_204, c["y0"], 0.0, days * 1440.0, **kw)
+    alts = yardstick_runs(O, O.UID_204, c["y0"], 0.0, days * 1440.0, perturbations=YARDSTICK_PERTURBATIONS, **kw)
+    problems = []
+    for mm in (0, 1):
+        got = gpu_run(c, mm, time_pieces=6)
+        shapes_equal = all(np.array_equal(got[k], o[k]) for o in (gpu_run(c, mm, time_pieces=0), gpu_run(c, mm, time_pieces=9, group_tiles=8))
+                           for k in ("y_final", "stiff", "n_attempt", "n_accept"))
+        got_alts = [gpu_run(c, mm, perturbed_params(DEFAULT_PARAMS, er, eh), time_pieces=6) for er, eh in YARDSTICK_PERTURBATIONS[:4]]
+        within, exempt, dev, spread = parity_or_shown_ill_conditioned(got, ref, alts, names=("y_final",), got_alts=got_alts)
+        bad = ~(within | exempt)
+        second_tier = 0
+        if bad.any():
+            idx = np.flatnonzero(bad)
+            s2, f2 = extended_yardstick(O, O.UID_204, c["y0"], 0.0, days * 1440.0, idx, names=("y_final",), **kw)
+            shown = f2 | (s2 >= 0.5) | (s2 >= dev[idx])
+            exempt[idx[shown]] = True
+            second_tier = int(shown.sum())
+            bad = ~(within | exempt)
+        same = got["stiff"] == ref["stiff"]
+        dn = np.abs(got["n_attempt"][same].astype(np.int64) - ref["n_attempt"][same].astype(np.int64))
+        info = dict(seed=seed, math=mm, nodense=True, shapes_equal=bool(shapes_equal), flagged=int((ref["stiff"] != 0).sum()),
+                    flag_mismatch=int((~same).sum()), worst_within=round(float(dev[within].max()), 4) if within.any() else 0.0,
+                    exempt=int(exempt.sum()), second_tier=second_tier, unexplained=int(bad.sum()),
+                    max_dn=int(dn.max()) if dn.size else 0, finite=bool(np.isfinite(got["y_final"]).all()))
+        if info["unexplained"] > max(1, ns // 1000) or info["exempt"] > 0.15 * ns or not info["finite"] or not shapes_equal:
+            problems.append(info)
+        print(info, flush=True)
+    return problems
+
+
 def one(seed, ns, days):
+    if NODENSE:
+        return one_nodense(seed, ns, days)
     c = make_case(seed, ns, days, RADAU)
     sp, y0, q, per_cell, run_len = c["sp"], c["y0"], c["q"], c["per_cell"], c["run_len"]
     kw = dict(query=q, sp=sp, forc=c["block"], forc_dt_h=c["dt"], forc_nT=c["nT"], attempt_cap=2_000_000, radau=RADAU)
@@ -117,8 +157,9 @@ def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     ns = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
     days = int(sys.argv[3]) if len(sys.argv) > 3 else 3
-    global RADAU
+    global RADAU, NODENSE
     RADAU = len(sys.argv) > 4 and sys.argv[4] == "radau"
+    NODENSE = len(sys.argv) > 4 and sys.argv[4] == "nodense"
     bad = []
     for seed in range(1000, 1000 + n):
         bad += one(seed, ns, days)
