@@ -26,11 +26,11 @@ out = {"tag": tag, "source": "tools/pmc_issue.sh (rocprofv3 --pmc, two SQ passes
 for w in ("headline", "wet", "cold", "cold_radau", "cold_radau_continue"):
     counters, kname, meta = {}, None, {}
     for p in ("A", "B"):
-        files = glob.glob(os.path.join(src, f"{w}_{p}", "*", "*_counter_collection.csv"))
+        files = sorted(glob.glob(os.path.join(src, f"{w}_{p}", "*", "*_counter_collection.csv")), key=os.path.getmtime)   # (gpurun merges the directories of several calls: take the newest)
         if not files:
             continue
         want = ("radau_fallback_kernel",) if w.startswith("cold_radau") else ("rk45_queue_kernel", "rk45_multi_kernel")
-        rows = [r for r in csv.DictReader(open(files[0])) if any(k in r["Kernel_Name"] for k in want)]
+        rows = [r for r in csv.DictReader(open(files[-1])) if any(k in r["Kernel_Name"] for k in want)]
         if not rows:
             continue
         by = {}

@@ -25,11 +25,11 @@ os.makedirs(prof, exist_ok=True)
 
 
 def rows(sub):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))
-    return list(csv.DictReader(open(f[0]))) if f else []
+    f = sorted(glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv")), key=os.path.getmtime)
+    return list(csv.DictReader(open(f[-1]))) if f else []   # (the newest: gpurun merges the directories of several calls)
 
 
-stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+stats = sorted(glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")), key=os.path.getmtime)[-1]
 lines = open(stats).read().splitlines()
 with open(os.path.join(prof, f"{tag}_kernel_stats.csv"), "w") as f:
     f.write("\n".join(lines[:12]) + "\n")
