@@ -109,6 +109,7 @@ def parse():
     ap.add_argument("--dense-window", type=int, default=96, help="queries per streamed window (1 M x 96 x 40 B = 3.84 GB per buffer)")
     ap.add_argument("--c5-ns", type=int, default=500_000, help="hillslopes of the config-5 share run in HBM windows (0 skips it)")
     ap.add_argument("--c5-days", type=int, default=30)
+    ap.add_argument("--c5-window", type=int, default=1440, help="queries per HBM window of the config-5 share")
     ap.add_argument("--dense-hbm-ns", type=int, default=1_000_000,
                     help="hillslopes of the in-HBM dense kernel measurement (1 day at 1-minute stride; 0 skips it)")
     ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
@@ -362,7 +363,7 @@ def dense_section(args):
     if ns3 > 0:
         tf3 = days3 * 1440.0
         q3 = synth.minute_queries(0.0, tf3, 1.0)          # 0 .. tf: days x 1440 + 1 queries
-        W3 = 1440
+        W3 = args.c5_window
         free_b, _ = torch.cuda.mem_get_info()
         if 40.0 * ns3 * W3 > 0.8 * free_b:
             ns3 = max(65536, int(0.8 * free_b / (40.0 * W3)) // 65536 * 65536)

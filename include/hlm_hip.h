@@ -298,6 +298,12 @@ typedef struct hlm_device_job {
      * lanes without any global re-tiling, extra launch or drain.  Every piece is handed over through the record
      * (queue_run_pieces is ignored).  Same results bit for bit.  0 / 1: an item is a tile.  At most 16. */
     int queue_group_tiles;
+    /* (ABI 4) Launch shape of a dense launch in the tile layout (dense_tiled = 2): n > 1 cuts the launch's query window
+     * into n sub-windows and runs the launch as a persistent grid over (sub-window, tile) items -- a lane pauses at the
+     * end of its sub-window as it does at the end of a query window and whichever wave draws the tile's next
+     * sub-window continues from the state record -- so that the launch does not end on waves that each run the whole
+     * window.  Same rows bit for bit.  0 = automatic, 1 = one wave per tile for the whole window. */
+    int dense_sub_windows;
 } hlm_device_job;
 
 /* The number of time pieces hlm_rk45_integrate_device(job) launches with (the automatic rule resolved; 0 = one wave

@@ -55,7 +55,7 @@ def test_struct_layouts_match_header(hlm, tmp_path):
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
-    assert len(hlm._lib.DeviceJob._fields_) == 39 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
+    assert len(hlm._lib.DeviceJob._fields_) == 40 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
 
 
 def test_registry_roundtrip_and_validation_without_gpu(hlm):

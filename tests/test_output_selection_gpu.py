@@ -348,3 +348,64 @@ def test_selection_on_the_three_state_model(gpu, layout):
         assert np.array_equal(got["y_final"], full["y_final"])
     with pytest.raises(H.HlmError):
         run((3,))
+
+
+# ---- dense launches as a persistent grid over (sub-window, tile) items (hlm_device_job.dense_sub_windows) --------------
+@pytest.mark.parametrize("case", ["wet-with-early-queries", "cold-cells-flagged", "ragged-sub-wave", "strict", "toy", "selected"])
+def test_dense_sub_windows_hold_the_same_rows(gpu, case):
+    """hlm_device_job.dense_sub_windows = n: the dense launch in the tile layout (csrc/hlm_rk45_dense_kernel.h) as a
+    persistent grid over (sub-window, tile) items -- a lane pauses at the end of its sub-window exactly as at the end
+    of a query window (steps that straddle it are given back and redone) and another wave continues the tile from the
+    state record.  Rows, finals, flags and both counters equal the one-wave-per-tile launch bit for bit for n = 2, 3, 7
+    and 64 (more sub-windows than some steps have queries): queries before t0 and past tf, cold cells with hillslopes
+    flagged in different sub-windows (zero rows from there on), fewer hillslopes than a wave, STRICT arithmetic, the
+    three-state model, a device-side output selection; and inside the windowed streaming to the host (the sub-windows
+    then cut each window; the lanes live in the caller's record)."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    kw, days, model = {}, 2, H.Model204
+    if case == "toy":
+        rng = np.random.default_rng(3)
+        ns, days = 300, 3
+        sp = synth.model204_params(0, ns, seed=3)
+        sp["alpha3"] = rng.uniform(5.0, 60.0, ns)
+        sp["alpha4"] = rng.uniform(20.0, 400.0, ns)
+        y0 = np.stack([rng.uniform(0.0, 2.0, ns), rng.uniform(0.0, 1.0, ns), rng.uniform(0.0, 0.5, ns)], axis=1)
+        cells = synth.cell_of_system(0, ns, ncell=16, run_len=7)
+        inflow = ((rng.random((24 * days, 16)) < 0.3) * rng.uniform(0.0, 0.2, (24 * days, 16))).astype(np.float32)
+        model = H.ToyModel3
+        q = synth.minute_queries(0.0, days * 1440.0, 23.0)
+    else:
+        ns, tmin, wet = {"wet-with-early-queries": (300, 0.5, True), "cold-cells-flagged": (5000, -5.0, False), "ragged-sub-wave": (37, 0.5, True),
+                         "strict": (700, 0.5, True), "selected": (1000, -5.0, True)}[case]
+        days = 8 if case == "cold-cells-flagged" else 2
+        sp, y0, cells, pr, t2m, dt, nT, q = _case(H, ns=ns, days=days, wet=wet, tmin=tmin)
+        if case == "strict":
+            kw = dict(math_mode=H.MATH_STRICT)
+        if case == "selected":
+            kw = dict(dense_states=(1, 3))
+
+    def engine(n):
+        eng = ShardEngine(model, y0, 0.0, days * 1440.0, sp=sp, query=q, dense_tiled=2, dense_sub_windows=n, **kw)
+        if case == "toy":
+            eng.set_forcings_per_cell((inflow,), cells, (1.0,), (inflow.shape[0],))
+        else:
+            eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+        return eng
+    e1 = engine(1)
+    e1.integrate()
+    one = e1.results()
+    if case == "cold-cells-flagged":
+        assert 0.02 < (one["stiff"] == 1).mean() < 0.98
+    for n in (2, 3, 7, 64):
+        e = engine(n)
+        e.dense.fill_(-7.0)   # every row of the buffer is written by the launch
+        e.integrate()
+        got = e.results()
+        for k in ("dense", "y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(got[k], one[k]), (case, n, k)
+    # windowed streaming to the host with sub-windows inside every window
+    e = engine(3)
+    host, _ = e.integrate_streamed(37)
+    assert np.array_equal(host, one["dense"]) and np.array_equal(e.results()["y_final"], one["y_final"])

@@ -60,7 +60,7 @@ class DeviceJob(C.Structure):
         ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
         ("lane_refill", C.c_int),
         ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
-        ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int), ("queue_run_pieces", C.c_int), ("queue_group_tiles", C.c_int),
+        ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int), ("queue_run_pieces", C.c_int), ("queue_group_tiles", C.c_int), ("dense_sub_windows", C.c_int),
     ]
 
 

@@ -104,6 +104,18 @@ int auto_time_pieces(int num_systems, double t0, double tf)
     const double p = (tf - t0) / 720.0;
     return p >= 32.0 ? 32 : (p >= 8.0 ? (int)p : 0);
 }
+// The automatic number of sub-windows of a dense launch in the tile layout (hlm_device_job.dense_sub_windows = 0):
+// four when the launch has fewer than five rounds of waves (2 048 resident two-wave-per-SIMD slots on an MI355X; 640 000
+// hillslopes) and at least 64 queries per sub-window, else one wave per tile.  Measured, 1 440 queries x 1 day, same box
+// (profiles/r04_dense_subwindows_probe.txt): 200 000 hillslopes 3.74 -> 3.22 ms (n = 5), 500 000 (config 5's share per
+// GPU) 7.39 -> 7.21 ms = 0.487 -> 0.500 of the HBM spec, 1 000 000 13.67 -> 13.87 ms: every item pays a prologue, an
+// epilogue and a drained ring, which only a launch with few rounds earns back at its end.
+int auto_dense_sub_windows(int num_systems, int window_queries)
+{
+    const long long tiles = ((long long)num_systems + hlm::WAVE - 1) / hlm::WAVE;
+    if (tiles >= 5ll * 2048ll || window_queries < 4 * 64) return 0;
+    return 4;
+}
 int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
 // hlm_set_output_states(): the dense rows of the host API carry only these state components (0 = all)
 int g_out_ncomp = 0;
@@ -228,6 +240,21 @@ KernelFn pick_dense_ring(int uid, int math, bool fixed, bool res)
     return with_model<KernelFn>(uid, [&](auto m) { return pick_dense_ring<decltype(m)>(math, fixed, res); });
 }
 
+// the dense ring kernel as a persistent grid over (sub-window, tile) items (hlm_rk45_dense_kernel.h): adaptive steps
+using DenseQueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int);
+template <class Model>
+DenseQueueFn pick_dense_queue(int math, bool sel)
+{
+    using namespace hlm;
+    constexpr int R = HLM_DENSE_RING_ROWS;
+    if (math == HLM_MATH_FAST) return sel ? rk45_dense_queue_kernel<Model, MATH_FAST, false, R, true> : rk45_dense_queue_kernel<Model, MATH_FAST, false, R, false>;
+    return sel ? rk45_dense_queue_kernel<Model, MATH_STRICT, false, R, true> : rk45_dense_queue_kernel<Model, MATH_STRICT, false, R, false>;
+}
+DenseQueueFn pick_dense_queue(int uid, int math, bool sel)
+{
+    return with_model<DenseQueueFn>(uid, [&](auto m) { return pick_dense_queue<decltype(m)>(math, sel); });
+}
+
 #ifdef HLM_EXPERIMENTAL_PATHS
 // the kernels with lane refill (hlm_rk45_refill_kernel.h): no dense output, no resume state
 using RefillFn = void (*)(const hlm::Rk45Args, unsigned int*);
@@ -334,6 +361,7 @@ int validate_job(const hlm_device_job* j)
     if (j->time_pieces > 1 && ((long long)j->num_systems + 63) / 64 * (long long)j->time_pieces >= (1ll << 32) - 1)
         return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces %d x %d hillslopes: more than 2^32 (piece, tile) items", j->time_pieces, j->num_systems);
     if (j->queue_run_pieces < 0) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_run_pieces must be >= 0 (0 = automatic)");
+    if (j->dense_sub_windows < 0 || j->dense_sub_windows > 4096) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_sub_windows must be within [0, 4096]");
     if (j->queue_group_tiles < 0 || j->queue_group_tiles > hlm::QUEUE_MAX_GROUP)
         return fail(HLM_ERR_INVALID_ARGUMENT, "queue_group_tiles must be within [0, %d]", hlm::QUEUE_MAX_GROUP);
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
@@ -569,10 +597,64 @@ int job_time_pieces(const hlm_device_job* j)
     return pieces > 1 ? pieces : 0;
 }
 
+// sub-windows of a dense launch in the tile layout (hlm_device_job.dense_sub_windows; 0 = the automatic rule)
+int job_dense_sub_windows(const hlm_device_job* j)
+{
+    if (j->num_queries <= 0 || j->dense_tiled != hlm::DENSE_TILE_COMP || j->fixed_step > 0.0) return 0;
+    if (j->use_t_stop || j->forc_first_index[0] != 0) return 0;   // (time chunks / forcing chunks: one wave per tile)
+    for (int k = 0; k < j->nforc; ++k)
+        if (j->forc_first_index[k] != 0 || (j->forc_rows[k] != 0 && j->forc_rows[k] != j->forc_nT[k])) return 0;
+    const int qb = j->query_end ? j->query_begin : 0, qe = j->query_end ? j->query_end : j->num_queries;
+    int n = j->dense_sub_windows;
+    if (n == 0) n = auto_dense_sub_windows(j->num_systems, qe - qb);
+    if (n > qe - qb) n = qe - qb;
+    return n > 1 ? n : 0;
+}
+
+// The dense ring kernel as a persistent grid over (sub-window, tile) items.  The lane states between the sub-windows
+// live in the caller's record when the job has one (a query window of a streamed run: the launch also starts from it
+// and leaves the paused lanes in it), else in a stream-ordered scratch allocation.
+int launch_dense_queue(const hlm_device_job* j, int nsub, hipStream_t stream)
+{
+    DenseQueueFn fn = pick_dense_queue(j->uid, j->math_mode, job_selects(j));
+    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
+    int dev = 0, cus = 0, per_cu = 0;
+    HLM_HIP_TRY(hipGetDevice(&dev));
+    HLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+    HLM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), hlm::WAVE, 0));
+    const long long resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
+    const long long tiles = ((long long)j->num_systems + hlm::WAVE - 1) / hlm::WAVE;
+    const unsigned blocks = (unsigned)(tiles < resident ? tiles : resident);
+    const size_t rbytes = j->d_resume ? 0 : (hlm_resume_bytes_model(j->uid, j->num_systems) + 15u) & ~(size_t)15u;
+    const size_t qbytes = sizeof(unsigned int) * ((size_t)tiles + 2);  // next item | finished sub-windows per tile | abort word
+    char* pool = nullptr;
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + qbytes, stream));
+    unsigned int* queue = reinterpret_cast<unsigned int*>(pool + rbytes);
+    {
+        const unsigned int words = (unsigned int)(qbytes / sizeof(unsigned int));
+        hipLaunchKernelGGL(hlm::queue_init_kernel, dim3((words + 255u) / 256u), dim3(256), 0, stream, queue, words);
+        if (hipError_t e = hipGetLastError(); e != hipSuccess) {
+            (void)hipFreeAsync(pool, stream);
+            return fail(HLM_ERR_HIP, "queue_init_kernel failed: %s", hipGetErrorString(e));
+        }
+    }
+    hlm::Rk45Args a = make_args(j);
+    if (!j->d_resume) {
+        a.resume = reinterpret_cast<double*>(pool);
+        a.resume_in = 0;
+    }
+    hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, nsub);
+    const hipError_t launched = hipGetLastError();
+    HLM_HIP_TRY(hipFreeAsync(pool, stream));  // stream-ordered: after the kernel
+    HLM_HIP_TRY(launched);
+    return HLM_SUCCESS;
+}
+
 int launch(const hlm_device_job* j, hipStream_t stream)
 {
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
+    if (const int nsub = job_dense_sub_windows(j); nsub > 1) return launch_dense_queue(j, nsub, stream);
 #ifdef HLM_EXPERIMENTAL_PATHS
     if (!dense && j->lane_refill && !job_is_resumable(j)) return launch_refill(j, stream);
 #endif

@@ -97,19 +97,24 @@ __device__ unsigned long long g_phase_cycles[8];
 #define HLM_STAMP(v)
 #endif
 
-template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R, bool SEL = false>
-__global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
+// One tile (64 hillslopes, one wave) through the query window [qb, qe) of a buffer that holds the rows [bqb, bqe):
+// the body of both dense kernels below.  QUEUED: the lane states come from and go to the record with device-coherent
+// accesses (another wave of the same launch wrote or will read them: rk45_dense_queue_kernel).
+template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R, bool SEL, bool QUEUED>
+__device__ __forceinline__ void dense_ring_tile(const Rk45Args& A, const unsigned blk, const int qb, const int qe, const int bqb, const int bqe,
+                                                const int resume_in)
 {
     using namespace dp;
     static_assert(R > 0 && (R & (R - 1)) == 0, "the ring slot of row q is q & (R - 1)");
+    static_assert(RESUMABLE || !QUEUED, "sub-windows hand the lanes over through the record");
     constexpr int NEQ = Model::N_EQ, RESUME_F64 = resume_f64(NEQ);
-    // XCD-aware block -> hillslope-chunk map (see rk45_multi_kernel)
-    const unsigned nblk = gridDim.x, orig = blockIdx.x;
-    const unsigned xcd = orig & 7u, qd = nblk >> 3, rm = nblk & 7u;
-    const unsigned blk = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + (orig >> 3);
     const int lane = (int)threadIdx.x;
     const int sys = (int)(blk * WAVE) + lane;
     if (sys >= A.ns) return;
+    auto rload_f = [](const double* p) -> double { if constexpr (QUEUED) return coherent_load(p); else return *p; };
+    auto rload_i = [](const int* p) -> int { if constexpr (QUEUED) return coherent_load(p); else return *p; };
+    auto rstore_f = [](double* p, double v) { if constexpr (QUEUED) coherent_store(p, v); else *p = v; };
+    auto rstore_i = [](int* p, int v) { if constexpr (QUEUED) coherent_store(p, v); else *p = v; };
 
     using lds_double_ptr = __attribute__((address_space(3))) double*;
     // doubles per ring slot: N_EQ x 64, or (HLM_RING_POW2) the next power of two, so that a slot's offset is a shift
@@ -140,11 +145,10 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     // Query window [qb, qe) of this launch (the whole range unless the host streams the dense output
     // in windows, hlm_rk45_integrate_streamed); the buffer holds exactly these rows, tile-major:
     // element (q, c) of this lane = row0[(q - qb) * 64 N_EQ + c * 64].
-    const int qb = A.q_begin, qe = A.q_end;
     const int q_hi = A.nq < qe ? A.nq : qe;
     [[maybe_unused]] const int K = SEL ? A.dense_k : NEQ;  // components per row
     const size_t Q_STRIDE = SEL ? (size_t)WAVE * (size_t)A.dense_k : (size_t)WAVE * NEQ;
-    double* const row0 = A.dense + (size_t)blk * (size_t)(qe - qb) * Q_STRIDE + (size_t)lane;
+    double* const row0 = A.dense + (size_t)blk * (size_t)(bqe - bqb) * Q_STRIDE + (size_t)lane;
     // ring column of component c (SEL: its position in the row, or the spare last column -- dense_k < N_EQ)
     [[maybe_unused]] int col[NEQ];
 #pragma unroll
@@ -156,9 +160,9 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     int next_q = qb;  // this lane's query cursor: it has produced (or owes nothing for) the rows below it
     int* const resume_i =
         RESUMABLE && A.resume ? reinterpret_cast<int*>(A.resume + (size_t)RESUME_F64 * A.ns) : nullptr;
-    if (resume_i && A.resume_in) {
-        const int st = resume_i[(size_t)4 * A.ns + sys];
-        next_q = resume_i[(size_t)3 * A.ns + sys];
+    if (resume_i && resume_in) {
+        const int st = rload_i(&resume_i[(size_t)4 * A.ns + sys]);
+        next_q = rload_i(&resume_i[(size_t)3 * A.ns + sys]);
         if (next_q < qb) next_q = qb;  // (windows are visited in order; never index before the buffer)
         if (st != SYS_PAUSED) {
             live = false;
@@ -167,12 +171,12 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             t = tf;  // whatever stopped it, it takes no part in the integration any more
         } else {
 #pragma unroll
-            for (int i = 0; i < NEQ; ++i) y[i] = A.resume[(size_t)i * A.ns + sys];
-            t = A.resume[(size_t)NEQ * A.ns + sys];
-            h = A.resume[(size_t)(NEQ + 1) * A.ns + sys];
-            reject_count = resume_i[(size_t)0 * A.ns + sys];
-            n_attempt = (uint32_t)resume_i[(size_t)1 * A.ns + sys];
-            n_accept = (uint32_t)resume_i[(size_t)2 * A.ns + sys];
+            for (int i = 0; i < NEQ; ++i) y[i] = rload_f(&A.resume[(size_t)i * A.ns + sys]);
+            t = rload_f(&A.resume[(size_t)NEQ * A.ns + sys]);
+            h = rload_f(&A.resume[(size_t)(NEQ + 1) * A.ns + sys]);
+            reject_count = rload_i(&resume_i[(size_t)0 * A.ns + sys]);
+            n_attempt = (uint32_t)rload_i(&resume_i[(size_t)1 * A.ns + sys]);
+            n_accept = (uint32_t)rload_i(&resume_i[(size_t)2 * A.ns + sys]);
         }
     }
     const int my_start_q = next_q;  // rows below it were written by earlier launches: never touched here
@@ -400,7 +404,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
                 auto store = [&](int q, const double (&v)[NEQ]) {
                     // (a first launch owns every row of its window; a paused lane only the rows it produced)
                     if (!RESUMABLE || (next_q > q && q >= my_start_q)) {
-                        double* o = row0 + (size_t)(q - qb) * Q_STRIDE;
+                        double* o = row0 + (size_t)(q - bqb) * Q_STRIDE;
 #pragma unroll
                         for (int c = 0; c < NEQ; ++c)
                             if (!SEL || c < K) o[c * WAVE] = v[c];
@@ -428,7 +432,7 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
             for (int c = 0; c < NEQ; ++c)
                 if (!SEL || c < K) v[c] = slot[c * WAVE];
             if (has_row && (!RESUMABLE || q_flush >= my_start_q)) {  // (a first launch owns every row of its window)
-                double* o = row0 + (size_t)(q_flush - qb) * Q_STRIDE;
+                double* o = row0 + (size_t)(q_flush - bqb) * Q_STRIDE;
 #pragma unroll
                 for (int c = 0; c < NEQ; ++c)
                     if (!SEL || c < K) o[c * WAVE] = v[c];
@@ -461,17 +465,17 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
     if (RESUMABLE && mode == M_STUCK) status = SYS_PAUSED;  // stopped at t_stop
     if (resume_i) {
         // a lane that has stopped for good has (zero-)written every row the wave flushed
-        resume_i[(size_t)3 * A.ns + sys] = (status != SYS_PAUSED && q_flush > next_q) ? q_flush : next_q;
+        rstore_i(&resume_i[(size_t)3 * A.ns + sys], (status != SYS_PAUSED && q_flush > next_q) ? q_flush : next_q);
         if (!finished_before) {
-            resume_i[(size_t)4 * A.ns + sys] = status;
+            rstore_i(&resume_i[(size_t)4 * A.ns + sys], status);
             if (status == SYS_PAUSED) {
 #pragma unroll
-                for (int i = 0; i < NEQ; ++i) A.resume[(size_t)i * A.ns + sys] = y[i];
-                A.resume[(size_t)NEQ * A.ns + sys] = t;
-                A.resume[(size_t)(NEQ + 1) * A.ns + sys] = h;
-                resume_i[(size_t)0 * A.ns + sys] = reject_count;
-                resume_i[(size_t)1 * A.ns + sys] = (int)n_attempt;
-                resume_i[(size_t)2 * A.ns + sys] = (int)n_accept;
+                for (int i = 0; i < NEQ; ++i) rstore_f(&A.resume[(size_t)i * A.ns + sys], y[i]);
+                rstore_f(&A.resume[(size_t)NEQ * A.ns + sys], t);
+                rstore_f(&A.resume[(size_t)(NEQ + 1) * A.ns + sys], h);
+                rstore_i(&resume_i[(size_t)0 * A.ns + sys], reject_count);
+                rstore_i(&resume_i[(size_t)1 * A.ns + sys], (int)n_attempt);
+                rstore_i(&resume_i[(size_t)2 * A.ns + sys], (int)n_accept);
             }
         }
     }
@@ -483,6 +487,77 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = flagged ? 0.0 : y[i];
         if (A.flag_state && flagged) record_flag_state<NEQ>(A.flag_state, sys, y, t);
+    }
+}
+
+// One wave per tile for the launch's whole query window (grid = ceil(ns / 64)).
+template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R, bool SEL = false>
+__global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
+{
+    // XCD-aware block -> hillslope-chunk map (see rk45_multi_kernel)
+    const unsigned nblk = gridDim.x, orig = blockIdx.x;
+    const unsigned xcd = orig & 7u, qd = nblk >> 3, rm = nblk & 7u;
+    const unsigned blk = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + (orig >> 3);
+    dense_ring_tile<Model, MATH, FIXED, RESUMABLE, R, SEL, false>(A, blk, A.q_begin, A.q_end, A.q_begin, A.q_end, A.resume_in);
+}
+
+// The same launch as a PERSISTENT grid over (sub-window, tile) items (round 4).  The launch's query window is cut into
+// nsub sub-windows and every resident wave keeps drawing the next item, sub-window-major, from a device counter; a
+// lane pauses at the end of its sub-window exactly as it does at the end of a query window (the RESUMABLE protocol:
+// same committed steps, same rows) and whichever wave draws the tile's next sub-window continues from the state
+// record, read and written with device-coherent accesses.  Why: with one wave per tile the launch ends on waves that
+// all run the window's length (1 M hillslopes: 7.6 rounds of 2 048 waves, 500 000: 3.8) and its last round is the
+// emptier the fewer rounds there are -- 0.51 of the HBM spec at 1 M hillslopes per launch, 0.48 at 500 000, whatever
+// the window's length (profiles/r04_dense_subwindows_probe.txt); with items a quarter of a window long the end of the
+// launch is a quarter as ragged.  Item (s, tile) waits for (s - 1, tile) through a per-tile counter, as in
+// rk45_queue_kernel: drawn earlier, so finished or running on a resident wave.
+template <class Model, int MATH, bool FIXED, int R, bool SEL = false>
+__global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nsub)
+{
+    const int lane = (int)threadIdx.x;
+    const unsigned ntiles = ((unsigned)A.ns + WAVE - 1u) / WAVE, nitems = ntiles * (unsigned)nsub;
+    unsigned int* const done = queue + 1;
+    const long long Q0 = A.q_begin, QN = (long long)A.q_end - A.q_begin;
+    // (no branch on the lane number anywhere in the protocol, and the loop is bounded: see rk45_queue_kernel)
+    for (unsigned drawn = 0; drawn <= nitems; ++drawn) {
+        const unsigned item = (unsigned)__builtin_amdgcn_readfirstlane(
+            (int)__hip_atomic_fetch_add(queue, lane == 0 ? 1u : 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        if (item >= nitems) break;
+        const unsigned s = item / ntiles, tile = item - s * ntiles;
+        bool lost = false;
+        if (s > 0) {
+            auto finished = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&done[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); };
+            if (finished() < s) {
+                const unsigned long long since = wall_clock64();
+                while (finished() < s) {
+                    __builtin_amdgcn_s_sleep(16);
+                    const unsigned aborted = (unsigned)__builtin_amdgcn_readfirstlane(
+                        (int)__hip_atomic_load(&done[ntiles], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                    if (aborted != 0u || wall_clock64() - since > 2000000000ull) {   // 20 s: a lost wave; never seen
+                        __hip_atomic_store(&done[ntiles], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        lost = true;
+                        break;
+                    }
+                }
+            }
+            asm volatile("" ::: "memory");  // (the record is loaded after the counter, also as the compiler sees it)
+        }
+        const int qs = (int)(Q0 + QN * (long long)s / nsub), qe = (int)(Q0 + QN * (long long)(s + 1u) / nsub);
+        if (lost) {
+            // (watchdog) nobody continues this tile: its unfinished hillslopes come back flagged, with zero finals
+            const int sys = (int)(tile * WAVE) + lane;
+            int* const resume_i = reinterpret_cast<int*>(A.resume + (size_t)resume_f64(Model::N_EQ) * A.ns);
+            if (sys < A.ns && coherent_load(&resume_i[(size_t)4 * A.ns + sys]) == SYS_PAUSED) {
+                A.stiff[sys] = HLM_SYS_CAPPED;
+#pragma unroll
+                for (int i = 0; i < Model::N_EQ; ++i) A.y_final[(size_t)sys * Model::N_EQ + i] = 0.0;
+                coherent_store(&resume_i[(size_t)4 * A.ns + sys], HLM_SYS_CAPPED);
+            }
+        } else {
+            dense_ring_tile<Model, MATH, FIXED, true, R, SEL, true>(A, tile, qs, qe, A.q_begin, A.q_end, (s > 0u || A.resume_in != 0) ? 1 : 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the rows and the record are out: publish
+        __hip_atomic_store(&done[tile], s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)
     }
 }
 

@@ -133,6 +133,13 @@ __device__ __forceinline__ size_t forcing_row(unsigned long long idx, unsigned l
     return (size_t)(r < rows ? r : rows - 1ull);
 }
 
+// device-coherent accesses to the lane states handed from wave to wave INSIDE a launch (the queue kernels: any wave of
+// any XCD may continue a tile): agent-scope loads and stores, no cache write-back or invalidate anywhere
+__device__ __forceinline__ double coherent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int coherent_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void coherent_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- dense output of an accepted step ------------------------------------------------------------------------
 // The reference evaluates y(t + theta h) = y + h sum_{m=0..3} Q_m theta^(m+1) with Q = P^T k, P = SciPy's 7 x 4
 // matrix (rk45_step_dense.cuh:193-244).  That quartic is the continuous extension of the Dormand-Prince pair in

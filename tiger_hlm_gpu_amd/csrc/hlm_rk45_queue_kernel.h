@@ -109,12 +109,6 @@ struct QueueRuns {
 
 // queue[0]: next item; queue[1 + tile]: RUNS of `tile` finished so far; queue[1 + ntiles]: abort word.  The resume record (A.resume, SoA as in
 // the RESUMABLE kernels: y[N_EQ], t, h | reject_count, n_attempt, n_accept, next_q, status) carries the lanes.
-// device-coherent accesses to the lane states between the pieces (any wave of any XCD may continue a tile)
-__device__ __forceinline__ double coherent_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int coherent_load(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coherent_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void coherent_store(int* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
 // the queue of a launch, zeroed by a kernel of the same stream
 __global__ void queue_init_kernel(unsigned int* __restrict__ queue, unsigned int words)
 {
