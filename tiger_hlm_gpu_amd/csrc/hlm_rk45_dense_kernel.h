@@ -554,7 +554,14 @@ __global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_queue
                 coherent_store(&resume_i[(size_t)4 * A.ns + sys], HLM_SYS_CAPPED);
             }
         } else {
-            dense_ring_tile<Model, MATH, FIXED, true, R, SEL, true>(A, tile, qs, qe, A.q_begin, A.q_end, (s > 0u || A.resume_in != 0) ? 1 : 0);
+            // The item's view of the launch arguments is READ AGAIN from the kernel-argument segment through a pointer
+            // the compiler cannot see through: what the body derives from them then lives inside the item, instead of
+            // being hoisted out of the item loop and held -- and spilled: 93 SGPRs, each back through a v_readlane --
+            // across it.
+            Rk45ArgsConst* kp = (Rk45ArgsConst*)__builtin_amdgcn_kernarg_segment_ptr();   // (A is the kernel's first argument: offset 0)
+            asm volatile("" : "+s"(kp));
+            const Rk45Args a = load_args(kp);
+            dense_ring_tile<Model, MATH, FIXED, true, R, SEL, true>(a, tile, qs, qe, a.q_begin, a.q_end, (s > 0u || a.resume_in != 0) ? 1 : 0);
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // the rows and the record are out: publish
         __hip_atomic_store(&done[tile], s + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // (all lanes, one value)

@@ -79,6 +79,30 @@ struct Rk45Args {
     double* flag_state;
 };
 
+// The launch arguments read again from the kernel-argument segment (constant address space: scalar loads), field by
+// field -- for persistent kernels that want an item's view of them to live inside the item (see rk45_dense_queue_kernel).
+// EVERY field of Rk45Args is copied here: a field added there is added here.
+using Rk45ArgsConst = const Rk45Args __attribute__((address_space(4)));
+__device__ __forceinline__ Rk45Args load_args(Rk45ArgsConst* p)
+{
+    Rk45Args a;
+    a.y0 = p->y0; a.query = p->query; a.sp = p->sp; a.forc = p->forc; a.forc_col = p->forc_col; a.forc_ld = p->forc_ld;
+#pragma unroll
+    for (int k = 0; k < HLM_KERNEL_MAX_NF; ++k) {
+        a.forc_dtmin[k] = p->forc_dtmin[k]; a.forc_nT[k] = p->forc_nT[k]; a.forc_base[k] = p->forc_base[k];
+        a.forc_first[k] = p->forc_first[k]; a.forc_rows[k] = p->forc_rows[k];
+    }
+    a.nforc = p->nforc; a.ns = p->ns; a.nq = p->nq; a.t0 = p->t0; a.tf = p->tf; a.t_stop = p->t_stop;
+    a.h0 = p->h0; a.rtol = p->rtol; a.atol = p->atol; a.safety = p->safety; a.min_scale = p->min_scale; a.max_scale = p->max_scale;
+    a.fixed_step = p->fixed_step; a.cap = p->cap; a.y_final = p->y_final; a.dense = p->dense; a.dense_tiled = p->dense_tiled;
+    a.q_begin = p->q_begin; a.q_end = p->q_end; a.resume = p->resume; a.resume_in = p->resume_in; a.stiff = p->stiff;
+    a.n_attempt = p->n_attempt; a.n_accept = p->n_accept; a.index = p->index; a.index_count = p->index_count; a.dense_k = p->dense_k;
+#pragma unroll
+    for (int c = 0; c < HLM_MAX_NEQ; ++c) a.dense_pos[c] = p->dense_pos[c];
+    a.flag_state = p->flag_state;
+    return a;
+}
+
 // y + sum c_j * k_j accumulated left to right with one FMA per term, the order the
 // reference's "acc += h*a*k" loop uses (rk45_step_dense.cuh:96-101).
 __device__ __forceinline__ double lc(double acc) { return acc; }
