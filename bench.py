@@ -859,6 +859,15 @@ def main():
                 va = copy.copy(args)
                 va.wet_surface = wet
                 res.update(_issue_fields(_per_gpu_key(va, 0, engv.ns)))
+                if wet and H.api.time_pieces_for(engv.job()) > 1 and not args.queue_run_pieces:
+                    # the launch-shape knob on this workload: tiles of unequal cost (saturated against unsaturated
+                    # static stores) want every piece handed over; the automatic runs are tuned on the headline
+                    del engv
+                    torch.cuda.empty_cache()
+                    va.queue_run_pieces = 1
+                    engv, _ = build_engine(va, rank, world, wet=wet, math=math)
+                    _, kms1, _ = timed_passes(engv, total, 1, 1, 1)
+                    res["kernel_ms_queue_run_pieces_1"] = kms1[0]
             del engv
             return res
         for name, wet, math in (("variant_wet_surface", True, args.math),
