@@ -54,10 +54,12 @@ typedef enum {
 
 /* Math mode.  1 = FAST, the DEFAULT of the host API: divisions by per-system constants become
  * multiplications by their reciprocals, x^(2/3) and x^(-1/5) are evaluated by division-free series
- * from integer / f32 seeds (<= 8e-16 relative error over the whole double range -- closer to the
- * correctly rounded value than the OCML pow STRICT calls), the error norm uses one reciprocal.
- * 0 = STRICT: IEEE divides and OCML pow in the reference's own operation structure (FMA-contracted
- * like nvcc's default); 2.4x slower.  STRICT exists for two behaviours FAST does not have:
+ * from integer / f32 seeds (<= 8e-16 relative error over the whole double range), the error norm
+ * uses one reciprocal.
+ * 0 = STRICT: IEEE divides and the correctly rounded values of pow(x, 2.0/3.0) and pow(u, 0.2) -- the
+ * double exponents the reference spells; what glibc's pow returns in 999 of 1 000 cases
+ * (csrc/hlm_strict_pow.h) -- in the reference's own operation structure (FMA-contracted like nvcc's
+ * default); 2.2x slower.  STRICT exists for two behaviours FAST does not have:
  *  (a) a NaN / Inf state component is carried along silently, as in the reference (its error norm
  *      skips NaN ratios); in FAST it poisons the error norm, every attempt is rejected and the
  *      system is flagged (stiff = 1, zero rows) after six rejects;
@@ -285,12 +287,13 @@ typedef struct hlm_device_job {
     /* (ABI 4) What the queue hands out is a RUN of consecutive pieces of a tile; only the end of a run passes the
      * lane states through HBM to whichever wave draws the tile's next run, inside a run they stay in registers (the
      * lanes still pause at every piece's end: that re-aligns them in simulated time).  0 = automatic: with more tiles
-     * than the device holds waves each run takes half of what is left of the window, down to a sixteenth of it -- the
-     * granularity the end of the launch needs, a third of the HBM traffic; smaller launches hand every piece over (the
-     * queue then evens out how the waves sit on the SIMDs).  n >= 1: runs of n pieces each (1 = every piece handed
-     * over, round 3's protocol: the better choice when a few tiles cost several times the mean -- hillslopes dropping
-     * out with stiff flags --, because long runs start the tiles late in the queue order late).  Same results bit for
-     * bit. */
+     * than the device holds waves each run takes half of what is left of the window, at most a quarter and at least a
+     * sixteenth of it (32 pieces: 8, 8, 8, 4, 2, 2) -- the granularity the end of the launch needs, a third of the HBM
+     * traffic; smaller launches hand every piece over (the queue then evens out how the waves sit on the SIMDs).
+     * n >= 1: runs of n pieces each (1 = every piece handed over, round 3's protocol: the better choice when a few
+     * tiles cost several times the mean -- hillslopes dropping out with stiff flags --, because long runs start the
+     * tiles late in the queue order late).  -n: the automatic schedule with runs of at most n pieces.  Same results
+     * bit for bit. */
     int queue_run_pieces;
     /* (ABI 4) G > 1, for a job that launches in time pieces: an item of the queue is a GROUP of G neighbouring tiles
      * and one piece; the wave packs the group's hillslopes that are still integrating into full passes of 64 lanes
@@ -404,7 +407,8 @@ int hlm_host_free_pinned(void* hptr);
 
 /* Self-test of the device elementary functions the FAST math mode substitutes (the analogue of
  * the reference's printf debug kernels, main.cpp:184-246): evaluates function `which` on n
- * doubles.  0: x^(2/3) FAST, 1: x^(-1/5) FAST, 2: 1/x FAST, 3: x^(2/3) STRICT, 4: x^(-1/5) STRICT. */
+ * doubles.  0: x^(2/3) FAST, 1: x^(-1/5) FAST, 2: 1/x FAST, 3: x^(2/3) STRICT, 4: x^(-1/5) STRICT, 5 / 6: n / d by
+ * the invariant divisor's reciprocal / IEEE (divisors in d_in[n .. 2n)), 7 / 8: the seed residual inside 3 / 4's power. */
 int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void* hip_stream);
 
 /* Single device evaluations of Model::rhs (the reference's debugRHS kernel, main.cpp:219-246):

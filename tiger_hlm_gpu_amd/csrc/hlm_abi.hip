@@ -360,7 +360,7 @@ int validate_job(const hlm_device_job* j)
     // (the queue kernel numbers its (piece, tile) items with 32 bits)
     if (j->time_pieces > 1 && ((long long)j->num_systems + 63) / 64 * (long long)j->time_pieces >= (1ll << 32) - 1)
         return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces %d x %d hillslopes: more than 2^32 (piece, tile) items", j->time_pieces, j->num_systems);
-    if (j->queue_run_pieces < 0) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_run_pieces must be >= 0 (0 = automatic)");
+    if (j->queue_run_pieces < -kMaxTimePieces) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_run_pieces must be >= %d (0 = automatic, -n = automatic with runs of at most n pieces)", -kMaxTimePieces);
     if (j->dense_sub_windows < 0 || j->dense_sub_windows > 4096) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_sub_windows must be within [0, 4096]");
     if (j->queue_group_tiles < 0 || j->queue_group_tiles > hlm::QUEUE_MAX_GROUP)
         return fail(HLM_ERR_INVALID_ARGUMENT, "queue_group_tiles must be within [0, %d]", hlm::QUEUE_MAX_GROUP);
@@ -469,15 +469,16 @@ size_t g_debug_queue_rbytes = 0, g_debug_queue_qbytes = 0;
 #endif
 
 // The runs of pieces a queue launch hands out (hlm_device_job.queue_run_pieces; hlm_rk45_queue_kernel.h "RUNS").
-// Automatic: with more tiles than resident waves every run takes half of what is left of the window, down to a
-// sixteenth of it (32 pieces: 16, 8, 4, 2, 2): the launch's tail is that of its last items, and 16 pieces were where
-// round 3's sweep reached the asymptote -- headline 129.3 ms and 5.5 GB of HBM traffic against 129.6 ms and 16.9 GB
-// with every piece handed over (profiles/r04_queue_runs_probe.txt).  A launch with no more tiles than resident waves
-// hands every piece over: its waves sit unevenly on the SIMDs (1 563 waves on 1 024 SIMDs), the queue evens that out
-// piece by piece, and its bytes are few (100 000 hillslopes, cold cells: 20.8 ms against 23.1 ms as one run per tile).
-// What long runs cost: tiles whose cost is far from the mean (cold cells: a few lanes grinding towards their stiff
-// flag with tiny steps).  A tile late in the queue order starts its long first run late and its pieces are serial:
-// SURVEY's cold C3 takes 124.5 ms with these runs, 113.0 ms with queue_run_pieces = 1 -- the knob for such workloads.
+// Automatic: with more tiles than resident waves every run takes half of what is left of the window, at most a
+// quarter and at least a sixteenth of it (32 pieces: 8, 8, 8, 4, 2, 2): the launch's tail is that of its last
+// items, and five hand-overs instead of 31 leave a third of the HBM traffic (profiles/r04_queue_runs_probe.txt).  The
+// cap is what workloads with a spread of tile costs need: a tile's pieces are serial and the queue is in order, so
+// a first run of half the window (round 4's first rule: 16, 8, 4, 2, 2) starts the tiles late in the order late --
+// headline 129.8 ms either way, wet surface 217.7 -> 210.3 ms, SURVEY's cold cells 122.5 -> 118.9 ms (113.0 with every
+// piece handed over: queue_run_pieces = 1; -n = this schedule with runs of at most n pieces).  A launch with no more
+// tiles than resident waves hands every piece over: its waves sit unevenly on the SIMDs (1 563 waves on 1 024
+// SIMDs), the queue evens that out piece by piece, and its bytes are few (100 000 hillslopes, cold cells: 20.8 ms
+// against 23.1 ms as one run per tile).
 hlm::QueueRuns make_queue_runs(int pieces, long long tiles, long long resident, int run_pieces)
 {
     hlm::QueueRuns r;
@@ -498,6 +499,11 @@ hlm::QueueRuns make_queue_runs(int pieces, long long tiles, long long resident, 
         return r;
     }
 #endif
+    // run_pieces < 0: the automatic schedule with no run longer than |run_pieces| pieces (uniform runs where the
+    // shrinking schedule would need more than QUEUE_MAX_RUNS entries)
+    const int cap = run_pieces < 0 ? -run_pieces : (pieces / 4 > 1 ? pieces / 4 : 1);
+    const int least = pieces / 16 > 1 ? pieces / 16 : 1;
+    if (run_pieces < 0 && (cap <= least || (pieces + cap - 1) / cap + 4 > hlm::QUEUE_MAX_RUNS - 1)) run_pieces = cap;
     if (run_pieces > 0) {
         r.uniform = run_pieces < pieces ? run_pieces : pieces;
         r.nruns = (pieces + r.uniform - 1) / r.uniform;
@@ -508,11 +514,11 @@ hlm::QueueRuns make_queue_runs(int pieces, long long tiles, long long resident, 
         r.nruns = pieces;
         return r;
     }
-    const int least = pieces / 16 > 1 ? pieces / 16 : 1;
     int b = 0;
     while (b < pieces && r.nruns < hlm::QUEUE_MAX_RUNS - 1) {
         const int rem = pieces - b;
         int len = rem / 2 > least ? rem / 2 : least;
+        if (len > cap) len = cap;
         if (len > rem) len = rem;
         r.begin_[r.nruns++] = b;
         b += len;
@@ -1510,7 +1516,7 @@ int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters,
 
 int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void* hip_stream)
 {
-    if (which < 0 || which > 6) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest function %d", which);
+    if (which < 0 || which > 8) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest function %d", which);
     if (n < 0 || (n > 0 && (!d_in || !d_out))) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest buffers");
     if (n == 0) return HLM_SUCCESS;
     hipLaunchKernelGGL(hlm::selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,

@@ -16,6 +16,7 @@
 #include <stdint.h>
 
 #include "hlm_hip.h"
+#include "hlm_strict_pow.h"
 
 namespace hlm {
 
@@ -92,7 +93,8 @@ __device__ __forceinline__ bool divisor_in_safe_range(double d)
 // e = 1 - x w^n, the exact root is w (1-e)^(-1/n) = w (1 + c1 e + c2 e^2 + c3 e^3 + ...).
 
 // x^(2/3) for the Manning term (model_204.hpp:103).
-// STRICT: OCML pow (<1 ulp; the reference makes the same call through libdevice).
+// STRICT: the correctly rounded power for the double exponent 0.6666666666666666 (hlm_strict_pow.h; what glibc's pow
+//         returns in 999 of 1 000 cases -- the reference makes the library call, through libdevice on the GPU).
 // FAST:   x * x^(-1/3) with x^(-1/3) from an integer seed and two series refinements, all in
 //         ordinary VALU instructions -- no f32 log/exp (quarter rate), no frexp/ldexp/convert
 //         shuffling:
@@ -107,7 +109,7 @@ template <int MATH>
 __device__ __forceinline__ double pow_two_thirds(double x)
 {
     if constexpr (MATH == MATH_STRICT) {
-        return pow(x, 2.0 / 3.0);
+        return strict_pow_two_thirds(x);
     } else {
         // zero and subnormal arguments (the seed would be out of range) are lifted to the smallest normal
         // number: the result is then <= 1.8e-205 instead of the true value, which is below that too -- one

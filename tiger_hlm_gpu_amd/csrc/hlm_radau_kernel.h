@@ -251,7 +251,7 @@ __device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], con
 
 // MATH: the arithmetic of the model's RHS (hlm_set_math_mode / hlm_device_job.math_mode), as in the RK45
 // kernel.  It matters here more than there: an attempt evaluates the RHS 6 + 3 per Newton iteration
-// = ~14 times, and STRICT's OCML pow costs ~200 instructions each.
+// = ~14 times (STRICT's x^(2/3): hlm_strict_pow.h, ~40 instructions each; OCML's pow took ~200 until round 4).
 // Occupancy: the general path keeps two 5x5 LU factorisations (75 doubles) in registers: one wave per
 // SIMD.  With a triangular Jacobian they are gone and two waves fit.
 #ifdef HLM_RADAU_COUNTERS

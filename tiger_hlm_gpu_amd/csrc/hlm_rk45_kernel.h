@@ -120,12 +120,13 @@ __device__ __forceinline__ double fast_rcp(double x)
 }
 
 // (1/x)^(1/5) for the step-size controller, rk45_kernel.cu:151,156:
-// pow(1.0/(err+1e-16), 0.2).  STRICT keeps the divide and OCML pow.
+// pow(1.0/(err+1e-16), 0.2).  STRICT keeps the divide and takes the correctly rounded power for the double
+// exponent 0.2 (hlm_strict_pow.h).
 template <int MATH>
 __device__ __forceinline__ double inv_fifth_root(double x)
 {
     if constexpr (MATH == MATH_STRICT) {
-        return pow(1.0 / x, 0.2);
+        return strict_pow_fifth(1.0 / x);
     } else {
         // f32 exp2/log2 seed z ~ x^(-1/5) (x in [1e-16, huge]), residual e = 1 - x z^5,
         // exact root = z (1-e)^(-1/5) = z (1 + e/5 + 3/25 e^2 + 11/125 e^3 + O(e^4)).
@@ -927,8 +928,9 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) radau_flag_bin_kernel(const int
 
 // ---- self-test of the FAST-mode elementary functions (hlm_selftest_math) ---------------------
 // which: 0 = x^(2/3) (pow_two_thirds<FAST>), 1 = x^(-1/5) (inv_fifth_root<FAST>), 2 = 1/x (fast_rcp),
-//        3 = x^(2/3) STRICT (OCML pow), 4 = x^(-1/5) STRICT, 5 = div_by_invariant, 6 = IEEE n/d
-//        (5 and 6 read the divisors from in[n .. 2n))
+//        3 = x^(2/3) STRICT (hlm_strict_pow.h), 4 = x^(-1/5) STRICT, 5 = div_by_invariant, 6 = IEEE n/d
+//        (5 and 6 read the divisors from in[n .. 2n)), 7 / 8 = the seed's residual e inside 3 / 4's power (for x > 0:
+//        what the f32 log2 / exp2 of this hardware leave for the series)
 __global__ void selftest_math_kernel(int which, const double* __restrict__ in, double* __restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -946,7 +948,9 @@ __global__ void selftest_math_kernel(int which, const double* __restrict__ in, d
             r = div_by_invariant(x, d, 1.0 / d);
             break;
         }
-        default: r = x / in[i + n]; break;  // 6: IEEE division, the reference for case 5
+        case 6: r = x / in[i + n]; break;  // IEEE division, the reference for case 5
+        case 7: (void)strict_pow_two_thirds_core(x, &r); break;
+        default: (void)strict_pow_fifth_core(x, &r); break;  // 8
     }
     out[i] = r;
 }

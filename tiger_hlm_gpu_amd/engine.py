@@ -30,7 +30,7 @@ class ShardEngine:
         # twelve simulated hours, at most 32, none below 8)
         self.time_pieces = time_pieces
         # hlm_device_job.queue_run_pieces: 0 = automatic runs of pieces per queue item, n = runs of n pieces (1 = every
-        # piece handed over through HBM)
+        # piece handed over through HBM), -n = the automatic schedule with runs of at most n pieces
         self.queue_run_pieces = int(queue_run_pieces)
         # hlm_device_job.queue_group_tiles: G > 1 = an item is a group of G tiles whose survivors are packed per piece
         self.queue_group_tiles = int(queue_group_tiles)
