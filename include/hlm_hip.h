@@ -298,8 +298,10 @@ typedef struct hlm_device_job {
     /* (ABI 4) G > 1, for a job that launches in time pieces: an item of the queue is a GROUP of G neighbouring tiles
      * and one piece; the wave packs the group's hillslopes that are still integrating into full passes of 64 lanes
      * (on the device, piece by piece, from the status words of the state record) -- flagged hillslopes stop costing
-     * lanes without any global re-tiling, extra launch or drain.  Every piece is handed over through the record
-     * (queue_run_pieces is ignored).  Same results bit for bit.  0 / 1: an item is a tile.  At most 16. */
+     * lanes without any global re-tiling, extra launch or drain.  With queue_run_pieces = 0 every piece is handed over
+     * through the record (what workloads that lose hillslopes want); a run length or a cap named there is honoured:
+     * the groups are then packed at the start of every run and stay as packed inside it.  Same results bit for bit.
+     * 0 / 1: an item is a tile.  At most 16. */
     int queue_group_tiles;
     /* (ABI 4) Launch shape of a dense launch in the tile layout (dense_tiled = 2): n > 1 cuts the launch's query window
      * into n sub-windows and runs the launch as a persistent grid over (sub-window, tile) items -- a lane pauses at the

@@ -318,7 +318,8 @@ def test_group_tiles_packing_is_bit_identical(gpu, case):
     Finals, flags and both counters of every hillslope equal the one-wave-per-tile launch bit for bit: cold cells
     flagged in different pieces (later passes straddle tiles and forcing cells), a workload in which nobody drops out,
     fewer hillslopes than a wave, every hillslope capped in the first piece (later pieces find empty groups), the
-    three-state model, STRICT arithmetic on wet cold cells; G = 2, 8, 16 (a ragged last group), 14 and 40 pieces."""
+    three-state model, STRICT arithmetic on wet cold cells; G = 2, 4, 8, 16 (a ragged last group), 14 and 40 pieces,
+    packed per piece and per run of pieces."""
     H = gpu
     from tiger_hlm_gpu_amd import synth
     from tiger_hlm_gpu_amd.engine import ShardEngine
@@ -351,8 +352,8 @@ def test_group_tiles_packing_is_bit_identical(gpu, case):
         inflow = (rng.random((24 * days, 16)) < 0.3) * rng.uniform(0.0, 0.2, (24 * days, 16))
         model, tf = H.ToyModel3, days * 1440.0
 
-    def run(pieces, group):
-        eng = ShardEngine(model, y0, t0, tf, sp=sp, time_pieces=pieces, queue_group_tiles=group, **kw)
+    def run(pieces, group, run_pieces=0):
+        eng = ShardEngine(model, y0, t0, tf, sp=sp, time_pieces=pieces, queue_group_tiles=group, queue_run_pieces=run_pieces, **kw)
         if case == "toy":
             eng.set_forcings_per_cell((inflow.astype(np.float32),), cells, (1.0,), (inflow.shape[0],))
         elif sp is not None:
@@ -360,10 +361,12 @@ def test_group_tiles_packing_is_bit_identical(gpu, case):
         eng.integrate()
         return eng.results()
     a = run(0, 0)
-    for group, pieces in ((2, 14), (8, 14), (8, 40), (16, 14)):
-        b = run(pieces, group)
+    # (run_pieces 0: every piece handed over, the mode's default; 3 / -4: the groups are packed at the start of every
+    # RUN of pieces -- uniform runs of 3, the shrinking schedule with runs of at most 4 -- and stay as packed inside it)
+    for group, pieces, run_pieces in ((2, 14, 0), (8, 14, 0), (8, 40, 0), (16, 14, 0), (8, 40, 3), (8, 40, -4), (4, 14, -4)):
+        b = run(pieces, group, run_pieces)
         for k in ("y_final", "stiff", "n_attempt", "n_accept"):
-            assert np.array_equal(a[k], b[k]), (case, group, pieces, k)
+            assert np.array_equal(a[k], b[k]), (case, group, pieces, run_pieces, k)
     if case == "cold-cells":
         assert 0.05 < (a["stiff"] == 1).mean() < 0.95
     if case == "dummy-capped":

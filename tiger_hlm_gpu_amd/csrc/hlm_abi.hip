@@ -582,8 +582,9 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
     g_debug_queue_rbytes = rbytes;
     g_debug_queue_qbytes = qbytes;
 #endif
-    // groups of tiles packed piece by piece (queue_group_tiles): every piece is handed over, an item is a group
-    hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, group > 1 ? 1 : j->queue_run_pieces);
+    // groups of tiles packed at the start of every run (queue_group_tiles): every piece handed over unless the job
+    // names a run length or a cap of its own
+    hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, group > 1 && j->queue_run_pieces == 0 ? 1 : j->queue_run_pieces);
     runs.group = group;
     runs.t_begin = w0;
     runs.piece_len = (w1 - w0) / (double)pieces;
