@@ -410,7 +410,7 @@ int hlm_host_free_pinned(void* hptr);
 /* Self-test of the device elementary functions the FAST math mode substitutes (the analogue of
  * the reference's printf debug kernels, main.cpp:184-246): evaluates function `which` on n
  * doubles.  0: x^(2/3) FAST, 1: x^(-1/5) FAST, 2: 1/x FAST, 3: x^(2/3) STRICT, 4: x^(-1/5) STRICT, 5 / 6: n / d by
- * the invariant divisor's reciprocal / IEEE (divisors in d_in[n .. 2n)), 7 / 8: the seed residual inside 3 / 4's power. */
+ * the invariant divisor's reciprocal / IEEE (divisors in d_in[n .. 2n)), 7 / 8: the seed residual inside 3 / 4's power, 9: (1/x)^(1/4) STRICT (the Radau pass's controller). */
 int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void* hip_stream);
 
 /* Single device evaluations of Model::rhs (the reference's debugRHS kernel, main.cpp:219-246):

@@ -11,4 +11,8 @@ void strict_pow_fifth_array(const double* x, double* out, long n)
 {
     for (long i = 0; i < n; ++i) out[i] = hlm::strict_pow_fifth(x[i]);
 }
+void strict_pow_fourth_array(const double* x, double* out, long n)
+{
+    for (long i = 0; i < n; ++i) out[i] = hlm::strict_pow_fourth(x[i]);
+}
 }

@@ -1440,6 +1440,11 @@ def test_fast_math_elementary_functions(gpu):
     cr5 = correctly_rounded(1.0 / xe5, 0.2)
     got5s = run(4, xe5)
     assert np.all(np.abs(got5s - cr5) <= np.spacing(cr5)) and np.mean(got5s != cr5) < 1e-3
+    cr4 = correctly_rounded(1.0 / xe5, 0.25)   # the Radau pass's controller: pow(1.0 / x, 0.25)
+    got4s = run(9, xe5)
+    assert np.all(np.abs(got4s - cr4) <= np.spacing(cr4)) and np.mean(got4s != cr4) < 1e-3
+    for w in (7, 8):   # the seeds' residuals on this hardware: what the three-term series are sized for
+        assert np.abs(run(w, xs[xs > 0])).max() < 2e-6
     xr = 10.0 ** rng.uniform(-12, 12, 400000) * rng.choice([-1.0, 1.0], 400000)
     assert np.max(np.abs(run(2, xr) * xr - 1.0)) < 1e-13
 

@@ -35,7 +35,8 @@ def correctly_rounded(x, c):
 
 
 @pytest.mark.parametrize("fn,c,decades", [("strict_pow_two_thirds_array", 2.0 / 3.0, [(-323, 308), (-12, 1), (-3, 3)]),
-                                          ("strict_pow_fifth_array", 0.2, [(-323, 308), (0, 16), (-3, 3)])])
+                                          ("strict_pow_fifth_array", 0.2, [(-323, 308), (0, 16), (-3, 3)]),
+                                          ("strict_pow_fourth_array", 0.25, [(-323, 308), (0, 16), (-3, 3)])])
 def test_strict_powers_are_correctly_rounded(strict_pow, fn, c, decades):
     rng = np.random.default_rng(7)
     wrong = total = 0
@@ -48,7 +49,7 @@ def test_strict_powers_are_correctly_rounded(strict_pow, fn, c, decades):
         total += x.size
     assert wrong <= total // 2000    # (measured: 0 of 120 000 in a longer run; glibc's pow: 16 of 20 000)
     # exactly representable results
-    x = np.array([1.0, 8.0, 27.0, 0.125, 2.0 ** -300, 2.0 ** 300, 32.0, 243.0, 2.0 ** -1000])
+    x = np.array([1.0, 8.0, 27.0, 0.125, 2.0 ** -300, 2.0 ** 300, 32.0, 243.0, 2.0 ** -1000, 16.0, 81.0, 2.0 ** -1074])
     ref = correctly_rounded(x, c)
     assert np.array_equal(strict_pow(fn, x), ref)
 
@@ -58,7 +59,7 @@ def test_strict_powers_special_values_follow_pow(strict_pow):
     libm.pow.restype = ctypes.c_double
     libm.pow.argtypes = [ctypes.c_double, ctypes.c_double]
     x = np.array([0.0, -0.0, -1.0, -1e-300, np.inf, -np.inf, np.nan, 5e-324, 1e-320, 2.2250738585072014e-308, 1.7976931348623157e308])
-    for fn, c in (("strict_pow_two_thirds_array", 2.0 / 3.0), ("strict_pow_fifth_array", 0.2)):
+    for fn, c in (("strict_pow_two_thirds_array", 2.0 / 3.0), ("strict_pow_fifth_array", 0.2), ("strict_pow_fourth_array", 0.25)):
         want = np.array([libm.pow(float(v), c) for v in x])
         got = strict_pow(fn, x)
         assert np.array_equal(got, want, equal_nan=True)

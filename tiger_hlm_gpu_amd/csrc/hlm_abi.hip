@@ -1517,7 +1517,7 @@ int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters,
 
 int hlm_selftest_math(int which, const double* d_in, double* d_out, int n, void* hip_stream)
 {
-    if (which < 0 || which > 8) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest function %d", which);
+    if (which < 0 || which > 9) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest function %d", which);
     if (n < 0 || (n > 0 && (!d_in || !d_out))) return fail(HLM_ERR_INVALID_ARGUMENT, "selftest buffers");
     if (n == 0) return HLM_SUCCESS;
     hipLaunchKernelGGL(hlm::selftest_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,

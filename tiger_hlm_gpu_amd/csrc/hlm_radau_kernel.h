@@ -51,7 +51,8 @@ __device__ __forceinline__ double recip(double x)
     if constexpr (MATH == MATH_FAST) return fast_rcp(x); else return 1.0 / x;
 }
 
-// (1 / x)^(1/4) for the step-size controller.  STRICT: pow as the oracle writes it.  FAST: as inv_fifth_root of the RK45
+// (1 / x)^(1/4) for the step-size controller.  STRICT: the IEEE quotient and the correctly rounded fourth root
+// (hlm_strict_pow.h; pow(1.0 / x, 0.25) as the oracle writes it).  FAST: as inv_fifth_root of the RK45
 // loop -- an f32 exp2 / log2 seed z ~ x^(-1/4), residual e = 1 - x z^4, exact root z (1 - e)^(-1/4) =
 // z (1 + e/4 + 5/32 e^2 + ...) -- a dozen instructions instead of two double-precision square roots and a reciprocal
 // (~45).  x = err + 1e-16 >= 1e-16; beyond 1e30 the factor is clamped to minScale whatever its value, so x is capped
@@ -60,7 +61,7 @@ template <int MATH>
 __device__ __forceinline__ double inv_fourth_root(double x)
 {
     if constexpr (MATH == MATH_STRICT) {
-        return pow(1.0 / x, 0.25);
+        return strict_pow_fourth(1.0 / x);
     } else {
         const double xc = fmin(x, 1e30);
         double z = (double)__builtin_amdgcn_exp2f(-0.25f * __builtin_amdgcn_logf((float)xc));

@@ -930,7 +930,7 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) radau_flag_bin_kernel(const int
 // which: 0 = x^(2/3) (pow_two_thirds<FAST>), 1 = x^(-1/5) (inv_fifth_root<FAST>), 2 = 1/x (fast_rcp),
 //        3 = x^(2/3) STRICT (hlm_strict_pow.h), 4 = x^(-1/5) STRICT, 5 = div_by_invariant, 6 = IEEE n/d
 //        (5 and 6 read the divisors from in[n .. 2n)), 7 / 8 = the seed's residual e inside 3 / 4's power (for x > 0:
-//        what the f32 log2 / exp2 of this hardware leave for the series)
+//        what the f32 log2 / exp2 of this hardware leave for the series), 9 = (1/x)^(1/4) STRICT (the Radau pass's)
 __global__ void selftest_math_kernel(int which, const double* __restrict__ in, double* __restrict__ out, int n)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -950,7 +950,8 @@ __global__ void selftest_math_kernel(int which, const double* __restrict__ in, d
         }
         case 6: r = x / in[i + n]; break;  // IEEE division, the reference for case 5
         case 7: (void)strict_pow_two_thirds_core(x, &r); break;
-        default: (void)strict_pow_fifth_core(x, &r); break;  // 8
+        case 8: (void)strict_pow_fifth_core(x, &r); break;
+        default: r = strict_pow_fourth(1.0 / x); break;  // 9
     }
     out[i] = r;
 }

@@ -1,6 +1,6 @@
-// STRICT-mode powers: pow(x, 2.0/3.0) (model_204.hpp:103) and pow(u, 0.2) (rk45_kernel.cu:151,156) as the
-// reference's host library evaluates them -- correctly rounded results for the DOUBLE exponents the source
-// spells (0.6666666666666666 = 2/3 - 2^-53/3 and 0.2000000000000000111 = 1/5 + 2^-54/5), in ~35 VALU
+// STRICT-mode powers: pow(x, 2.0/3.0) (model_204.hpp:103), pow(u, 0.2) (rk45_kernel.cu:151,156) and the Radau pass's
+// pow(u, 0.25) as the reference's host library evaluates them -- correctly rounded results for the DOUBLE exponents
+// the source spells (0.6666666666666666 = 2/3 - 2^-53/3, 0.2000000000000000111 = 1/5 + 2^-54/5, 0.25), in ~35 VALU
 // instructions instead of the ~215 of the general pow(x, y).
 //
 // Until round 4 STRICT called OCML's pow: measured at up to 12 ulp from the correctly rounded value on
@@ -143,7 +143,37 @@ HLM_POW_HD double strict_pow_fifth_core(double u, double* residual = nullptr)
     return strict_pow_ldexp(b + __builtin_fma(b, t, be), k);
 }
 
-// pow(x, 2.0 / 3.0) and pow(u, 0.2) for every argument: +-0 -> 0, finite x < 0 and NaN -> NaN, +-Inf -> +Inf
+// RN(u^(1/4)) -- pow(u, 0.25) of the Radau pass's controller (the oracle's hlm_oracle_radau.c; 0.25 is exact, no
+// exponent term) -- for every positive finite u
+HLM_POW_HD double strict_pow_fourth_core(double u)
+{
+    // u = u1 16^k with u1 = m 2^r in [0.5, 8): u^(1/4) = 2^k u1^(1/4)
+    int ex;
+    const double m = strict_pow_frexp(u, &ex);
+    const unsigned e4 = (unsigned)(ex + 1076);                       // 1076 = 4 * 269
+    const int r = (int)(e4 & 3u), k = (int)(e4 >> 2) - 269;
+    const double u1 = strict_pow_ldexp(m, r);
+    const float L1 = (float)r + strict_pow_log2f((float)m);          // log2 u1 in [-1, 3)
+    const double z = (double)strict_pow_exp2f(L1 * -0.25f);          // ~ u1^(-1/4), 24 bits
+    const double z2 = z * z;                                         // exact
+    const double z3 = z2 * z;
+    const double z3e = __builtin_fma(z2, z, -z3);                    // z^3 = z3 + z3e exactly
+    const double z4 = z2 * z2;
+    const double z4e = __builtin_fma(z2, z2, -z4);                   // z^4 = z4 + z4e exactly
+    double e = __builtin_fma(-u1, z4, 1.0);
+    e = __builtin_fma(-u1, z4e, e);                                  // 1 - u1 z^4
+    // u1^(1/4) = u1 z^3 (1 - e)^(-3/4);  (1 - e)^(-3/4) - 1 = 3/4 e + 21/32 e^2 + 77/128 e^3 (+ 1155/2048 e^4 < 1e-23)
+    double s = __builtin_fma(e, 77.0 / 128.0, 21.0 / 32.0);
+    s = __builtin_fma(e, s, 0.75);
+    const double t = e * s;
+    double b = u1 * z3;
+    HLM_POW_OPAQUE(b);
+    double be = __builtin_fma(u1, z3, -b);
+    be = __builtin_fma(u1, z3e, be);
+    return strict_pow_ldexp(b + __builtin_fma(b, t, be), k);
+}
+
+// pow(x, 2.0 / 3.0), pow(u, 0.2) and pow(u, 0.25) for every argument: +-0 -> 0, finite x < 0 and NaN -> NaN, +-Inf -> +Inf
 HLM_POW_HD double strict_pow_two_thirds(double x)
 {
     double r = strict_pow_two_thirds_core(x);
@@ -154,6 +184,13 @@ HLM_POW_HD double strict_pow_two_thirds(double x)
 HLM_POW_HD double strict_pow_fifth(double u)
 {
     double r = strict_pow_fifth_core(u);
+    if (!(u > 0.0)) r = u == 0.0 ? 0.0 : __builtin_nan("");
+    if (__builtin_fabs(u) == __builtin_inf()) r = __builtin_inf();
+    return r;
+}
+HLM_POW_HD double strict_pow_fourth(double u)
+{
+    double r = strict_pow_fourth_core(u);
     if (!(u > 0.0)) r = u == 0.0 ? 0.0 : __builtin_nan("");
     if (__builtin_fabs(u) == __builtin_inf()) r = __builtin_inf();
     return r;
