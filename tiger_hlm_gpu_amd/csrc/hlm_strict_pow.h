@@ -143,7 +143,7 @@ HLM_POW_HD double strict_pow_fifth_core(double u, double* residual = nullptr)
     return strict_pow_ldexp(b + __builtin_fma(b, t, be), k);
 }
 
-// RN(u^(1/4)) -- pow(u, 0.25) of the Radau pass's controller (the oracle's hlm_oracle_radau.c; 0.25 is exact, no
+// RN(u^(1/4)) -- pow(u, 0.25) of the Radau pass's controller (as its CPU restatement writes it; 0.25 is exact, no
 // exponent term) -- for every positive finite u
 HLM_POW_HD double strict_pow_fourth_core(double u)
 {
