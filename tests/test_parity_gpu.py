@@ -1057,7 +1057,7 @@ def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
         # what the queue hands out (hlm_device_job.queue_run_pieces, round 4): automatic runs of pieces (one run while
         # the tiles fit the resident waves, halving runs beyond: cold-cells and benchmark), every piece handed over
         # through HBM (1: round 3's protocol), runs of 3 pieces (the last run shorter)
-        for run_pieces in (0, 1, 3):
+        for run_pieces in (0, 1, 3, -2):
             b = run(p, run_pieces)
             for k in ("y_final", "stiff", "n_attempt", "n_accept"):
                 assert np.array_equal(a[k], b[k]), (case, p, run_pieces, k)
