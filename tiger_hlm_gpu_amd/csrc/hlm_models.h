@@ -523,8 +523,9 @@ struct DummyDev {
     static __device__ __forceinline__ void rhs(const Local&, const Forc&, const double (&y)[N_EQ],
                                                double (&dydt)[N_EQ])
     {
-        // Every product-sum below is written as the ONE operation sequence it is to compile to (contraction off,
-        // explicit FMAs): the kernels inline this function several times (k0 / k1..k6, first attempt / loop body,
+        // Every product-sum below is written as the ONE operation sequence it is to compile to (explicit FMAs: a
+        // product that feeds an fma intrinsic cannot be fused any further -- the pragma below only documents the
+        // intent, -ffp-contract=fast on the command line disregards it): the kernels inline this function several times (k0 / k1..k6, first attempt / loop body,
         // resumed / fresh lane) and all copies must round alike, or a resumed run differs from the uninterrupted
         // one in the last bit.  Left to -ffp-contract=fast, "I2 - I3" (two products, one sum) was fused as
         // fma(-0.4, H3, I2) in one copy and as fma(0.6, H1, -I3) in another.  The forms are the ones the compiler
@@ -591,7 +592,7 @@ struct ToyDev {
     template <int MATH>
     static __device__ __forceinline__ void rhs(const Local& P, const Forc& F, const double (&y)[N_EQ], double (&dydt)[N_EQ])
     {
-        // (one operation sequence per statement, contraction off: see DummyDev::rhs.  "out0 - out1" and
+        // (one operation sequence per statement, explicit FMAs: see DummyDev::rhs.  "out0 - out1" and
         // "out1 - k3 y2" are sums of two products.)
 #pragma clang fp contract(off)
         const double u = 0.3 * y[0], out1 = (0.02 * y[1]) * y[1];
