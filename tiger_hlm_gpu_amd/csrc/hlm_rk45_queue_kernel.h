@@ -29,7 +29,7 @@
 // 3) re-read the 136-byte parameter record and moved 76 bytes of lane state out and back in 31 times per hillslope:
 // 16.9 GB of HBM traffic per headline launch against 3.2 GB algorithmic.  What removes the launch's tail is the
 // granularity of its LAST items only, so the runs shrink towards the end of the window (QueueRuns: by default each
-// run takes half of what is left, down to a sixteenth of the window; launches with no more tiles than resident waves
+// run takes half of what is left, at most a quarter and at least a sixteenth of the window; launches with no more tiles than resident waves
 // keep handing every piece over: make_queue_runs in hlm_abi.hip has the measurements).  Same bits whatever the runs
 // (hlm_device_job.queue_run_pieces, tests).
 //
