@@ -141,6 +141,10 @@ inline void set_radau_mode(int mode) { detail::check(hlm_set_radau_fallback(mode
 // reference's map, rk45_kernel.cu:33), P > 1 = a persistent grid over P time pieces x tiles, negative = automatic
 // (the default).  Same results bit for bit either way.
 inline void set_time_pieces(int pieces) { detail::check(hlm_set_time_pieces(pieces), "set_time_pieces"); }
+// What the queue of such a launch hands out and whether neighbouring tiles are packed (hlm_set_queue_shape): run_pieces
+// 0 = automatic, n = runs of n pieces, -n = automatic with runs of at most n; group_tiles G > 1 = the hillslopes of G
+// tiles that are still integrating share full waves -- for domains that lose hillslopes to the stiff flag.  Same results.
+inline void set_queue_shape(int run_pieces, int group_tiles) { detail::check(hlm_set_queue_shape(run_pieces, group_tiles), "set_queue_shape"); }
 
 // ---- 1) allocate device buffers & copy inputs ------------------------------------------------
 template <class Model>

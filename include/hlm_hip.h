@@ -116,6 +116,12 @@ int hlm_set_lane_refill(int enabled);
  * (the default) = automatic: from 4 096 hillslopes on, one piece per twelve simulated hours, at most 32, none
  * when that makes fewer than 8 (a 4-day window is the shortest that is cut). */
 int hlm_set_time_pieces(int pieces);
+/* (ABI 4) hlm_device_job.queue_run_pieces and queue_group_tiles of the host API's launches in time pieces (see the job's
+ * fields): what the queue hands out -- 0 = automatic, n = runs of n pieces, -n = automatic with runs of at most n -- and
+ * G > 1 = the hillslopes of G neighbouring tiles that are still integrating packed into full waves (domains that lose
+ * hillslopes to the stiff flag: SURVEY's cold C3 runs its RK45 pass in 99 ms with (0, 8) against 118 ms with (0, 0)).
+ * Results do not depend on either. */
+int hlm_set_queue_shape(int run_pieces, int group_tiles);
 /* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
  * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free), every flagged system restarting at t0 as
  * radau_kernel.cu:44-52 does; 2: the same pass CONTINUING from the state each flagged system had reached

@@ -651,8 +651,9 @@ def test_cpp_driver_model204_g2(gpu, golden, tmp_path):
 
 def test_cpp_driver_time_pieces_same_final_csv(gpu, tmp_path):
     """rk45_solver --time-pieces P (rk45_api::set_time_pieces -> hlm_set_time_pieces): 6 000 hillslopes x 6 days
-    without dense output, one wave per tile (0) against 12 pieces and the automatic choice: the same final.csv byte
-    for byte, the same attempted steps."""
+    without dense output, one wave per tile (0) against 12 pieces and the automatic choice -- and --run-pieces /
+    --group-tiles (rk45_api::set_queue_shape -> hlm_set_queue_shape): the same final.csv byte for byte, the same
+    attempted steps."""
     import json
     import subprocess
     from tiger_hlm_gpu_amd import synth
@@ -660,7 +661,9 @@ def test_cpp_driver_time_pieces_same_final_csv(gpu, tmp_path):
     pcsv = tmp_path / "params.csv"
     synth.write_params_csv(pcsv, synth.model204_params(0, 6000))
     outs = {}
-    for tag, extra in (("fixed", ["--time-pieces", "0"]), ("twelve", ["--time-pieces", "12"]), ("auto", [])):
+    for tag, extra in (("fixed", ["--time-pieces", "0"]), ("twelve", ["--time-pieces", "12"]), ("auto", []),
+                       ("groups", ["--time-pieces", "12", "--group-tiles", "8"]), ("groups-runs", ["--time-pieces", "12", "--group-tiles", "4", "--run-pieces", "-4"]),
+                       ("runs", ["--time-pieces", "12", "--run-pieces", "5"])):
         f = tmp_path / f"final_{tag}.csv"
         out = subprocess.run([exe, "--model", "204", "--params", str(pcsv), "--tf", str(6 * 1440), "--nq", "0", "--initial-step", "0.01",
                               "--rain", "0.0004", "--out-final", str(f), "--out-dense", str(tmp_path / f"dense_{tag}.csv")] + extra,
@@ -668,7 +671,9 @@ def test_cpp_driver_time_pieces_same_final_csv(gpu, tmp_path):
         info = json.loads(out.strip().splitlines()[-1])
         outs[tag] = (open(f, "rb").read(), info["attempted_steps"])
     assert outs["fixed"][1] > 6000 * 100
-    assert outs["fixed"] == outs["twelve"] == outs["auto"]
+    assert outs["fixed"] == outs["twelve"] == outs["auto"] == outs["groups"] == outs["groups-runs"] == outs["runs"]
+    bad = subprocess.run([exe, "--model", "204", "--params", str(pcsv), "--tf", "100", "--nq", "0", "--group-tiles", "99"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "queue_group_tiles" in bad.stderr
 
 
 # ---- dense output in query windows (BASELINE config 5) ------------------------------------------

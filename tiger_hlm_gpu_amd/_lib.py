@@ -111,6 +111,7 @@ SIGNATURES = {
     "hlm_set_lane_refill": (C.c_int, [C.c_int]),
     "hlm_set_output_states": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "hlm_set_time_pieces": (C.c_int, [C.c_int]),
+    "hlm_set_queue_shape": (C.c_int, [C.c_int, C.c_int]),
     "hlm_time_pieces_for": (C.c_int, [C.POINTER(DeviceJob)]),
     "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
                                    C.c_int64, C.c_void_p]),

@@ -123,6 +123,12 @@ def set_time_pieces(pieces):
     check(lib().hlm_set_time_pieces(int(pieces)))
 
 
+def set_queue_shape(run_pieces=0, group_tiles=0):
+    """hlm_set_queue_shape: queue_run_pieces / queue_group_tiles of the host API's launches in time pieces (0, 0 =
+    automatic runs, an item is a tile; group_tiles = 8 for domains that lose hillslopes to the stiff flag)."""
+    check(lib().hlm_set_queue_shape(int(run_pieces), int(group_tiles)))
+
+
 def time_pieces_for(job):
     """The number of time pieces integrate_device(job) launches with (0 = one wave per tile)."""
     return int(lib().hlm_time_pieces_for(C.byref(job)))

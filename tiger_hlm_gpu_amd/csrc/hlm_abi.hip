@@ -90,6 +90,7 @@ int g_math = HLM_MATH_FAST;
 bool g_math_explicit = false;
 int g_refill = 0;  // hlm_set_lane_refill(): host-API launches without dense output use the refill kernel
 int g_time_pieces = -1;  // hlm_set_time_pieces(): < 0 = automatic (auto_time_pieces)
+int g_queue_run_pieces = 0, g_queue_group_tiles = 0;  // hlm_set_queue_shape(): hlm_device_job.queue_run_pieces / queue_group_tiles of the host API's launches
 constexpr int kMaxTimePieces = 4096;
 // The automatic launch shape of a run without dense output: from 4 096 hillslopes on, one piece per twelve simulated
 // hours, at most 32 -- and none at all when that makes fewer than 8: FEW pieces cost more than the drain they remove
@@ -800,6 +801,8 @@ int fill_job_from_registry(hlm_device_job* j, int uid, const ForcingState& F)
     j->attempt_cap = g_cap;
     j->lane_refill = g_refill;
     j->time_pieces = g_time_pieces;  // (< 0: resolved by the caller once it knows the number of systems)
+    j->queue_run_pieces = g_queue_run_pieces;
+    j->queue_group_tiles = g_queue_group_tiles;
     j->math_mode = g_math;
     if (!g_math_explicit && !(m->p[2] >= 1e-60 && m->p[2] <= 1e50)) j->math_mode = HLM_MATH_STRICT;
     j->d_forc = F.d_forc;
@@ -1040,6 +1043,18 @@ int hlm_set_time_pieces(int pieces)
     if (pieces > kMaxTimePieces) return fail(HLM_ERR_INVALID_ARGUMENT, "time pieces %d (at most %d)", pieces, kMaxTimePieces);
     std::lock_guard<std::mutex> lk(g_mu);
     g_time_pieces = pieces < 0 ? -1 : pieces;
+    return HLM_SUCCESS;
+}
+
+int hlm_set_queue_shape(int run_pieces, int group_tiles)
+{
+    if (run_pieces < -kMaxTimePieces || run_pieces > kMaxTimePieces)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "queue_run_pieces %d outside [%d, %d]", run_pieces, -kMaxTimePieces, kMaxTimePieces);
+    if (group_tiles < 0 || group_tiles > hlm::QUEUE_MAX_GROUP)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "queue_group_tiles must be within [0, %d]", hlm::QUEUE_MAX_GROUP);
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_queue_run_pieces = run_pieces;
+    g_queue_group_tiles = group_tiles;
     return HLM_SUCCESS;
 }
 
