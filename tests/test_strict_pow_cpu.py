@@ -13,10 +13,21 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def strict_pow(tmp_path_factory):
+def _cpu_has_fma():
+    try:
+        return " fma " in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+# the header as a plain host build, and as the device build compiles it: contraction on, hardware FMAs (the compensated
+# sums must survive -ffp-contract=fast: HLM_POW_OPAQUE)
+@pytest.fixture(scope="module", params=["-O2 -ffp-contract=off", "-O3 -ffp-contract=fast -mfma"], ids=["contract-off", "contract-fast"])
+def strict_pow(request, tmp_path_factory):
+    if "-mfma" in request.param and not _cpu_has_fma():
+        pytest.skip("this CPU has no FMA instructions")
     so = str(tmp_path_factory.mktemp("strict_pow") / "libstrict_pow_host.so")
-    subprocess.run(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", "-I", os.path.join(ROOT, "tiger_hlm_gpu_amd", "csrc"),
+    subprocess.run(["g++"] + request.param.split() + ["-shared", "-fPIC", "-I", os.path.join(ROOT, "tiger_hlm_gpu_amd", "csrc"),
                     os.path.join(ROOT, "tests", "cpp", "strict_pow_host.cpp"), "-o", so], check=True)
     lib = ctypes.CDLL(so)
 
@@ -41,7 +52,7 @@ def test_strict_powers_are_correctly_rounded(strict_pow, fn, c, decades):
     rng = np.random.default_rng(7)
     wrong = total = 0
     for lo, hi in decades:   # the whole range of doubles (subnormals too), then where the solver calls them
-        x = 10.0 ** rng.uniform(lo, hi, 3000)
+        x = 10.0 ** rng.uniform(lo, hi, 1500)
         ref = correctly_rounded(x, c)
         got = strict_pow(fn, x)
         assert np.all(np.abs(got - ref) <= np.spacing(ref))     # never more than the neighbouring double

@@ -37,11 +37,11 @@
 // is built with -ffp-contract=fast, which fuses such a product into the final addition -- b + q with b = x w becomes
 // fma(x, w, q) -- and counts its error twice (seen: every fourth result one ulp off; `#pragma clang fp contract(off)`
 // is ignored under =fast).  The leading product therefore passes through an empty asm: the compiler no longer sees a
-// multiplication feeding the addition.  (The host build: -ffp-contract=off.)
+// multiplication feeding the addition.  (Host builds get the same barrier, through memory.)
 #if defined(__HIP_DEVICE_COMPILE__)
 #define HLM_POW_OPAQUE(x) asm volatile("" : "+v"(x))
 #else
-#define HLM_POW_OPAQUE(x) (void)0
+#define HLM_POW_OPAQUE(x) asm volatile("" : "+m"(x))   // (host builds: the CPU test also compiles this header with contraction on)
 #endif
 
 namespace hlm {
