@@ -51,6 +51,32 @@ __device__ __forceinline__ double recip(double x)
     if constexpr (MATH == MATH_FAST) return fast_rcp(x); else return 1.0 / x;
 }
 
+// N reciprocals at once.  FAST: ONE Newton-refined v_rcp_f64 of the product and 3 (N - 1) multiplications
+// (x_0 ... x_{k-1} as prefix products forwards, the running reciprocal of the tail backwards) instead of N reciprocals
+// of 6 issue slots each (v_rcp_f64 is quarter rate): 18 instead of 30 slots for five, 33 instead of 60 for ten.  The
+// arguments are positive and moderate here (tolerances atol + rtol |y|; g/h - J_ii and |a/h - J_ii - i b/h|^2 with
+// h in [1e-6, 1e4] minutes), so their product stays far inside the double range.  STRICT: IEEE divisions, one by one.
+template <int MATH, int N>
+__device__ __forceinline__ void recip_all(const double (&x)[N], double (&inv)[N])
+{
+    if constexpr (MATH == MATH_FAST && N > 1) {
+        double pre[N];   // pre[k] = x_0 ... x_k
+        pre[0] = x[0];
+#pragma unroll
+        for (int k = 1; k < N; ++k) pre[k] = pre[k - 1] * x[k];
+        double r = fast_rcp(pre[N - 1]);   // 1 / (x_0 ... x_k) while k runs down
+#pragma unroll
+        for (int k = N - 1; k > 0; --k) {
+            inv[k] = r * pre[k - 1];
+            r *= x[k];
+        }
+        inv[0] = r;
+    } else {
+#pragma unroll
+        for (int k = 0; k < N; ++k) inv[k] = recip<MATH>(x[k]);
+    }
+}
+
 // (1 / x)^(1/4) for the step-size controller.  STRICT: the IEEE quotient and the correctly rounded fourth root
 // (hlm_strict_pow.h; pow(1.0 / x, 0.25) as the oracle writes it).  FAST: as inv_fifth_root of the RK45
 // loop -- an f32 exp2 / log2 seed z ~ x^(-1/4), residual e = 1 - x z^4, exact root z (1 - e)^(-1/4) =
@@ -471,10 +497,14 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                     }
                     solve_r(ev);
                     double err = 0.0;
+                    double tol[NEQ], inv_tol[NEQ];
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) tol[i] = A.atol + A.rtol * vmax_abs(y[i], y_new[i]);   // (fmax(|.|, |.|) as one instruction: hlm_models.h)
+                    recip_all<MATH>(tol, inv_tol);
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) {
-                        const double r = fabs(ev[i]) * recip<MATH>(A.atol + A.rtol * fmax(fabs(y[i]), fabs(y_new[i])));
-                        if (r > err) err = r;
+                        const double r = fabs(ev[i]) * inv_tol[i];
+                        err = vmax(err, r);   // (r >= 0 or NaN: the bare v_max_f64 keeps err for a NaN r, as "if (r > err)" did)
                     }
                     if (!(err == err)) {
                         h *= 0.5;  // NaN estimate: treat like a failed Newton
@@ -567,14 +597,20 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                     b_h = MU_CIM * inv_h;
                     bool ok = true;
                     if constexpr (TRI) {
+                        double den[2 * NEQ], inv_den[2 * NEQ], cr[NEQ];
 #pragma unroll
                         for (int i = 0; i < NEQ; ++i) {
-                            const double dr = g_h - Jm[i][i], cr = a_h - Jm[i][i];
-                            inv_r[i] = recip<MATH>(dr);
-                            const double d = recip<MATH>(cr * cr + b_h * b_h);  // 1 / ((a/h - J_ii) - i b/h)
-                            inv_cr[i] = cr * d;
-                            inv_ci[i] = b_h * d;
-                            ok = ok && fabs(dr) > 1e-300;
+                            den[i] = g_h - Jm[i][i];
+                            cr[i] = a_h - Jm[i][i];
+                            den[NEQ + i] = cr[i] * cr[i] + b_h * b_h;   // |(a/h - J_ii) - i b/h|^2
+                            ok = ok && fabs(den[i]) > 1e-300;
+                        }
+                        recip_all<MATH>(den, inv_den);
+#pragma unroll
+                        for (int i = 0; i < NEQ; ++i) {
+                            inv_r[i] = inv_den[i];
+                            inv_cr[i] = cr[i] * inv_den[NEQ + i];
+                            inv_ci[i] = b_h * inv_den[NEQ + i];
                         }
                     } else {
 #pragma unroll
@@ -588,8 +624,12 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                         ok = lu_real(Mr, piv_r, inv_r);
                         ok = lu_cplx(Cr, Ci, piv_c, inv_cr, inv_ci) && ok;
                     }
+                    {
+                        double sc[NEQ];   // the Newton increment's units
 #pragma unroll
-                    for (int i = 0; i < NEQ; ++i) inv_sc[i] = recip<MATH>(A.atol + A.rtol * fabs(y[i]));  // the Newton increment's units
+                        for (int i = 0; i < NEQ; ++i) sc[i] = A.atol + A.rtol * fabs(y[i]);
+                        recip_all<MATH>(sc, inv_sc);
+                    }
                     // Simplified Newton on W = (TI (x) I) Z,  Z_i = Y_i - y, from Z = W = 0 -- and its FIRST iteration
                     // right here: with Z = 0 all three stage states are y, so the three RHS evaluations of that iteration
                     // are f0 (the same function of the same bits): the iteration costs two triangular solves and no RHS
@@ -611,8 +651,8 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                             W[0][i] = d0[i];
                             W[1][i] = d1[i];
                             W[2][i] = d2[i];
-                            const double r = fmax(fmax(fabs(d0[i]), fabs(d1[i])), fabs(d2[i])) * inv_sc[i];
-                            if (r > nrm) nrm = r;
+                            const double r = vmax_abs2(vmax_abs(d0[i], d1[i]), d2[i]) * inv_sc[i];
+                            nrm = vmax(nrm, r);
 #pragma unroll
                             for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = T[s2][0] * W[0][i] + T[s2][1] * W[1][i] + T[s2][2] * W[2][i];
                         }
@@ -653,8 +693,8 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 W[0][i] += d0[i];
                 W[1][i] += d1[i];
                 W[2][i] += d2[i];
-                const double r = fmax(fmax(fabs(d0[i]), fabs(d1[i])), fabs(d2[i])) * inv_sc[i];
-                if (r > nrm) nrm = r;
+                const double r = vmax_abs2(vmax_abs(d0[i], d1[i]), d2[i]) * inv_sc[i];
+                nrm = vmax(nrm, r);
 #pragma unroll
                 for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = T[s2][0] * W[0][i] + T[s2][1] * W[1][i] + T[s2][2] * W[2][i];
             }
