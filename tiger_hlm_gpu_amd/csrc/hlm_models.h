@@ -43,6 +43,17 @@ __device__ __forceinline__ double vmax(double a, double b)
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// fmin(fmax(x, lo), hi) with WAVE-UNIFORM bounds (kernel arguments): two instructions, each bound as the one scalar
+// operand a VOP3 instruction may take.  Written with fmin / fmax the compiler first quiets all three operands
+// ("v_max_f64 lo, lo, lo" ...): three more VALU instructions per accepted step.  Same NaN behaviour as those
+// functions: a NaN x comes out as lo.
+__device__ __forceinline__ double vclamp_uniform(double x, double lo, double hi)
+{
+    double a, r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(a) : "v"(x), "s"(lo));
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "s"(hi));
+    return r;
+}
 // max(|a|, |b|) with the absolute values as source modifiers
 __device__ __forceinline__ double vmax_abs(double a, double b)
 {
