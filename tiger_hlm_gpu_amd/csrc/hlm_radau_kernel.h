@@ -535,7 +535,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                             for (int i = 0; i < NEQ; ++i) y[i] = y_new[i];
                             t = t_end;
                             ++n_accept;
-                            h *= fmin(fmax(fac, A.min_scale), A.max_scale);
+                            h *= vclamp_uniform(fac, A.min_scale, A.max_scale);
                             if (clipped && h < h_ctl) h = h_ctl;
                         } else {
                             h *= fmin(fmax(fmin(fac, 1.0), A.min_scale), A.max_scale);

@@ -279,7 +279,7 @@ __device__ __forceinline__ void dense_ring_tile(const Rk45Args& A, const unsigne
             if (accepted) {
                 // committed in (B), after the step's last row
                 t1 = t + h;
-                h_next = FIXED ? A.fixed_step : h * fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+                h_next = FIXED ? A.fixed_step : h * vclamp_uniform(fac, A.min_scale, A.max_scale);  // rk45_kernel.cu:151-152
                 mode = M_PENDING;
                 if (tq_next <= t1) dense_coefficients<NEQ>(y, yt, h, k0, k2, k3, k4, k5, k6, D1, k0, D3, D4);  // once per step
             }

@@ -804,7 +804,7 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         t = t1;
         ++n_accept;
         if constexpr (FIXED) h = A.fixed_step;
-        else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+        else h *= vclamp_uniform(fac, A.min_scale, A.max_scale);  // rk45_kernel.cu:151-152
     }
 
     if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap

@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                 t += h;
                 ++n_accept;
                 if constexpr (FIXED) h = A.fixed_step;
-                else h *= fmin(fmax(fac, A.min_scale), A.max_scale);  // rk45_kernel.cu:151-152
+                else h *= vclamp_uniform(fac, A.min_scale, A.max_scale);  // rk45_kernel.cu:151-152
             }
         }
     }
