@@ -263,7 +263,12 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                     for (unsigned c = c_begin; c < c_end; ++c) {
                         t_end = c + 1u < (unsigned)nchunk ? fmin(w_end, R.t_begin + (double)(c + 1u) * R.piece_len) : w_end;
                         while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
-                            if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
+                            // rk45_kernel.cu:54 "if (t + h > tf) h = tf - t": only the last steps of the window are clipped, so the
+                            // subtraction and the two selects wait behind a wave-uniform test (add + compare per attempt otherwise)
+                            if (__builtin_amdgcn_ballot_w64(t + h > tf) != 0ull) {
+                                asm volatile("");   // (keeps this a branch: the compiler otherwise turns it back into the selects)
+                                if (t + h > tf) h = tf - t;
+                            }
                             if (held.refresh(A, P, t, FV)) have_k0 = false;
                             ++n_attempt;
                             double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
