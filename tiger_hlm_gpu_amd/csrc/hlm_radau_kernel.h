@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                             h *= vclamp_uniform(fac, A.min_scale, A.max_scale);
                             if (clipped && h < h_ctl) h = h_ctl;
                         } else {
-                            h *= fmin(fmax(fmin(fac, 1.0), A.min_scale), A.max_scale);
+                            h *= vclamp_uniform(vmin(fac, 1.0), A.min_scale, A.max_scale);
                         }
                     }
                 }
@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                         for (int j = 0; j < Model::NF; ++j) {
                             if (j < A.nforc) {
                                 if (!(t < tb[j])) { F[j] = sample(j, tb[j]); moved = true; }
-                                t_b = fmin(t_b, tb[j]);
+                                t_b = vmin(t_b, tb[j]);
                             }
                         }
                         if (moved) FV = Model::prep_forcing(P, F);
