@@ -316,6 +316,10 @@ struct Model204Dev {
     // the cap and 1 at it, also for h < 0).  Reference: model_204.hpp:86-113 differentiated term by term.
     static constexpr bool HAS_JACOBIAN = true;
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;  // a cascade: store i only feels stores j <= i
+    // entries below the diagonal that are zero whatever the state (jacobian() never writes them): the gravitational
+    // and the aquifer store feel the snow and the static store only -- the Radau pass's forward substitutions leave
+    // those products out (FAST)
+    static constexpr bool jacobian_zero(int i, int j) { return (i == 3 && j == 2) || (i == 4 && (j == 2 || j == 3)); }
     template <int MATH>
     static __device__ __forceinline__ void jacobian(const Local& P, const Forc& F, const double (&y)[N_EQ],
                                                     double (&J)[N_EQ][N_EQ])
@@ -514,6 +518,7 @@ struct DummyDev {
     static constexpr bool HAS_JACOBIAN = true;  // constant: the system is linear
     static constexpr bool HAS_RHS_JACOBIAN = false;
     static constexpr bool JACOBIAN_LOWER_TRIANGULAR = true;
+    static constexpr bool jacobian_zero(int, int) { return false; }
     template <int MATH>
     static __device__ __forceinline__ void jacobian(const Local&, const Forc&, const double (&)[N_EQ],
                                                     double (&J)[N_EQ][N_EQ])

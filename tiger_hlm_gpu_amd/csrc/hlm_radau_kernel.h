@@ -246,18 +246,21 @@ __device__ __forceinline__ void solve_cplx(const double (&ar)[NEQ][NEQ], const d
 // factorisation, no pivoting (LU with partial pivoting would not pivot either: |mu/h - J_ii| exceeds the
 // entries below it), the solves are forward substitutions.  Entries a model's jacobian() leaves at the
 // literal 0.0 drop out at compile time.
-template <int NEQ>
+// SKIP(i, j): the model declares J_ij zero whatever the state (Model::jacobian_zero; FAST: the product 0 * b_j is
+// left out -- it is +-0 unless b_j is Inf / NaN, which ends the Newton iteration through its own check anyway)
+template <class Model, int MATH, int NEQ>
 __device__ __forceinline__ void solve_real_tri(const double (&Jm)[NEQ][NEQ], const double (&inv)[NEQ], double (&b)[NEQ])
 {
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) {
         double s = b[i];
 #pragma unroll
-        for (int j = 0; j < i; ++j) s += Jm[i][j] * b[j];  // the matrix entry is -J_ij
+        for (int j = 0; j < i; ++j)
+            if (!(MATH == MATH_FAST && Model::jacobian_zero(i, j))) s += Jm[i][j] * b[j];  // the matrix entry is -J_ij
         b[i] = s * inv[i];
     }
 }
-template <int NEQ>
+template <class Model, int MATH, int NEQ>
 __device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], const double (&ir)[NEQ], const double (&ii)[NEQ],
                                                double (&br)[NEQ], double (&bi)[NEQ])
 {
@@ -266,6 +269,7 @@ __device__ __forceinline__ void solve_cplx_tri(const double (&Jm)[NEQ][NEQ], con
         double sr = br[i], si = bi[i];
 #pragma unroll
         for (int j = 0; j < i; ++j) {
+            if (MATH == MATH_FAST && Model::jacobian_zero(i, j)) continue;
             sr += Jm[i][j] * br[j];
             si += Jm[i][j] * bi[j];
         }
@@ -451,10 +455,10 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = W[s2][i] = 0.0;
     }
     auto solve_r = [&](double (&b)[NEQ]) {
-        if constexpr (TRI) solve_real_tri(Jm, inv_r, b); else solve_real(Mr, piv_r, inv_r, b);
+        if constexpr (TRI) solve_real_tri<Model, MATH>(Jm, inv_r, b); else solve_real(Mr, piv_r, inv_r, b);
     };
     auto solve_c = [&](double (&br)[NEQ], double (&bi)[NEQ]) {
-        if constexpr (TRI) solve_cplx_tri(Jm, inv_cr, inv_ci, br, bi); else solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, br, bi);
+        if constexpr (TRI) solve_cplx_tri<Model, MATH>(Jm, inv_cr, inv_ci, br, bi); else solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, br, bi);
     };
 
     // Two loops.  The inner one is the state machine; it is left whenever a lane has finished its system (once per ~90
