@@ -43,6 +43,31 @@ constexpr double PD[NS][3] = {
     {13.0 / 3.0 + 7.0 * SQRT6 / 3.0, -23.0 / 3.0 - 22.0 * SQRT6 / 3.0, 10.0 / 3.0 + 5.0 * SQRT6},
     {13.0 / 3.0 - 7.0 * SQRT6 / 3.0, -23.0 / 3.0 + 22.0 * SQRT6 / 3.0, 10.0 / 3.0 - 5.0 * SQRT6},
     {1.0 / 3.0, -8.0 / 3.0, 10.0 / 3.0}};
+static_assert(T[2][0] == 1.0 && T[2][1] == 1.0 && T[2][2] == 0.0 && TI[1][0] == -TI[0][0] && TI[1][1] == -TI[0][1],
+              "the shortcuts of stage_increments / transformed_residuals (FAST) read these entries off the matrices");
+// Z = (T (x) I) W for one component.  FAST: the last row of T is (1, 1, 0) -- Z_3 = W_1 + W_2, no product with 0.
+template <int MATH>
+__device__ __forceinline__ void stage_increments(double w0, double w1, double w2, double& z0, double& z1, double& z2)
+{
+    z0 = T[0][0] * w0 + T[0][1] * w1 + T[0][2] * w2;
+    z1 = T[1][0] * w0 + T[1][1] * w1 + T[1][2] * w2;
+    if constexpr (MATH == MATH_FAST) z2 = w0 + w1;
+    else z2 = T[2][0] * w0 + T[2][1] * w1 + T[2][2] * w2;
+}
+// (TI (x) I) F for one component.  FAST: the first two rows of TI share their first two entries up to the sign.
+template <int MATH>
+__device__ __forceinline__ void transformed_residuals(double f0, double f1, double f2, double& r0, double& r1, double& r2)
+{
+    if constexpr (MATH == MATH_FAST) {
+        const double u = TI[0][0] * f0 + TI[0][1] * f1;
+        r0 = u + TI[0][2] * f2;
+        r1 = TI[1][2] * f2 - u;
+    } else {
+        r0 = TI[0][0] * f0 + TI[0][1] * f1 + TI[0][2] * f2;
+        r1 = TI[1][0] * f0 + TI[1][1] * f1 + TI[1][2] * f2;
+    }
+    r2 = TI[2][0] * f0 + TI[2][1] * f1 + TI[2][2] * f2;
+}
 // 1/x in the job's arithmetic: IEEE division (STRICT) or the Newton-refined v_rcp_f64 the RK45 loop uses
 // for its error ratio (FAST) -- an attempt of this pass divides ~30 times
 template <int MATH>
@@ -657,8 +682,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                             W[2][i] = d2[i];
                             const double r = vmax_abs2(vmax_abs(d0[i], d1[i]), d2[i]) * inv_sc[i];
                             nrm = vmax(nrm, r);
-#pragma unroll
-                            for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = T[s2][0] * W[0][i] + T[s2][1] * W[1][i] + T[s2][2] * W[2][i];
+                            stage_increments<MATH>(W[0][i], W[1][i], W[2][i], Z[0][i], Z[1][i], Z[2][i]);
                         }
                         HLM_RCOUNT(1);
                         prev = nrm;
@@ -684,9 +708,11 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
             }
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) {
-                d0[i] = (TI[0][0] * Fs[0][i] + TI[0][1] * Fs[1][i] + TI[0][2] * Fs[2][i]) - g_h * W[0][i];
-                d1[i] = (TI[1][0] * Fs[0][i] + TI[1][1] * Fs[1][i] + TI[1][2] * Fs[2][i]) - (a_h * W[1][i] + b_h * W[2][i]);
-                d2[i] = (TI[2][0] * Fs[0][i] + TI[2][1] * Fs[1][i] + TI[2][2] * Fs[2][i]) - (a_h * W[2][i] - b_h * W[1][i]);
+                double r0, r1, r2;
+                transformed_residuals<MATH>(Fs[0][i], Fs[1][i], Fs[2][i], r0, r1, r2);
+                d0[i] = r0 - g_h * W[0][i];
+                d1[i] = r1 - (a_h * W[1][i] + b_h * W[2][i]);
+                d2[i] = r2 - (a_h * W[2][i] - b_h * W[1][i]);
             }
             solve_r(d0);
             solve_c(d1, d2);
@@ -699,8 +725,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 W[2][i] += d2[i];
                 const double r = vmax_abs2(vmax_abs(d0[i], d1[i]), d2[i]) * inv_sc[i];
                 nrm = vmax(nrm, r);
-#pragma unroll
-                for (int s2 = 0; s2 < NS; ++s2) Z[s2][i] = T[s2][0] * W[0][i] + T[s2][1] * W[1][i] + T[s2][2] * W[2][i];
+                stage_increments<MATH>(W[0][i], W[1][i], W[2][i], Z[0][i], Z[1][i], Z[2][i]);
             }
             // the exits of the nested Newton loop, in its order
             int end = END_NONE;
