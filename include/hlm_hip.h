@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define HLM_ABI_VERSION 4
+#define HLM_ABI_VERSION 5
 #define HLM_NEQ 5           /* Model204::N_EQ, models/model_204.hpp:19 (and the DummyModel's) */
 #define HLM_MAX_NEQ 8       /* largest N_EQ a registered model may have (kernels are templates over it) */
 #define HLM_MAX_FORCINGS 16 /* I_O/forcing_data.h:5 */
@@ -315,7 +315,18 @@ typedef struct hlm_device_job {
      * sub-window continues from the state record -- so that the launch does not end on waves that each run the whole
      * window.  Same rows bit for bit.  0 = automatic, 1 = one wave per tile for the whole window. */
     int dense_sub_windows;
+    /* (ABI 5) Diagnostic: nullable DEVICE array of HLM_PATH_COUNTERS uint64 the launch ADDS to (the caller zeroes it):
+     * lane-attempts by the RHS form that produced the attempt's result -- [0] unsaturated static store with a dry
+     * surface store, [1] unsaturated with a wet surface (both: the two draining stores in closed form), [2] dry surface
+     * stage by stage, [3] the general RHS (models/model_204.hpp:94-113 in full: the static store overflows, x2 > 0, the
+     * cascade and the Manning pow run) -- [4] lane-attempts computed twice (begun on an unsaturated form, left its
+     * regime inside the step, recomputed stage by stage; counted under [2] / [3] too), [5] wave-attempts, [6]
+     * wave-attempts that executed more than one form.  Served by a counting instance of the queue kernel: the job must
+     * launch in time pieces, FAST arithmetic, adaptive steps, queue_group_tiles <= 1 (else HLM_ERR_INVALID_ARGUMENT).
+     * Results are those of the plain instance bit for bit; bench.py's saturating variants read it. */
+    uint64_t* d_path_counts;
 } hlm_device_job;
+#define HLM_PATH_COUNTERS 7
 
 /* The number of time pieces hlm_rk45_integrate_device(job) launches with (the automatic rule resolved; 0 = one wave
  * per tile: dense output, a resumable job, lane refill, or too small a launch).  No device is touched. */

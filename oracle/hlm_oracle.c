@@ -270,12 +270,13 @@ static void integrate_one(const hlm_oracle_job* J, int sys)
     double y[NEQ], y_next[NEQ], k[7][NEQ], err;
     for (int i = 0; i < n; ++i) y[i] = J->y0[(size_t)sys * n + i];
 
-    int next_q = 0, reject_count = 0, stiff = 0, capped = 0;
+    int next_q = 0, reject_count = 0, stiff = 0, capped = 0, paused = 0;
     uint32_t n_attempt = 0, n_accept = 0;
-    double t = J->t0;
-    double h = fixed ? J->fixed_step : P->initialStep;
+    double t = J->start_t ? J->start_t[sys] : J->t0;   /* (segment replay: see hlm_oracle.h) */
+    double h = fixed ? J->fixed_step : (J->start_h ? J->start_h[sys] : P->initialStep);
 
     while (t < J->tf && !stiff) {
+        if (J->use_t_stop && t >= J->t_stop) { paused = 1; break; }
         if (n_attempt >= cap) { capped = 1; break; }
         if (t + h > J->tf) h = J->tf - t; /* :54 */
 
@@ -340,8 +341,10 @@ static void integrate_one(const hlm_oracle_job* J, int sys)
     if (J->n_attempt) J->n_attempt[sys] = n_attempt;
     if (J->n_accept) J->n_accept[sys] = n_accept;
     if (J->t_reached) J->t_reached[sys] = t;
+    if (J->h_reached) J->h_reached[sys] = h;
     if (J->y_reached)
         for (int i = 0; i < n; ++i) J->y_reached[(size_t)sys * n + i] = y[i];
+    if (paused) { J->stiff[sys] = HLM_ORACLE_PAUSED; return; }
     if (capped && t < J->tf) { J->stiff[sys] = HLM_ORACLE_CAPPED; return; }
     if (stiff && t < J->tf) { J->stiff[sys] = HLM_ORACLE_STIFF; return; } /* :167-170 */
     for (int i = 0; i < n; ++i) J->y_final[(size_t)sys * n + i] = y[i]; /* :173-175 */

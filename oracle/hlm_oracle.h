@@ -87,7 +87,19 @@ typedef struct {
      * from the state at which RK45 gave up -- the rows RK45 wrote up to there stay, the implicit method takes
      * over from (t_reached, y_reached) with the first step initialStep. */
     int radau_continue;
+    /* hlm_oracle_rk45_run only: SEGMENT REPLAY (tests/conftest.py, third tier of the parity yardstick).  start_t /
+     * start_h (nullable, [ns]): system s enters the loop of rk45_kernel.cu:53 at (start_t[s], y0[s]) with the step
+     * start_h[s] -- a state another run of the same loop had reached -- instead of (t0, initialStep); t0 keeps its role
+     * in the minimum-step rule (:160).  use_t_stop: a system leaves the loop before the first attempt whose start time
+     * has reached t_stop (status HLM_ORACLE_PAUSED; t_reached / y_reached / h_reached hold the state): the pause
+     * protocol of the GPU's time chunks (hlm_device_job.t_stop), so that the two can be compared chunk by chunk. */
+    const double* start_t;
+    const double* start_h;
+    int use_t_stop;
+    double t_stop;
+    double* h_reached;       /* [ns] nullable: the step the next attempt would have used */
 } hlm_oracle_job;
+#define HLM_ORACLE_PAUSED 3
 
 /* The whole integration, rk45_kernel.cu:17-176.  Returns 0, or -1 on bad arguments. */
 int hlm_oracle_rk45_run(const hlm_oracle_job* job);

@@ -50,6 +50,7 @@ class _Job(C.Structure):
         ("y_final", C.c_void_p), ("dense_raw", C.c_void_p), ("stiff", C.c_void_p),
         ("n_attempt", C.c_void_p), ("n_accept", C.c_void_p), ("t_reached", C.c_void_p),
         ("y_reached", C.c_void_p), ("radau_continue", C.c_int),
+        ("start_t", C.c_void_p), ("start_h", C.c_void_p), ("use_t_stop", C.c_int), ("t_stop", C.c_double), ("h_reached", C.c_void_p),
     ]
 
 
@@ -152,7 +153,7 @@ def rk45_dense(y, k, h, theta):
 
 def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT=None,
         params=DEFAULT_PARAMS, forc_stub_f64=None, fixed_step=0.0, attempt_cap=0, nthreads=0,
-        reorder=True, radau=False, radau_only=False, fma=False, radau_continue=False):
+        reorder=True, radau=False, radau_only=False, fma=False, radau_continue=False, start_t=None, start_h=None, t_stop=None):
     """Integrate; returns dict(y_final[ns,5], dense[ns,nq,5] (or raw [ns,5,nq]), stiff, n_attempt, n_accept).
 
     radau=True re-integrates the systems RK45 flagged with the Radau-IIA fallback
@@ -160,7 +161,10 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     radau_continue=True (with radau): the flagged systems continue from the state RK45 reached instead of
     restarting at t0 (hlm_oracle_job.radau_continue).
     fma=True runs the FMA-contracted build instead: NOT a reference, only the yardstick for how far
-    two valid roundings of the same computation separate on this input."""
+    two valid roundings of the same computation separate on this input.
+    start_t / start_h ([ns]) and t_stop: segment replay (hlm_oracle.h) -- every system enters the loop at (start_t, y0)
+    with the step start_h and leaves it paused (stiff = PAUSED = 3, state in t_reached / y_reached / h_reached) before
+    the first attempt that starts at or after t_stop."""
     n = neq(uid)
     y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, n)
     ns = y0.shape[0]
@@ -196,6 +200,16 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     j.t_reached = _p(treach)
     yreach = np.zeros((ns, n))
     j.y_reached = _p(yreach)
+    hreach = np.zeros(ns)
+    j.h_reached = _p(hreach)
+    if start_t is not None:
+        st = np.ascontiguousarray(start_t, dtype=np.float64)
+        sh = np.ascontiguousarray(start_h, dtype=np.float64)
+        assert st.shape == (ns,) and sh.shape == (ns,)
+        j.start_t, j.start_h = _p(st), _p(sh)
+        keep += [st, sh]
+    if t_stop is not None:
+        j.use_t_stop, j.t_stop = 1, float(t_stop)
     j.radau_continue = 1 if (radau_continue and not radau_only) else 0
     if radau_only:
         stiff[:] = 1
@@ -213,4 +227,4 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
         dense = np.empty((ns, nq, n))
         lib().hlm_oracle_reorder_dense_n(_p(raw), _p(dense), ns, nq, n)
     return {"y_final": yf, "dense": dense, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "t_reached": treach,
-            "y_reached": yreach}
+            "y_reached": yreach, "h_reached": hreach}

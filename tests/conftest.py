@@ -90,10 +90,11 @@ YARDSTICK_PERTURBATIONS = ((1e-12, 0.0), (-1e-12, 0.0), (1e-11, 0.0), (-1e-11, 0
                            (0.0, 1e-12), (0.0, -1e-12))
 
 
-def perturbed_params(params, e_rtol, e_h0):
+def perturbed_params(params, e_rtol, e_h0, e_atol=0.0):
     p = list(params)
     p[0] *= 1.0 + e_h0
     p[1] *= 1.0 + e_rtol
+    p[2] *= 1.0 + e_atol
     return tuple(p)
 
 
@@ -164,27 +165,75 @@ def _subset_case(idx, y0, kw):
     return np.ascontiguousarray(y0[idx]), sub
 
 
-def extended_yardstick(oracle, uid, y0, t0, tf, idx, names=("y_final", "dense"), params=DEFAULT_PARAMS,
-                       n=EXTENDED_YARDSTICK_SAMPLES, seed=914, **kw):
-    """(spread, flips) of the hillslopes ``idx`` under ``n`` random perturbations of rtol and the first step,
-    relative size 1e-12 .. 1e-10 (a third rtol only, a third h0 only, a third both), against the unperturbed
-    oracle run of the same hillslopes.  Deterministic (seeded)."""
-    idx = np.asarray(idx, dtype=np.int64)
-    y0s, sub = _subset_case(idx, y0, kw)
-    base = oracle.run(uid, y0s, t0, tf, params=params, **sub)
+# The second tier on capacities that saturate storm after storm (SATURATING_YARDSTICK_SCALE, with_atol, gpu_subset_run).
+# Every rain onset there is a cascade of rejects whose outcome -- how small the step gets, whether six rejects or the
+# minimum step flag the hillslope (rk45_kernel.cu:160) -- depends on where the last step before the onset landed, and the
+# cascade amplifies a difference in the state by many orders of magnitude: the oracle's own text compiled with FMA
+# contraction, continued from THE SAME state, is off by 0.2 minutes in t and 65 parity bounds in y one storm hour later
+# (measured hour by hour with hlm_oracle_job.start_t / t_stop; 2 % of the hours of such a hillslope do that), while no
+# accept / reject decision of the run lies closer than 4e-5 to its threshold and the error norms of the two builds agree
+# to 4e-11 (99th percentile).  After two or three onsets two correct implementations simply hold different step
+# sequences, and WHICH later onset flags the hillslope is a draw.  Per hillslope the draw has a probability p of
+# "flagged somewhere in the window"; where p is 0.99, 48 oracle samples all flag with probability 0.6 -- and the GPU's
+# single run does not with probability 0.01, on 30 000 such hillslopes.  So on this workload the tier
+# (a) perturbs by 1e-9 .. 1e-7 instead of 1e-12 .. 1e-10 and moves atol with rtol: the perturbation then needs one or two
+#     onsets less to grow to O(1) -- hillslopes flagged in the first days have seen few -- whichever term of
+#     atol + rtol |y| dominates (the stores in question are 1e-7 m deep); a change of 1e-7 relative in tolerances of 1e-6
+#     moves a well-conditioned result by ~1e-13 relative, far below the bound;
+# (b) samples the GPU's side as well (``gpu_subset_run``): the same perturbations through the HIP path on the unexplained
+#     hillslopes alone.  A hillslope on which the GPU's one run is the rare draw shows it there: the GPU's perturbed runs
+#     then mostly agree with the oracle and differ from the GPU's own unperturbed run.  A hillslope on which the GPU is
+#     SYSTEMATICALLY different from the oracle -- a wrong kernel -- moves on neither side and fails.
+SATURATING_YARDSTICK_SCALE = (-9.0, -7.0)
+
+
+def yardstick_samples(n=EXTENDED_YARDSTICK_SAMPLES, seed=914, scale=(-12.0, -10.0), with_atol=False):
+    """The second tier's perturbations (relative change of rtol, of initialStep, of atol): relative size 10^scale, a third
+    rtol only, a third initialStep only, a third both; ``with_atol`` moves atol with rtol.  Deterministic (seeded)."""
     rng = np.random.default_rng(seed)
-    spread = np.zeros(len(idx))
-    flips = np.zeros(len(idx), dtype=bool)
+    out = []
     for k in range(n):
-        er = rng.uniform(-1, 1) * 10.0 ** rng.uniform(-12, -10)
-        eh = rng.uniform(-1, 1) * 10.0 ** rng.uniform(-12, -10)
+        er = rng.uniform(-1, 1) * 10.0 ** rng.uniform(*scale)
+        eh = rng.uniform(-1, 1) * 10.0 ** rng.uniform(*scale)
         if k % 3 == 0:
             eh = 0.0
         if k % 3 == 1:
             er = 0.0
-        a = oracle.run(uid, y0s, t0, tf, params=perturbed_params(params, er, eh), **sub)
+        out.append((er, eh, er if with_atol else 0.0))
+    return out
+
+
+def extended_yardstick(oracle, uid, y0, t0, tf, idx, names=("y_final", "dense"), params=DEFAULT_PARAMS,
+                       n=EXTENDED_YARDSTICK_SAMPLES, seed=914, scale=(-12.0, -10.0), with_atol=False, **kw):
+    """(spread, flips) of the hillslopes ``idx`` under the perturbations of yardstick_samples(), against the unperturbed
+    oracle run of the same hillslopes."""
+    idx = np.asarray(idx, dtype=np.int64)
+    y0s, sub = _subset_case(idx, y0, kw)
+    base = oracle.run(uid, y0s, t0, tf, params=params, **sub)
+    spread = np.zeros(len(idx))
+    flips = np.zeros(len(idx), dtype=bool)
+    for er, eh, ea in yardstick_samples(n, seed, scale, with_atol):
+        a = oracle.run(uid, y0s, t0, tf, params=perturbed_params(params, er, eh, ea), **sub)
         spread = np.maximum(spread, scaled_deviation(a, base, names))
         flips |= a["stiff"] != base["stiff"]
+    return spread, flips
+
+
+def extended_yardstick_gpu(gpu_subset_run, got, idx, names, params=DEFAULT_PARAMS, n=EXTENDED_YARDSTICK_SAMPLES, seed=914,
+                           scale=(-12.0, -10.0), with_atol=False):
+    """The same samples through the HIP path: ``gpu_subset_run(idx, params)`` integrates the hillslopes ``idx`` alone and
+    returns their result dict.  The unperturbed subset run must hold the bits of the full run ``got`` (a hillslope's
+    result does not depend on its neighbours); (spread, flips) are measured against it."""
+    base = gpu_subset_run(idx, params)
+    for k in names + ("stiff",):
+        if got.get(k) is not None:
+            assert np.array_equal(base[k], got[k][idx]), f"GPU subset run differs from the full run in {k}"
+    spread = np.zeros(len(idx))
+    flips = np.zeros(len(idx), dtype=bool)
+    for er, eh, ea in yardstick_samples(n, seed, scale, with_atol):
+        g = gpu_subset_run(idx, perturbed_params(params, er, eh, ea))
+        spread = np.maximum(spread, scaled_deviation(g, base, names))
+        flips |= g["stiff"] != base["stiff"]
     return spread, flips
 
 
@@ -205,11 +254,12 @@ def _zero_row_pattern_differs(a, b):
 
 
 def assert_parity_with_exemptions(got, ref, alts, max_exempt, names=("y_final", "dense"), what="", got_alts=(),
-                                  extended=None, max_exempt_extended=0):
+                                  extended=None, max_exempt_extended=0, proportion_guard=True):
     """Every hillslope within the bound with the oracle's flag, or individually shown ill-conditioned; at most
     ``max_exempt`` of the latter (committed per test).  ``extended`` = dict(oracle=, uid=, y0=, t0=, tf=, kw=) runs
     the second tier (extended_yardstick) on the hillslopes the first tier leaves unexplained; at most
-    ``max_exempt_extended`` may need it.  Returns (first-tier exemptions, worst deviation among the rest)."""
+    ``max_exempt_extended`` may need it (``extended["scale"]`` / ``["with_atol"]``: see extended_yardstick).  Returns
+    (first-tier exemptions, worst deviation among the rest)."""
     within, exempt, dev, spread = parity_or_shown_ill_conditioned(got, ref, alts, names, got_alts)
     flips = np.any([a["stiff"] != ref["stiff"] for a in alts], axis=0) | (got["stiff"] != ref["stiff"])
     for g in got_alts:
@@ -224,16 +274,25 @@ def assert_parity_with_exemptions(got, ref, alts, max_exempt, names=("y_final", 
     flips |= moved_flag_time
     bad = ~(within | exempt)
     n_ext = 0
+    ext_set = np.zeros(len(bad), dtype=bool)   # the hillslopes only the second tier explains
     if bad.any() and extended is not None:
         idx = np.flatnonzero(bad)
+        tier = dict(scale=extended.get("scale", (-12.0, -10.0)), with_atol=extended.get("with_atol", False))
         s2, f2 = extended_yardstick(extended["oracle"], extended["uid"], extended["y0"], extended["t0"], extended["tf"],
-                                    idx, names=names, **extended.get("kw", {}))
+                                    idx, names=names, **tier, **extended.get("kw", {}))
+        if extended.get("gpu_subset_run") is not None:   # the GPU's side of the same samples, on the hillslopes still unexplained
+            left = ~(f2 | (s2 >= 0.5) | (s2 >= dev[idx]))
+            if left.any():
+                s3, f3 = extended_yardstick_gpu(extended["gpu_subset_run"], got, idx[left], tuple(names), **tier)
+                s2[left] = np.maximum(s2[left], s3)
+                f2[left] |= f3
         shown2 = f2 | (s2 >= 0.5) | (s2 >= dev[idx])
         spread = spread.copy()
         spread[idx] = np.maximum(spread[idx], s2)
         flips[idx] |= f2
         exempt = exempt.copy()
         exempt[idx[shown2]] = True
+        ext_set[idx[shown2]] = True
         n_ext = int(shown2.sum())
         bad = ~(within | exempt)
     if os.environ.get("HLM_PARITY_DIAG"):  # development aid: per-hillslope numbers of every call
@@ -244,7 +303,10 @@ def assert_parity_with_exemptions(got, ref, alts, max_exempt, names=("y_final", 
     detail = [(int(i), float(dev[i]), float(spread[i]), int(got["stiff"][i]), int(ref["stiff"][i])) for i in np.flatnonzero(bad)[:10]]
     assert not bad.any(), (f"{what}: {bad.sum()} hillslopes outside the parity bound and NOT shown ill-conditioned "
                            f"(index, dev, yardstick spread, flag got/ref): {detail}")
-    far = exempt & ~flips & (dev > EXEMPT_DEV_OVER_SPREAD * np.maximum(spread, 0.5))
+    # (proportion_guard=False: workloads on which the deviation of an ill-conditioned hillslope is a heavy-tailed draw --
+    # three yardstick samples do not bound a fourth draw within a factor; the caller then holds the DISTRIBUTION of the
+    # GPU's deviations against the yardstick's: assert_deviations_distributed_like_the_yardstick)
+    far = exempt & ~flips & (dev > EXEMPT_DEV_OVER_SPREAD * np.maximum(spread, 0.5)) & proportion_guard
     assert not far.any(), (f"{what}: exempt hillslopes whose deviation is out of proportion to what the yardstick moved "
                            f"(index, dev, spread): {[(int(i), float(dev[i]), float(spread[i])) for i in np.flatnonzero(far)[:10]]}")
     n = int(exempt.sum()) - n_ext
@@ -258,6 +320,8 @@ def assert_parity_with_exemptions(got, ref, alts, max_exempt, names=("y_final", 
     assert recording or n_ext <= max_exempt_extended, (f"{what}: {n_ext} hillslopes needed the second yardstick tier "
                                                        f"(committed: {max_exempt_extended})")
     _check_committed_exempt_set(what, exempt)
+    if max_exempt_extended > 0 or (recording and n_ext > 0):   # (pinned by index like the first tier's, under its own label)
+        _check_committed_exempt_set(what + " (second tier)", ext_set)
     if os.environ.get("HLM_PARITY_RECORD") and extended is not None:   # how many of them needed the second tier
         rec = os.environ["HLM_PARITY_RECORD"]
         cur = json.load(open(rec)) if os.path.exists(rec) else {}
@@ -304,3 +368,36 @@ def _check_committed_exempt_set(what, exempt):
         f"tests/golden/parity_exempt_sets.json: {idx[:20]}")
     extra = sorted(set(idx) - set(_EXEMPT_SETS.get(what, [])))
     assert not extra, f"{what}: exempt hillslopes outside the committed index set: {extra[:20]}"
+
+
+def assert_deviations_distributed_like_the_yardstick(got, ref, alts, names=("y_final",), what="", factor=1.25, quantiles=(0.9, 0.99, 0.999)):
+    """For workloads on which two correct implementations hold different step sequences after a few events (see
+    SATURATING_YARDSTICK_SCALE): hillslope by hillslope the GPU can only be held to the bound where the hillslope is
+    well-conditioned (assert_parity_with_exemptions does that); over ALL hillslopes its disagreement with the oracle
+    must look like the disagreement of the oracle's own variants (``alts``: the FMA build, rtol (1 +- 1e-12)) with the
+    oracle -- a kernel that is wrong on the ill-conditioned hillslopes only would show here:
+    * hillslopes whose flag differs from the oracle's: at most ``factor`` x the worst variant's count (+ 3 sigma);
+    * hillslopes unflagged on both sides but outside the bound: likewise;
+    * the 90 / 99 / 99.9 % quantiles of the deviation among the hillslopes unflagged on both sides: at most 3 x the
+      largest of the variants' same quantiles (where that is above the bound at all).
+    Returns a dict of the numbers."""
+    dev = scaled_deviation(got, ref, names)
+    mism = int((got["stiff"] != ref["stiff"]).sum())
+    both = (got["stiff"] == 0) & (ref["stiff"] == 0)
+    out_g = int((dev[both] > 1.0).sum())
+    a_mism, a_out, a_q = [], [], []
+    for a in alts:
+        d = scaled_deviation(a, ref, names)
+        b = (a["stiff"] == 0) & (ref["stiff"] == 0)
+        a_mism.append(int((a["stiff"] != ref["stiff"]).sum()))
+        a_out.append(int((d[b] > 1.0).sum()))
+        a_q.append(np.quantile(d[b], quantiles))
+    g_q = np.quantile(dev[both], quantiles)
+    res = {"flag_mismatches": mism, "yardstick_flag_mismatches": a_mism, "outside_bound_unflagged": out_g, "yardstick_outside_bound_unflagged": a_out,
+           "deviation_quantiles": [float(x) for x in g_q], "yardstick_deviation_quantiles": [[float(x) for x in q] for q in a_q]}
+    lim = lambda counts: factor * max(counts) + 3.0 * np.sqrt(max(counts) + 1.0)
+    assert mism <= lim(a_mism), f"{what}: {mism} flag mismatches with the oracle; its own variants: {a_mism}"
+    assert out_g <= lim(a_out), f"{what}: {out_g} unflagged hillslopes outside the bound; the oracle's own variants: {a_out}"
+    worst_q = np.max(np.array(a_q), axis=0)
+    assert np.all(g_q <= np.maximum(3.0 * worst_q, 1.0)), f"{what}: deviation quantiles {g_q} against the variants' {worst_q}"
+    return res

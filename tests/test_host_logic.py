@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol(hlm):
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
     # and the python binding covers exactly the header
     assert sorted(hlm._lib.SIGNATURES) == names
-    assert hlm._lib.lib().hlm_abi_version() == 4
+    assert hlm._lib.lib().hlm_abi_version() == 5
 
 
 def test_struct_layouts_match_header(hlm, tmp_path):
@@ -50,12 +50,12 @@ def test_struct_layouts_match_header(hlm, tmp_path):
     exe = tmp_path / "layout"
     subprocess.run(["gcc", "-std=c11", "-I", os.path.join(ROOT, "include"), "-o", str(exe), str(src)], check=True)
     got = dict(ln.split() for ln in subprocess.run([str(exe)], check=True, stdout=subprocess.PIPE, text=True).stdout.splitlines())
-    assert int(got["abi"]) == hlm._lib.lib().hlm_abi_version() == 4
+    assert int(got["abi"]) == hlm._lib.lib().hlm_abi_version() == 5
     for cname, ct in structs.items():
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
-    assert len(hlm._lib.DeviceJob._fields_) == 40 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
+    assert len(hlm._lib.DeviceJob._fields_) == 41 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
 
 
 def test_registry_roundtrip_and_validation_without_gpu(hlm):
@@ -425,7 +425,7 @@ def test_queue_kernels_keep_the_item_loop_wave_uniform():
     if not os.path.exists(asm) or os.path.getmtime(asm) < max(os.path.getmtime(f) for f in srcs):
         subprocess.run(["make", "-C", csrc, "asm"], check=True, capture_output=True)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_queue_isa.py"), asm], capture_output=True, text=True)
-    assert r.returncode == 0 and "18 instances, 0 bad" in r.stdout, r.stdout + r.stderr
+    assert r.returncode == 0 and "19 instances, 0 bad" in r.stdout, r.stdout + r.stderr
 
 
 def test_tableau_polynomials_of_the_linear_test_equation(tmp_path):

@@ -170,3 +170,37 @@ def test_fma_yardstick_build_tracks_the_oracle(oracle, golden):
     assert np.max(np.abs(a["y_final"] - b["y_final"]) / (1e-300 + np.abs(a["y_final"]))) < 1e-10
     assert np.max(np.abs(a["dense"] - b["dense"])) < 1e-10
     assert np.abs(a["y_final"] - golden["g2_final"]).max() < 1e-12  # the plain build is the pinned one
+
+
+def test_oracle_pause_protocol_reproduces_the_uninterrupted_run(oracle):
+    """hlm_oracle_job.start_t / start_h / t_stop (the third tier of the GPU parity yardstick replays the GPU's states
+    segment by segment with it): the oracle stopped at every hour -- before the first attempt that starts at or after
+    the edge, the GPU's pause protocol -- and continued from its own (y, t, h) gives the flags, final states and
+    attempt counts of the uninterrupted run BIT FOR BIT, on capacities that saturate storm after storm (hillslopes
+    are flagged all through the window)."""
+    from tiger_hlm_gpu_amd import synth
+    O = oracle
+    ns, start, days = 48, 300_000, 4
+    sp = synth.model204_params(start, ns, saturating=True)
+    y0 = synth.model204_y0(ns, settled_for=sp)
+    cells = synth.cell_of_system(start, ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days)
+    tf = days * 1440.0
+    forc = synth.expand_per_stream(pr, t2m, cells)
+    ref = O.run(O.UID_204, y0, 0.0, tf, sp=sp, forc=forc, forc_dt_h=dt, forc_nT=nT)
+    y, t, h = y0.copy(), np.zeros(ns), np.full(ns, 0.01)
+    live, st, yf, att = np.ones(ns, bool), np.zeros(ns, np.int32), np.zeros((ns, 5)), np.zeros(ns, np.int64)
+    for k in range(1, int(tf / 60) + 1):
+        idx = np.flatnonzero(live)
+        if idx.size == 0:
+            break
+        r = O.run(O.UID_204, y[idx], 0.0, tf, sp=sp[idx], forc=forc[:, idx], forc_dt_h=dt, forc_nT=nT, start_t=t[idx], start_h=h[idx],
+                  t_stop=None if k * 60.0 >= tf else k * 60.0)
+        att[idx] += r["n_attempt"]
+        p = r["stiff"] == 3
+        assert np.all(r["t_reached"][p] >= k * 60.0)
+        y[idx[p]], t[idx[p]], h[idx[p]] = r["y_reached"][p], r["t_reached"][p], r["h_reached"][p]
+        d = idx[~p]
+        st[d], yf[d], live[d] = r["stiff"][~p], r["y_final"][~p], False
+    assert 0 < (ref["stiff"] == 1).sum() < ns
+    assert np.array_equal(st, ref["stiff"]) and np.array_equal(yf, ref["y_final"]) and np.array_equal(att, ref["n_attempt"])

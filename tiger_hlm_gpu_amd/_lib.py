@@ -21,6 +21,7 @@ UID_TOY3 = 3
 MATH_STRICT = 0
 MATH_FAST = 1
 SYS_OK, SYS_STIFF, SYS_CAPPED = 0, 1, 2
+PATH_COUNTERS = 7  # HLM_PATH_COUNTERS (hlm_device_job.d_path_counts)
 
 
 class HlmError(RuntimeError):
@@ -61,6 +62,7 @@ class DeviceJob(C.Structure):
         ("lane_refill", C.c_int),
         ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
         ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int), ("queue_run_pieces", C.c_int), ("queue_group_tiles", C.c_int), ("dense_sub_windows", C.c_int),
+        ("d_path_counts", C.c_void_p),
     ]
 
 

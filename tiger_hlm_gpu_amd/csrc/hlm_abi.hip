@@ -276,17 +276,22 @@ RefillFn pick_refill(int uid, int math, bool fixed)
 // the persistent kernels over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): no dense output
 using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int, const hlm::QueueRuns);
 template <class Model>
-QueueFn pick_queue(int math, bool fixed, bool retile)
+QueueFn pick_queue(int math, bool fixed, bool retile, bool count = false)
 {
     using namespace hlm;
+    // (the counting instance: FAST, adaptive, tiles as items -- validate_job refuses d_path_counts on anything else)
+    if (count) {   // (only a model with per-hillslope RHS forms has anything to count: Model 204)
+        if constexpr (Model::HAS_NORAINPATH && Model::NORAIN_LINEAR > 0) return rk45_queue_kernel<Model, MATH_FAST, false, false, true>;
+        else return nullptr;
+    }
     if (retile && !fixed)   // (the re-tiling instances: adaptive steps only -- a fixed-step run never flags)
         return math == HLM_MATH_FAST ? rk45_queue_kernel<Model, MATH_FAST, false, true> : rk45_queue_kernel<Model, MATH_STRICT, false, true>;
     if (math == HLM_MATH_FAST) return fixed ? rk45_queue_kernel<Model, MATH_FAST, true> : rk45_queue_kernel<Model, MATH_FAST, false>;
     return fixed ? rk45_queue_kernel<Model, MATH_STRICT, true> : rk45_queue_kernel<Model, MATH_STRICT, false>;
 }
-QueueFn pick_queue(int uid, int math, bool fixed, bool retile)
+QueueFn pick_queue(int uid, int math, bool fixed, bool retile, bool count = false)
 {
-    return with_model<QueueFn>(uid, [&](auto m) { return pick_queue<decltype(m)>(math, fixed, retile); });
+    return with_model<QueueFn>(uid, [&](auto m) { return pick_queue<decltype(m)>(math, fixed, retile, count); });
 }
 
 KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
@@ -365,6 +370,10 @@ int validate_job(const hlm_device_job* j)
     if (j->dense_sub_windows < 0 || j->dense_sub_windows > 4096) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_sub_windows must be within [0, 4096]");
     if (j->queue_group_tiles < 0 || j->queue_group_tiles > hlm::QUEUE_MAX_GROUP)
         return fail(HLM_ERR_INVALID_ARGUMENT, "queue_group_tiles must be within [0, %d]", hlm::QUEUE_MAX_GROUP);
+    if (j->lane_refill == 0 && j->d_path_counts &&
+        (j->math_mode != HLM_MATH_FAST || j->fixed_step > 0.0 || j->queue_group_tiles > 1 || j->num_queries > 0))
+        return fail(HLM_ERR_INVALID_ARGUMENT, "d_path_counts: the counting instance is the queue kernel in FAST arithmetic with adaptive "
+                                              "steps, no dense output and tiles as items (queue_group_tiles <= 1)");
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
@@ -423,6 +432,7 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     a.n_attempt = j->d_n_attempt;
     a.n_accept = j->d_n_accept;
     a.flag_state = j->d_flag_state;
+    a.path_counts = reinterpret_cast<unsigned long long*>(j->d_path_counts);
     if (job_selects(j)) {
         a.dense_k = j->dense_ncomp;
         for (int c = 0; c < HLM_MAX_NEQ; ++c) a.dense_pos[c] = -1;
@@ -539,8 +549,8 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
 {
     const bool fixed = j->fixed_step > 0.0;
     const int group = j->queue_group_tiles > 1 && !fixed ? j->queue_group_tiles : 1;
-    QueueFn fn = pick_queue(j->uid, j->math_mode, fixed, group > 1);
-    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
+    QueueFn fn = pick_queue(j->uid, j->math_mode, fixed, group > 1, j->d_path_counts != nullptr);
+    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d%s", j->uid, j->d_path_counts ? " (d_path_counts: the model has no per-hillslope RHS forms to count)" : "");
     if (windowed && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "a window launch needs d_resume");
     int dev = 0, cus = 0, per_cu = 0;
     HLM_HIP_TRY(hipGetDevice(&dev));
@@ -587,6 +597,8 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
     // names a run length or a cap of its own
     hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, group > 1 && j->queue_run_pieces == 0 ? 1 : j->queue_run_pieces);
     runs.group = group;
+    if (group > 1)   // test hook: sibling passes of a group staggered in time (hlm_rk45_queue_kernel.h)
+        if (const char* e = std::getenv("HLM_QUEUE_STAGGER_TICKS")) runs.stagger_ticks = (unsigned int)std::strtoul(e, nullptr, 10);
     runs.t_begin = w0;
     runs.piece_len = (w1 - w0) / (double)pieces;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, pieces, runs);
@@ -662,6 +674,8 @@ int launch(const hlm_device_job* j, hipStream_t stream)
 {
     const bool dense = j->num_queries > 0;
     const bool fixed = j->fixed_step > 0.0;
+    if (j->d_path_counts && job_time_pieces(j) <= 1)
+        return fail(HLM_ERR_INVALID_ARGUMENT, "d_path_counts: this job does not launch in time pieces (set time_pieces > 1)");
     if (const int nsub = job_dense_sub_windows(j); nsub > 1) return launch_dense_queue(j, nsub, stream);
 #ifdef HLM_EXPERIMENTAL_PATHS
     if (!dense && j->lane_refill && !job_is_resumable(j)) return launch_refill(j, stream);

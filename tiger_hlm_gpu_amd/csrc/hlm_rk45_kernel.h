@@ -77,6 +77,9 @@ struct Rk45Args {
     // nullable, [ns][N_EQ + 1]: a lane that is flagged stiff records the state it had reached, {y[N_EQ], t}, for a
     // Radau pass that continues from there instead of restarting at t0 (hlm_device_job.d_flag_state)
     double* flag_state;
+    // nullable, [PATH_COUNTERS] (COUNT instances of the queue kernel only; hlm_device_job.d_path_counts): lane-attempts per
+    // RHS form, summed over the launch -- see LanePathCount
+    unsigned long long* path_counts;
 };
 
 // The launch arguments read again from the kernel-argument segment (constant address space: scalar loads), field by
@@ -100,6 +103,7 @@ __device__ __forceinline__ Rk45Args load_args(Rk45ArgsConst* p)
 #pragma unroll
     for (int c = 0; c < HLM_MAX_NEQ; ++c) a.dense_pos[c] = p->dense_pos[c];
     a.flag_state = p->flag_state;
+    a.path_counts = p->path_counts;
     return a;
 }
 
@@ -511,6 +515,88 @@ __device__ __forceinline__ void attempt_per_lane_path(const typename Model::Loca
         }
         if (general) rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
     }
+    have_k0 = true;
+}
+
+// ---- which RHS form integrated an attempt (diagnostic instances only: hlm_device_job.d_path_counts) -----------------
+// Lane-attempts by the form that produced the attempt's result -- [0] unsaturated with a dry surface (PATH_NORAIN, the
+// linear stores in closed form), [1] unsaturated with a wet surface (PATH_WETU, closed form), [2] dry surface stage by
+// stage (PATH_DRY), [3] the general RHS (PATH_GENERAL: the static store overflows, the whole cascade runs) -- and
+// [4] lane-attempts computed TWICE: started on an unsaturated form, left its regime inside the step, recomputed stage by
+// stage (they are counted under [2] / [3] as well).  [5] wave-attempts (one per wave and trip of the attempt loop),
+// [6] wave-attempts that executed more than one form (lanes of the wave on different forms, or a recomputation).
+constexpr int PATH_COUNTERS = 7;
+struct LanePathCount {
+    uint32_t n[PATH_COUNTERS] = {};
+    __device__ __forceinline__ void lane(int k) { ++n[k]; }
+    // called by every lane that took part in the attempt; the wave's first active lane keeps the wave-level counts
+    __device__ __forceinline__ void wave(bool several)
+    {
+        const unsigned long long act = __builtin_amdgcn_ballot_w64(true);
+        if ((int)__builtin_ctzll(act) == (int)threadIdx.x) { ++n[5]; n[6] += several ? 1u : 0u; }
+    }
+    __device__ __forceinline__ void flush(unsigned long long* out)
+    {
+        if (!out) return;
+#pragma unroll
+        for (int k = 0; k < PATH_COUNTERS; ++k)
+            if (n[k]) (void)__hip_atomic_fetch_add(&out[k], (unsigned long long)n[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+};
+
+// attempt_per_lane_path with the counts: THE SAME sequence of calls (the results are bit-identical, tested), kept as a
+// copy because the plain function is part of the headline kernel, whose register allocation moves with anything that
+// touches its text -- even template parameters that compile to nothing (measured: 36 -> 73 spilled VGPRs).
+template <class Model, int MATH, bool FIXED>
+__device__ __forceinline__ void attempt_per_lane_path_counted(const typename Model::Local& P, const typename Model::Forc& FV,
+                                                              const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool& have_k0,
+                                                              double (&k0)[Model::N_EQ], double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ],
+                                                              double (&k3)[Model::N_EQ], double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ],
+                                                              double (&k6)[Model::N_EQ], double (&yt)[Model::N_EQ], double& err, double& jump,
+                                                              LanePathCount& pc)
+{
+    const bool nr = Model::norainpath_ok(P, FV, y), wu = !nr && Model::wetupath_ok(P, FV, y);
+    // how many of the four blocks below this WAVE executes
+    int forms = (__builtin_amdgcn_ballot_w64(nr) != 0ull) + (__builtin_amdgcn_ballot_w64(wu) != 0ull);
+    bool tried_unsat = false;
+    bool stagewise = true;
+    if (nr) {
+        const bool had_k0 = have_k0;
+        const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED, true>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        stagewise = broke;
+        have_k0 = broke ? had_k0 : true;
+        tried_unsat = true;
+        if (!broke) pc.lane(0);
+    }
+    else if (wu) {
+        const bool had_k0 = have_k0;
+        const bool broke = rk_attempt<Model, MATH, PATH_WETU, FIXED, true>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        stagewise = broke;
+        have_k0 = broke ? had_k0 : true;
+        tried_unsat = true;
+        if (!broke) pc.lane(1);
+    }
+    int stage_forms = 0;  // stage-wise blocks this lane's branch executed (uniform among the lanes that took it)
+    if (stagewise) {
+        bool general = true;
+        if constexpr (Model::HAS_FASTPATH) {
+            if (__builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
+                const bool broke = rk_attempt<Model, MATH, PATH_DRY, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                have_k0 = true;
+                general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+                ++stage_forms;
+                if (!general) pc.lane(2);
+            }
+        }
+        if (general) {
+            rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+            ++stage_forms;
+            pc.lane(3);
+        }
+        if (tried_unsat) pc.lane(4);
+    }
+    forms += __builtin_amdgcn_ballot_w64(stage_forms >= 2) != 0ull ? 2 : (__builtin_amdgcn_ballot_w64(stage_forms >= 1) != 0ull ? 1 : 0);
+    pc.wave(forms > 1);
     have_k0 = true;
 }
 

@@ -37,9 +37,15 @@
 // (SURVEY's generator flags 42 % of them stiff; a flagged lane idles in its wave for the rest of the launch: 42 of 64
 // lanes active).  The tiles are taken in GROUPS of G neighbours: item (piece, tile j) is pass j % G of group j / G --
 // the wave reads the group's status words, packs the hillslopes that are still integrating into an LDS list (in their
-// order, by ballot and popcount; all G waves of a group build the same list) and integrates the 64 hillslopes of ITS
-// pass, or nothing when the group has fewer passes left.  A piece of a group starts when all G passes of its previous
-// piece are through (the group's counter counts passes).  Every piece is handed over through the record (runs of
+// order, by ballot and popcount) and integrates the 64 hillslopes of ITS pass, or nothing when the group has fewer passes
+// left.  All G passes of a (run, group) must build THE SAME list although they run at different times and the status
+// words change under them (a sibling pass finishes or flags a hillslope): the list is therefore a function of the state
+// at the START of the run -- a hillslope that stops integrating in run r stores its status with the run number in the
+// upper bits (status | (r + 1) << 8), and a pass of run r lists every hillslope that is PAUSED or carries the tag of
+// run r itself ("alive when the run began"; round-4 advisor finding: with the live status words a pass that came late
+// saw a shorter list, and a hillslope could be skipped or integrated twice).  Nothing else reads the tag: every other
+// reader of the record only asks "== SYS_PAUSED?".  A piece of a group starts when all G passes of its previous piece
+// are through (the group's counter counts passes), so no status word of run r + 1 exists while a pass of run r lists.  Every piece is handed over through the record (runs of
 // one piece), which this mode needs anyway; there is no global re-tiling, no extra launch and no drain, and a group
 // of 8 tiles is one forcing cell's worth of neighbours, so the passes rarely mix forcing cells.  The results cannot depend on the
 // packing: lane states travel by hillslope number and no RHS form is chosen by a neighbour's values.
@@ -49,6 +55,8 @@
 // gives the tile up: its unfinished hillslopes come back flagged HLM_SYS_CAPPED with zero finals, the channel of
 // "stopped before tf by a resource limit", and an abort word makes every later wait give up at once.
 #pragma once
+
+#include <type_traits>
 
 #include "hlm_rk45_kernel.h"
 
@@ -84,6 +92,7 @@ __device__ unsigned long long* g_queue_prof = nullptr;
 #define HLM_QUEUE_WAIT_LIMIT_TICKS 2000000000ull  // 20 s of wall_clock64() (100 MHz)
 #endif
 constexpr unsigned long long QUEUE_WAIT_LIMIT_TICKS = HLM_QUEUE_WAIT_LIMIT_TICKS;
+constexpr int STATUS_TAG_SHIFT = 8;   // GROUPS: status | (run + 1) << STATUS_TAG_SHIFT (see below)
 
 // The runs of a launch (kernel argument): run r covers the pieces [begin(r), begin(r + 1)).
 constexpr int QUEUE_MAX_RUNS = 15;
@@ -100,6 +109,10 @@ struct QueueRuns {
     // neighbouring tiles whose hillslopes still integrating are packed into full passes of 64, piece by piece; item
     // (piece, tile j) is pass j % G of group j / G (see "GROUPS" below)
     int group;
+    // test hook (HLM_QUEUE_STAGGER_TICKS in the environment of the launching process; 0 = off): pass p of a group waits
+    // p x this many ticks of the 100 MHz clock before it builds its list, so that its sibling passes have finished
+    // hillslopes by then -- the schedule the list rule above has to survive (tests/test_headline_kernel_gpu.py)
+    unsigned int stagger_ticks;
     __host__ __device__ int begin(int r, int npieces) const
     {
         if (uniform > 0) { const long long b = (long long)r * uniform; return b < npieces ? (int)b : npieces; }
@@ -119,7 +132,8 @@ __global__ void queue_init_kernel(unsigned int* __restrict__ queue, unsigned int
 // RETILE: the instances that may change which hillslopes share a wave -- groups of tiles packed per piece
 // (hlm_device_job.queue_group_tiles).  The plain instances (RETILE = false) carry none of that code: the headline
 // kernel's register allocation is sensitive to it (+1 ... 5 % with it compiled in).
-template <class Model, int MATH, bool FIXED, bool RETILE = false>
+// COUNT: the diagnostic instances that also count lane-attempts per RHS form (Rk45Args.path_counts; LanePathCount).
+template <class Model, int MATH, bool FIXED, bool RETILE = false, bool COUNT = false>
 __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
     rk45_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nchunk, const QueueRuns R)
 {
@@ -186,12 +200,26 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
         // the hillslopes of this item, 64 per pass: the tile's -- or (G > 1) the group's survivors, packed
         unsigned n_listed = WAVE;   // (G == 1: one pass over the tile's slots; the lanes filter themselves below)
         if (RETILE && G > 1u) {
+            if (R.stagger_ticks != 0u && !lost) {   // (test hook: let the sibling passes get ahead)
+                const long long until = (long long)wall_clock64() + (long long)(tile % G) * (long long)R.stagger_ticks;
+                while ((long long)wall_clock64() < until) __builtin_amdgcn_s_sleep(32);
+            }
             n_listed = 0u;
+            const int run_tag = (int)(r + 1u) << STATUS_TAG_SHIFT;
             for (unsigned k = 0; k < G; ++k) {
                 const unsigned slot = (dep * G + k) * WAVE + (unsigned)lane;
                 const bool in_range = slot < nsys;
                 const int s_k = in_range ? (int)slot : 0;
-                const bool alive = in_range && (!from_record || coherent_load(&resume_i[(size_t)4 * A.ns + s_k]) == SYS_PAUSED);
+                // alive when this run began: still PAUSED, or stopped by a sibling pass of this very run
+                bool alive = in_range;
+                if (in_range && from_record) {
+                    const int st = coherent_load(&resume_i[(size_t)4 * A.ns + s_k]);
+#ifdef HLM_QUEUE_OLD_LIST
+                    alive = st == SYS_PAUSED;   // (round 4's rule, kept only to show the stress test catches it)
+#else
+                    alive = st == SYS_PAUSED || (st & ~((1 << STATUS_TAG_SHIFT) - 1)) == run_tag;
+#endif
+                }
                 const unsigned long long m = __builtin_amdgcn_ballot_w64(alive);
                 if (alive) group_list[n_listed + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1ull))] = s_k;
                 n_listed += (unsigned)__builtin_popcountll(m);
@@ -213,7 +241,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = 0.0;
                 }
-                coherent_store(&resume_i[(size_t)4 * A.ns + sys], HLM_SYS_CAPPED);
+                coherent_store(&resume_i[(size_t)4 * A.ns + sys], HLM_SYS_CAPPED | (G > 1u ? (int)(r + 1u) << STATUS_TAG_SHIFT : 0));
             } else if (valid) {
                 int status = HLM_SYS_OK;
                 bool runs = true;
@@ -255,6 +283,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                     typename Model::Forc FV = Model::prep_forcing(P, held.F);
                     bool have_k0 = false;  // k0 = rhs(t, y, F) is a pure function: recomputed, it has the bits of the carried one
                     double k0[NEQ];
+                    [[maybe_unused]] typename std::conditional<COUNT, LanePathCount, int>::type pc{};
 
                     // ---- the loop of rk45_multi_kernel, piece by piece --------------------------------------------
                     // lanes pause the first time t reaches the end of their piece (the last piece runs to tf) and go on
@@ -273,7 +302,8 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                             ++n_attempt;
                             double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
                             [[maybe_unused]] double err = 0.0, jump = 0.0;
-                            attempt_on_cheapest_path<Model, MATH, FIXED, false>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                            if constexpr (COUNT) attempt_per_lane_path_counted<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump, pc);
+                            else attempt_on_cheapest_path<Model, MATH, FIXED, false>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
                             [[maybe_unused]] double fac = 1.0;
                             if constexpr (!FIXED) {
                                 fac = A.safety * inv_fifth_root<MATH>(err + 1e-16);  // rk45_kernel.cu:151,156
@@ -305,6 +335,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                     }
 
                     HLM_QMARK(2, 4);
+                    if constexpr (COUNT) pc.flush(A.path_counts);
                     if (status == HLM_SYS_OK && t < t_end && n_attempt >= A.cap) status = HLM_SYS_CAPPED;  // attempt cap
                     if (status == HLM_SYS_OK && t < tf) {
                         // paused at the end of its run's last piece: the next run continues exactly here
@@ -317,7 +348,8 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                         coherent_store(&resume_i[(size_t)1 * A.ns + sys], (int)n_attempt);
                         coherent_store(&resume_i[(size_t)2 * A.ns + sys], (int)n_accept);
                     } else {
-                        coherent_store(&resume_i[(size_t)4 * A.ns + sys], status);
+                        // (G > 1: with the run's tag -- the sibling passes of this run still list the hillslope)
+                        coherent_store(&resume_i[(size_t)4 * A.ns + sys], RETILE ? (status | (G > 1u ? (int)(r + 1u) << STATUS_TAG_SHIFT : 0)) : status);
                         if (A.n_attempt) A.n_attempt[sys] = n_attempt;
                         if (A.n_accept) A.n_accept[sys] = n_accept;
                         const bool flagged = status != HLM_SYS_OK && t < tf;  // rk45_kernel.cu:167-170

@@ -36,6 +36,8 @@ class ShardEngine:
         self.queue_group_tiles = int(queue_group_tiles)
         # hlm_device_job.dense_sub_windows: n > 1 = a dense launch (tile layout) as a persistent grid over (sub-window, tile) items
         self.dense_sub_windows = int(dense_sub_windows)
+        # hlm_device_job.d_path_counts (diagnostic): count_paths() allocates the 7 counters and the launches add to them
+        self.path_counts = None
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
         self.ns = y0.shape[0]
         dev = self.device
@@ -116,7 +118,24 @@ class ShardEngine:
         j.dense_sub_windows = self.dense_sub_windows
         if self.dense is not None or self.nq:
             j.time_pieces = 0
+        if self.path_counts is not None:
+            j.d_path_counts = self.path_counts.data_ptr()
         return j
+
+    def count_paths(self, enabled=True):
+        """Route the launches through the counting instance of the queue kernel (hlm_device_job.d_path_counts: FAST,
+        adaptive, time pieces, no dense output) and zero the counters; ``path_shares()`` reads them."""
+        self.path_counts = torch.zeros(_lib.PATH_COUNTERS, dtype=torch.int64, device=self.device) if enabled else None
+
+    def path_shares(self):
+        """dict of the counters as shares of the lane-attempts / wave-attempts they count (see include/hlm_hip.h)."""
+        torch.cuda.synchronize(self.device)
+        n = [int(v) for v in self.path_counts.cpu().numpy()]
+        lanes, waves = max(sum(n[:4]), 1), max(n[5], 1)
+        return {"lane_attempts": sum(n[:4]), "unsaturated_dry_surface_closed_form": n[0] / lanes, "unsaturated_wet_surface_closed_form": n[1] / lanes,
+                "dry_surface_stagewise": n[2] / lanes, "general_rhs": n[3] / lanes, "computed_twice": n[4] / lanes,
+                "wave_attempts": n[5], "wave_attempts_on_several_forms": n[6] / waves,
+                "mean_lanes_per_wave_attempt": sum(n[:4]) / waves}
 
     def integrate(self, stream=None, t_stop=None, resume_in=False, radau=False):
         """Enqueue one pass of the hot path on ``stream`` (default: torch's current stream).

@@ -34,10 +34,22 @@ def uniform(seed, idx, field):
 Y0_204 = (0.01, 3.0, 0.0, 5.0, 0.2)  # main.cpp:376
 
 
-def model204_params(start, count, seed=42, active_surface=False):
+# Capacities at which the static store really saturates DURING the window (``saturating=True``).  SURVEY's
+# "active-surface" draw (hu ~ U[0.005, 0.05], start at h_stat = 3) overflows only in the first minutes: the
+# reference's ET stub (model_204.hpp:96-97: Emax = min(0.1 T, h_stat), loss h_stat / Hu * Emax per minute) empties a
+# static store of that size within the first hour, after which it sits near sqrt(rain * Hu) -- below Hu whenever the
+# rain rate is below Hu.  With the generator's rain rates (1e-4 m/min x Exp(1)) the store therefore overflows in the
+# storms only for capacities of that order: log-uniform over [5e-5, 5e-3] m covers hillslopes that saturate in every
+# storm, in the heavy ones only, and never.
+SATURATING_HU = (5e-5, 5e-3)
+
+
+def model204_params(start, count, seed=42, active_surface=False, saturating=False):
     """SpatialParams for hillslopes [start, start+count): ranges around data/small_test.csv
     (SURVEY 8d C3).  ``active_surface`` draws hu ~ U[0.005, 0.05] so that the static store
-    overflows and the Manning pow() branch is exercised."""
+    overflows and the Manning pow() branch is exercised (in the first minutes of a run that starts at
+    h_stat = 3: see SATURATING_HU); ``saturating`` draws hu log-uniformly over SATURATING_HU, capacities
+    the storms of forcing_tables() fill again and again."""
     idx = np.arange(start, start + count, dtype=np.uint64)
     u = lambda f: uniform(seed, idx, f)
     sp = np.zeros(count, dtype=SP_DTYPE)
@@ -45,6 +57,9 @@ def model204_params(start, count, seed=42, active_surface=False):
     sp["next_stream"] = sp["stream"] + 1
     sp["c1"] = C_1
     sp["Hu"] = (0.005 + 0.045 * u(1)) if active_surface else (50.0 + 250.0 * u(1))
+    if saturating:
+        lo, hi = np.log(SATURATING_HU[0]), np.log(SATURATING_HU[1])
+        sp["Hu"] = np.exp(lo + (hi - lo) * u(1))
     sp["infil"] = 4.0 * C_1
     sp["perco"] = 1.6 * C_1
     sp["n_mann"] = 0.03 + 0.12 * u(2)
@@ -61,12 +76,21 @@ def model204_params(start, count, seed=42, active_surface=False):
     return sp
 
 
-def model204_y0(count, wet_surface=False):
+def model204_y0(count, wet_surface=False, settled_for=None):
     """main.cpp:376 initial state.  ``wet_surface`` starts the surface store at 0.01 m: it
     then drains algebraically and never reaches 0, so the Manning pow() term is evaluated
-    in every stage of every step (the dry default skips it bit-exactly)."""
+    in every stage of every step (the dry default skips it bit-exactly).
+    ``settled_for`` = the hillslopes' SpatialParams: a start that is past the first hour's transient of a small
+    capacity -- no snow, the static store half full (min(3, Hu) / 2), the surface store wet.  From main.cpp:376's
+    state a capacity of millimetres dumps 3 m of water into a dry surface store at the first step of 0.01 min; the
+    reject that follows shrinks the step below (tf - t0) * 1e-6 = 0.043 min of a 30-day window and the hillslope is
+    flagged before t = 1 min (rk45_kernel.cu:160: three quarters of SURVEY's active-surface draw)."""
     y0 = np.tile(np.asarray(Y0_204, dtype=np.float64), (count, 1))
     if wet_surface:
+        y0[:, 2] = 0.01
+    if settled_for is not None:
+        y0[:, 0] = 0.0
+        y0[:, 1] = 0.5 * np.minimum(3.0, settled_for["Hu"])
         y0[:, 2] = 0.01
     return y0
 

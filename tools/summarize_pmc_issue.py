@@ -23,7 +23,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = {"tag": tag, "source": "tools/pmc_issue.sh (rocprofv3 --pmc, two SQ passes per workload, bench.py --steps 3 --warmup 1)",
        "units": "SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles; GRBM_GUI_ACTIVE is summed over the 8 XCDs",
        "workloads": {}}
-for w in ("headline", "wet", "cold", "cold_radau", "cold_radau_continue"):
+for w in ("headline", "wet", "saturating", "active_surface", "cold", "cold_radau", "cold_radau_continue"):
     counters, kname, meta = {}, None, {}
     for p in ("A", "B"):
         files = sorted(glob.glob(os.path.join(src, f"{w}_{p}", "*", "*_counter_collection.csv")), key=os.path.getmtime)   # (gpurun merges the directories of several calls: take the newest)
