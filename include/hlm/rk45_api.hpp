@@ -302,6 +302,59 @@ FinalType run_rk45_sharded(const std::vector<double>& h_y0, double t0, double tf
     return h_final;
 }
 
+// The same with dense output (BASELINE config 5 on the GPUs of a node, hlm_run_rk45_sharded_streamed): every device streams
+// the rows of its shards through its own pinned windows into sink(shard, sys_begin, sys_count, query_begin, query_end,
+// rows[sys_count][W][K]) -- called from one host thread per device (calls of different devices may overlap); no dense
+// rows cross between GPUs, as the reference's ranks each write their own dense file (main.cpp:796-823).
+using ShardWindowSink = std::function<void(int shard, int sys_begin, int sys_count, int query_begin, int query_end, const double* rows)>;
+template <class Model>
+FinalType run_rk45_sharded_streamed(const std::vector<double>& h_y0, double t0, double tf, const std::vector<double>& h_query_times,
+                                    int window_queries, const ShardWindowSink& sink, const typename Model::SP_TYPE* h_sp,
+                                    const std::vector<const float*>& tables, const std::vector<double>& dt_hours,
+                                    const std::vector<size_t>& nT, long long ld, const int32_t* col, int num_shards,
+                                    const std::vector<int>& devices, ShardedStats* stats = nullptr)
+{
+    constexpr int N_EQ = Model::N_EQ;
+    if (dt_hours.size() != nT.size() || tables.size() != nT.size() || nT.size() > HLM_MAX_FORCINGS)
+        throw std::runtime_error("run_rk45_sharded_streamed: forcing tables / dt / nT size mismatch");
+    hlm_sharded_run r{};
+    r.uid = Model::UID;
+    r.num_systems = int(h_y0.size() / N_EQ);
+    r.t0 = t0;
+    r.tf = tf;
+    r.h_y0 = h_y0.data();
+    r.h_sp = h_sp;
+    r.h_forc_tables = tables.empty() ? nullptr : tables.data();
+    for (size_t k = 0; k < nT.size(); ++k) { r.forc_dt_hours[k] = dt_hours[k]; r.forc_nT[k] = nT[k]; }
+    r.nforc = int(nT.size());
+    r.forc_ld = ld;
+    r.h_forc_col = col;
+    struct Ctx { const ShardWindowSink* sink; std::mutex mu; std::exception_ptr error; } ctx{&sink, {}, nullptr};
+    auto tramp = [](void* u, int shard, int s0, int cnt, int qb, int qe, const double* rows) -> int {
+        Ctx* c = static_cast<Ctx*>(u);
+        try {
+            (*c->sink)(shard, s0, cnt, qb, qe, rows);
+            return 0;
+        } catch (...) {   // an exception must not cross the C boundary: kept, rethrown by the caller's thread
+            std::lock_guard<std::mutex> lk(c->mu);
+            if (!c->error) c->error = std::current_exception();
+            return 1;
+        }
+    };
+    FinalType h_final((size_t)r.num_systems * N_EQ);
+    RunInfo info;
+    info.stiff.resize(r.num_systems);
+    info.n_attempt.resize(r.num_systems);
+    info.n_accept.resize(r.num_systems);
+    const int rc = hlm_run_rk45_sharded_streamed(&r, num_shards, devices.empty() ? nullptr : devices.data(), devices.empty() ? 1 : int(devices.size()),
+                                                 h_query_times.data(), int(h_query_times.size()), window_queries, sink ? +tramp : nullptr, &ctx,
+                                                 h_final.data(), info.stiff.data(), info.n_attempt.data(), info.n_accept.data(), stats);
+    if (ctx.error) std::rethrow_exception(ctx.error);
+    detail::check(rc, "run_rk45_sharded_streamed");
+    detail::last_info() = std::move(info);
+    return h_final;
+}
+
 // flags / step counters of the most recent retrieve_and_free on the calling thread
 inline RunInfo last_run_info() { return detail::last_info(); }
 

@@ -470,8 +470,10 @@ typedef struct hlm_sharded_run {
 #define HLM_GATHER_HOST 0 /* every device copies its shards' results to the host itself (no exchange between GPUs) */
 #define HLM_GATHER_RCCL 1 /* RCCL send / recv to devices[0], one copy per array from there */
 
+#define HLM_MAX_SHARD_DEVICES 16 /* devices of one node a sharded run may name (per-device fields of hlm_sharded_stats) */
+
 typedef struct hlm_sharded_stats {
-    double upload_ms;     /* host clock: inputs of all shards enqueued / copied */
+    double upload_ms;     /* host clock: the inputs of all shards in device memory (the slowest device's uploads) */
     double integrate_ms;  /* HIP events around each device's launches: the slowest device */
     double wall_to_integrated_ms; /* host clock: first launch -> all devices finished (includes the communicator's start) */
     double gather_ms;     /* HLM_GATHER_RCCL: the send / recv group on the root's stream (HIP events); else 0 */
@@ -481,7 +483,37 @@ typedef struct hlm_sharded_stats {
     uint64_t gather_bytes; /* bytes that crossed the communicator (incl. the root's own shards) */
     int rccl_version;     /* ncclGetVersion, 0 without RCCL */
     int num_shards, num_devices;
+    /* (ABI 5) */
+    int rccl_nranks;      /* ncclCommCount of the gather's communicator: how many ranks RCCL saw (0 without RCCL) */
+    int upload_mode;      /* HLM_UPLOAD_* the run used */
+    int device_ids[HLM_MAX_SHARD_DEVICES];          /* the HIP devices, in rank order (rank 0 = the gather's root) */
+    double upload_ms_device[HLM_MAX_SHARD_DEVICES];    /* per device: its uploads, first byte to completion */
+    double integrate_ms_device[HLM_MAX_SHARD_DEVICES]; /* per device: HIP events around its launches (streamed: its pipeline's wall time) */
+    uint64_t dense_bytes;    /* hlm_run_rk45_sharded_streamed: bytes of dense rows delivered to the sink, all devices */
+    double dense_kernel_ms;  /* hlm_run_rk45_sharded_streamed: sum of the window kernels over all devices */
 } hlm_sharded_stats;
+
+/* How the inputs reach the devices.  THREADS (default): one host thread per device issues that device's copies, so the
+ * uploads to D devices run side by side (a copy from the caller's pageable arrays occupies the calling thread; one
+ * thread feeding D devices -- SINGLE_THREAD, round 4's path -- uploads to them one after the other).  STAGED_THREADS:
+ * the threads additionally pack the inputs through a pair of pinned buffers each; slower than the runtime's own
+ * pageable copies where those run at the link's rate (measured: 55 GB/s against 27-34 GB/s), selectable for hosts
+ * where they do not. */
+#define HLM_UPLOAD_SINGLE_THREAD 0
+#define HLM_UPLOAD_THREADS 1
+#define HLM_UPLOAD_STAGED_THREADS 2
+int hlm_set_sharded_upload(int mode);
+
+/* The end-of-run gather of hlm_run_rk45_sharded as a LIST (no device is touched): piece k moves `bytes` bytes of
+ * shard `shard`'s result array `array` (0 = y_final, N_EQ doubles per hillslope; 1 = stiff; 2 = n_attempt; 3 = n_accept)
+ * from rank `from_rank` (= shard % num_devices) into the root's gathered array at byte offset `dst_offset_bytes`
+ * (source offset 0: a shard's arrays are its own).  Four pieces per non-empty shard, in shard order; pieces == NULL
+ * only counts.  The run builds its ncclSend / ncclRecv group from exactly this list. */
+typedef struct hlm_gather_piece {
+    int shard, from_rank, array;
+    uint64_t dst_offset_bytes, bytes;
+} hlm_gather_piece;
+int hlm_gather_plan(int num_systems, int num_shards, int num_devices, int neq, hlm_gather_piece* pieces, int* num_pieces);
 
 /* devices == NULL: devices 0 .. num_devices - 1.  The devices must be distinct.  num_shards >= 1 (more shards than
  * devices rehearses a larger node's split on a smaller one).  h_stiff / h_n_attempt / h_n_accept / stats are optional.
@@ -489,6 +521,21 @@ typedef struct hlm_sharded_stats {
 int hlm_run_rk45_sharded(const hlm_sharded_run* run, int num_shards, const int* devices, int num_devices,
                          int gather_mode, double* h_y_final, int32_t* h_stiff, uint32_t* h_n_attempt,
                          uint32_t* h_n_accept, hlm_sharded_stats* stats);
+/* (ABI 5) BASELINE config 5 on the GPUs of a node in one call: hlm_run_rk45_sharded with dense output.  Every device
+ * streams the rows of ITS shards through its own two device windows and two pinned staging buffers
+ * (hlm_rk45_integrate_streamed_sink per shard, one host thread per device) into `sink` -- no gather of dense rows
+ * between GPUs (6.9 TB for config 5); the reference's ranks each write their own dense file (main.cpp:796-823).
+ * sink(user, shard, sys_begin, sys_count, query_begin, query_end, rows): rows = [sys_count][query_end - query_begin][K]
+ * of the hillslopes sys_begin .. sys_begin + sys_count - 1 (K = N_EQ or the registered output selection), valid until
+ * it returns.  It is called from the device's host thread: calls of one device come one after the other, calls of
+ * different devices may overlap.  NULL discards the rows.  Finals, flags and counters arrive in the host arrays by
+ * one copy per shard (HLM_GATHER_HOST).  Rows are bit-identical to the one-launch run of the whole domain. */
+typedef int (*hlm_shard_window_sink)(void* user, int shard, int sys_begin, int sys_count, int query_begin, int query_end,
+                                     const double* h_rows);
+int hlm_run_rk45_sharded_streamed(const hlm_sharded_run* run, int num_shards, const int* devices, int num_devices,
+                                  const double* h_query_times, int num_queries, int window_queries,
+                                  hlm_shard_window_sink sink, void* user, double* h_y_final, int32_t* h_stiff,
+                                  uint32_t* h_n_attempt, uint32_t* h_n_accept, hlm_sharded_stats* stats);
 /* The reference's split rule (main.cpp:275-307 with G shards): first hillslope and length of shard s. */
 int hlm_shard_bounds(int num_systems, int num_shards, int shard, int* start, int* count);
 

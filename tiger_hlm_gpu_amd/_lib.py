@@ -84,7 +84,19 @@ class ShardedStats(C.Structure):
     """hlm_sharded_stats"""
     _fields_ = [("upload_ms", C.c_double), ("integrate_ms", C.c_double), ("wall_to_integrated_ms", C.c_double), ("gather_ms", C.c_double), ("download_ms", C.c_double),
                 ("comm_init_ms", C.c_double), ("gather_bytes", C.c_uint64), ("rccl_version", C.c_int), ("num_shards", C.c_int),
-                ("num_devices", C.c_int)]
+                ("num_devices", C.c_int), ("rccl_nranks", C.c_int), ("upload_mode", C.c_int), ("device_ids", C.c_int * 16),
+                ("upload_ms_device", C.c_double * 16), ("integrate_ms_device", C.c_double * 16), ("dense_bytes", C.c_uint64),
+                ("dense_kernel_ms", C.c_double)]
+
+
+class GatherPiece(C.Structure):
+    """hlm_gather_piece"""
+    _fields_ = [("shard", C.c_int), ("from_rank", C.c_int), ("array", C.c_int), ("dst_offset_bytes", C.c_uint64), ("bytes", C.c_uint64)]
+
+
+UPLOAD_SINGLE_THREAD, UPLOAD_THREADS, UPLOAD_STAGED_THREADS = 0, 1, 2
+# hlm_shard_window_sink: int (*)(void* user, int shard, int sys_begin, int sys_count, int query_begin, int query_end, const double* h_rows)
+SHARD_WINDOW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double))
 
 
 GATHER_HOST, GATHER_RCCL = 0, 1
@@ -153,6 +165,10 @@ SIGNATURES = {
     "hlm_run_rk45_sharded": (C.c_int, [C.POINTER(ShardedRun), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_int, C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_void_p, C.POINTER(ShardedStats)]),
     "hlm_shard_bounds": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "hlm_gather_plan": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(GatherPiece), C.POINTER(C.c_int)]),
+    "hlm_set_sharded_upload": (C.c_int, [C.c_int]),
+    "hlm_run_rk45_sharded_streamed": (C.c_int, [C.POINTER(ShardedRun), C.c_int, C.POINTER(C.c_int), C.c_int, C.c_void_p, C.c_int, C.c_int,
+                                                C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(ShardedStats)]),
     "hlm_kernel_info": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int),
                                   C.POINTER(C.c_int), C.POINTER(C.c_int)]),
 }

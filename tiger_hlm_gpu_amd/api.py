@@ -452,6 +452,98 @@ def shard_bounds(num_systems, num_shards, shard):
     return a.value, b.value
 
 
+def gather_plan(num_systems, num_shards, num_devices, neq=_lib.HLM_NEQ):
+    """hlm_gather_plan: the end-of-run gather of hlm_run_rk45_sharded as a list of dicts (shard, from_rank, array,
+    dst_offset_bytes, bytes) -- no device is touched."""
+    n = C.c_int(0)
+    check(lib().hlm_gather_plan(int(num_systems), int(num_shards), int(num_devices), int(neq), None, C.byref(n)))
+    arr = (_lib.GatherPiece * max(n.value, 1))()
+    check(lib().hlm_gather_plan(int(num_systems), int(num_shards), int(num_devices), int(neq), arr, C.byref(n)))
+    return [{f: getattr(arr[k], f) for f, _ in _lib.GatherPiece._fields_} for k in range(n.value)]
+
+
+def set_sharded_upload(mode):
+    """hlm_set_sharded_upload: "threads" (default: one host thread per device issues its copies), "single" (round 4's
+    path: one thread for all devices) or "staged" (threads packing through a pair of pinned buffers each)."""
+    check(lib().hlm_set_sharded_upload({"single": _lib.UPLOAD_SINGLE_THREAD, "threads": _lib.UPLOAD_THREADS, "staged": _lib.UPLOAD_STAGED_THREADS}[mode]))
+
+
+def _sharded_stats(st):
+    d = {f: getattr(st, f) for f, _ in _lib.ShardedStats._fields_}
+    nd = st.num_devices
+    for k in ("device_ids", "upload_ms_device", "integrate_ms_device"):
+        d[k] = [d[k][i] for i in range(nd)]
+    return d
+
+
+def _sharded_run_struct(model, y0, t0, tf, sp, tables, dt_hours, cells, devices, num_devices):
+    uid, neq = _uid(model), model.N_EQ
+    y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, neq)
+    ns = y0.shape[0]
+    r = _lib.ShardedRun()
+    r.uid, r.num_systems, r.t0, r.tf = uid, ns, float(t0), float(tf)
+    r.h_y0 = _ptr(y0)
+    keep = [y0]
+    if sp is not None:
+        sp = np.ascontiguousarray(sp, dtype=SP_DTYPE)
+        assert sp.shape == (ns,)
+        r.h_sp = _ptr(sp)
+        keep.append(sp)
+    tabs = [np.ascontiguousarray(t, dtype=np.float32) for t in tables]
+    if tabs:
+        ptrs = (C.c_void_p * len(tabs))(*[t.ctypes.data for t in tabs])
+        r.h_forc_tables = C.cast(ptrs, C.POINTER(C.c_void_p))
+        r.nforc, r.forc_ld = len(tabs), int(tabs[0].shape[1])
+        for k, t in enumerate(tabs):
+            assert t.shape[1] == r.forc_ld
+            r.forc_dt_hours[k], r.forc_nT[k] = float(dt_hours[k]), int(t.shape[0])
+        keep += [tabs, ptrs]
+    if cells is not None:
+        cells = np.ascontiguousarray(cells, dtype=np.int32)
+        assert cells.shape == (ns,)
+        r.h_forc_col = _ptr(cells)
+        keep.append(cells)
+    if devices is None:
+        nd, dev_arr = int(num_devices if num_devices is not None else 1), None
+    else:
+        nd = len(devices)
+        dev_arr = (C.c_int * nd)(*[int(d) for d in devices])
+    return r, keep, ns, neq, nd, dev_arr
+
+
+def run_rk45_sharded_streamed(model, y0, t0, tf, query, window_queries, sp=None, tables=(), dt_hours=(), cells=None, num_shards=1,
+                              devices=None, num_devices=None, sink=None):
+    """hlm_run_rk45_sharded_streamed: BASELINE config 5 on the GPUs of a node in one call -- every device streams the dense
+    rows of its shards through its own pinned windows into ``sink(shard, sys_begin, sys_count, query_begin, query_end,
+    rows[sys_count, W, K])`` (called from the device's host thread; None discards).  Returns (results dict, stats dict)."""
+    r, keep, ns, neq, nd, dev_arr = _sharded_run_struct(model, y0, t0, tf, sp, tables, dt_hours, cells, devices, num_devices)
+    q = np.ascontiguousarray(query, dtype=np.float64)
+    errors = []
+
+    def trampoline(_user, shard, s0, cnt, qb, qe, ptr):
+        try:
+            if sink is not None:
+                k = neq   # (output selection: the registered one; rows are [cnt][qe - qb][K])
+                rows = np.ctypeslib.as_array(ptr, shape=(cnt * (qe - qb) * k,)).reshape(cnt, qe - qb, k)
+                sink(shard, s0, cnt, qb, qe, rows)
+            return 0
+        except Exception as e:  # noqa: BLE001 -- an exception must not cross the C boundary
+            errors.append(e)
+            return 1
+    cb = _lib.SHARD_WINDOW_SINK(trampoline)
+    yf = np.empty((ns, neq))
+    stiff = np.empty(ns, dtype=np.int32)
+    na, nacc = np.empty(ns, dtype=np.uint32), np.empty(ns, dtype=np.uint32)
+    st = _lib.ShardedStats()
+    rc = lib().hlm_run_rk45_sharded_streamed(C.byref(r), int(num_shards), dev_arr, nd, _ptr(q), int(q.shape[0]), int(window_queries),
+                                             C.cast(cb, C.c_void_p), None, _ptr(yf), _ptr(stiff), _ptr(na), _ptr(nacc), C.byref(st))
+    if errors:
+        raise errors[0]
+    check(rc)
+    del keep
+    return {"y_final": yf, "stiff": stiff, "n_attempt": na, "n_accept": nacc}, _sharded_stats(st)
+
+
 def run_rk45_sharded(model, y0, t0, tf, sp=None, tables=(), dt_hours=(), cells=None, num_shards=1, devices=None,
                      num_devices=None, gather="rccl"):
     """hlm_run_rk45_sharded: the whole domain from host arrays, split by the reference's rule over ``num_shards`` shards
@@ -496,5 +588,4 @@ def run_rk45_sharded(model, y0, t0, tf, sp=None, tables=(), dt_hours=(), cells=N
     mode = {"rccl": _lib.GATHER_RCCL, "host": _lib.GATHER_HOST}[gather]
     check(lib().hlm_run_rk45_sharded(C.byref(r), int(num_shards), dev_arr, nd, mode, _ptr(yf), _ptr(stiff), _ptr(na), _ptr(nacc), C.byref(st)))
     del keep
-    stats = {f: getattr(st, f) for f, _ in _lib.ShardedStats._fields_}
-    return {"y_final": yf, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "dense": None}, stats
+    return {"y_final": yf, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "dense": None}, _sharded_stats(st)

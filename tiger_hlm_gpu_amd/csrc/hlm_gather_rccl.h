@@ -32,6 +32,7 @@ struct RcclApi {
     decltype(&ncclRecv) Recv = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
     decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclCommCount) CommCount = nullptr;
     void* handle = nullptr;
     std::string error;
 };
@@ -61,6 +62,7 @@ inline const RcclApi* rccl_api(std::string* why)
         api.Recv = reinterpret_cast<decltype(api.Recv)>(sym("ncclRecv"));
         api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
         api.GetVersion = reinterpret_cast<decltype(api.GetVersion)>(sym("ncclGetVersion"));
+        api.CommCount = reinterpret_cast<decltype(api.CommCount)>(sym("ncclCommCount"));
         if (!api.CommInitAll || !api.CommDestroy || !api.GroupStart || !api.GroupEnd || !api.Send || !api.Recv || !api.GetErrorString) {
             dlclose(api.handle);
             api.handle = nullptr;
@@ -133,6 +135,14 @@ public:
         int v = 0;
         if (api_ && api_->GetVersion) (void)api_->GetVersion(&v);
         return v;
+    }
+
+    // ranks of the communicator as RCCL counts them (ncclCommCount on the root's handle); 0 if it cannot say
+    int nranks() const
+    {
+        int n = 0;
+        if (api_ && api_->CommCount && !comms_.empty() && api_->CommCount(comms_[0], &n) != ncclSuccess) n = 0;
+        return n;
     }
 
     void destroy()

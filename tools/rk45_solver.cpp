@@ -538,8 +538,10 @@ int run(const Options& o, hlm_io::CsvStyle style)
     if (o.gather == "rccl" || o.gather == "host") {
         // One host thread, all devices: the reference's rank-0 split (main.cpp:275-307) inside the library and the
         // end-of-run gather over RCCL (hlm_run_rk45_sharded) -- final states, flags and step counters only.
-        if (nq > 0 || o.radau || o.stream_forcings > 0 || stream_dense)
-            usage("--gather rccl|host gathers final states only: needs --nq 0 and none of --radau / --stream-forcings / --stream-dense");
+        // (dense output: --gather host -- every device streams the rows of its shards to the host through its own pinned
+        // windows, hlm_run_rk45_sharded_streamed; nothing is gathered between the GPUs)
+        if ((nq > 0 && o.gather == "rccl") || o.radau || o.stream_forcings > 0 || stream_dense)
+            usage("--gather rccl gathers final states only: needs --nq 0 (dense output: --gather host) and none of --radau / --stream-forcings / --stream-dense");
         const int nd = std::min(G, std::max(ndev, 1));
         std::vector<int> devices((size_t)nd);
         for (int i = 0; i < nd; ++i) devices[(size_t)i] = (o.device + i) % std::max(ndev, 1);
@@ -563,6 +565,17 @@ int run(const Options& o, hlm_io::CsvStyle style)
             for (size_t n : fb.nT) { tables.push_back(base + row * (size_t)ld); row += n; }
         }
         rk45_api::ShardedStats st;
+        if (nq > 0) {
+            const int W = (int)std::min<size_t>(nq, 256);
+            h_y_final = rk45_api::run_rk45_sharded_streamed<Model>(
+                h_y0, t0, tf, h_query_times, W,
+                [&](int, int s0, int cnt, int qb, int qe, const double* rows) {   // (disjoint hillslopes per shard: no lock needed)
+                    for (int s = 0; s < cnt; ++s)
+                        std::copy(rows + (size_t)s * (qe - qb) * width, rows + (size_t)(s + 1) * (qe - qb) * width,
+                                  h_dense.begin() + ((size_t)(s0 + s) * nq + (size_t)qb) * width);
+                },
+                spatial.data(), tables, fb.dt_hours, fb.nT, ld, fb.nT.empty() ? nullptr : col, G, devices, &st);
+        } else
         h_y_final = rk45_api::run_rk45_sharded<Model>(h_y0, t0, tf, spatial.data(), tables, fb.dt_hours, fb.nT, ld, fb.nT.empty() ? nullptr : col,
                                                       G, devices, o.gather == "rccl", &st);
         const rk45_api::RunInfo info = rk45_api::last_run_info();
@@ -571,10 +584,10 @@ int run(const Options& o, hlm_io::CsvStyle style)
         t_h2d[0] = st.upload_ms * 1e-3;
         t_integrate[0] = st.integrate_ms * 1e-3;
         t_d2h[0] = (st.gather_ms + st.download_ms) * 1e-3;
-        char buf[256];
+        char buf[384];
         std::snprintf(buf, sizeof(buf), "{\"mode\": \"%s\", \"devices\": %d, \"shards\": %d, \"gather_ms\": %.4f, \"gather_bytes\": %llu, "
-                      "\"comm_init_ms\": %.3f, \"rccl_version\": %d}", o.gather.c_str(), st.num_devices, st.num_shards, st.gather_ms,
-                      (unsigned long long)st.gather_bytes, st.comm_init_ms, st.rccl_version);
+                      "\"comm_init_ms\": %.3f, \"rccl_version\": %d, \"rccl_nranks\": %d, \"upload_mode\": %d, \"dense_bytes\": %llu}", o.gather.c_str(), st.num_devices, st.num_shards, st.gather_ms,
+                      (unsigned long long)st.gather_bytes, st.comm_init_ms, st.rccl_version, st.rccl_nranks, st.upload_mode, (unsigned long long)st.dense_bytes);
         gather_note = buf;
     } else if (o.gather != "threads") {
         usage("--gather must be threads, rccl or host");
