@@ -81,8 +81,8 @@ def parse():
     ap.add_argument("--layout", choices=["per-stream", "per-cell"], default="per-stream")
     ap.add_argument("--dense-stride", type=float, default=0.0,
                     help="minutes between dense queries (0 = no dense output)")
-    ap.add_argument("--dense-tiled", type=int, nargs="?", const=1, default=0,
-                    help="with --dense-stride: device layout of the in-HBM dense buffer (0 host order, 1 tile-row, "
+    ap.add_argument("--dense-tiled", type=int, nargs="?", const=2, default=0, choices=[0, 2],
+                    help="with --dense-stride: device layout of the in-HBM dense buffer (0 host order, "
                          "2 tile-comp with wave-synchronous stores)")
     ap.add_argument("--wet-surface", action="store_true",
                     help="headline pass on the wet-surface regime (y0[2] = 0.01: the Manning x^(2/3) term in all 7 stages)")
@@ -93,8 +93,6 @@ def parse():
     ap.add_argument("--attempt-cap", type=int, default=0, help="attempts per hillslope at most (0 = the library's 2^24)")
     ap.add_argument("--tmin", type=float, default=0.5,
                     help="lower end of the daily temperatures; -5 is SURVEY 8d's C3 generator (cold cells get flagged stiff)")
-    ap.add_argument("--compact-minutes", type=float, default=0.0,
-                    help="> 0: the pass in launches of this many minutes with the surviving hillslopes compacted between them")
     ap.add_argument("--time-pieces", type=int, default=-1,
                     help="launch shape of the pass without dense output (hlm_device_job.time_pieces): > 1 = persistent grid "
                          "over (time piece, tile) items, 0 = one wave per tile (the reference's map), -1 = the library's automatic rule")
@@ -102,8 +100,6 @@ def parse():
                     help="hlm_device_job.queue_run_pieces: 0 automatic runs of pieces per queue item, 1 every piece handed over")
     ap.add_argument("--group-tiles", type=int, default=0,
                     help="hlm_device_job.queue_group_tiles: G > 1 = the survivors of G neighbouring tiles packed into full waves, piece by piece")
-    ap.add_argument("--lane-refill", action="store_true",
-                    help="persistent grid with lane refill (a lane whose hillslope is finished or flagged takes the next one)")
     ap.add_argument("--radau", action="store_true", help="follow every pass with the Radau-IIA fallback over the flagged hillslopes")
     ap.add_argument("--radau-continue", action="store_true",
                     help="with --radau: the flagged hillslopes continue from the state RK45 reached instead of restarting at t0")
@@ -156,7 +152,7 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
     eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q,
                       math_mode=H.MATH_FAST if (math or args.math) == "fast" else H.MATH_STRICT,
                       device=f"cuda:{torch.cuda.current_device()}", dense_tiled=args.dense_tiled,
-                      lane_refill=args.lane_refill, time_pieces=None if args.time_pieces < 0 else args.time_pieces, attempt_cap=args.attempt_cap,
+                      time_pieces=None if args.time_pieces < 0 else args.time_pieces, attempt_cap=args.attempt_cap,
                       queue_run_pieces=args.queue_run_pieces, queue_group_tiles=args.group_tiles)
     if args.layout == "per-stream":
         eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
@@ -196,7 +192,7 @@ def _issue_fields(per_gpu_key):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    extra = (f";compact={args.compact_minutes:g}" if args.compact_minutes > 0 else "") + (";refill" if args.lane_refill else "") + (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (f";runs={args.queue_run_pieces}" if args.queue_run_pieces else "") + (f";group={args.group_tiles}" if args.group_tiles else "") + (";wet" if args.wet_surface else "") + (f";hu={args.hu}" if args.hu != "default" else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
+    extra = (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (f";runs={args.queue_run_pieces}" if args.queue_run_pieces else "") + (f";group={args.group_tiles}" if args.group_tiles else "") + (";wet" if args.wet_surface else "") + (f";hu={args.hu}" if args.hu != "default" else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
     return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
@@ -848,8 +844,6 @@ def main():
     if args.radau:
         plain = eng.integrate
         eng.integrate = lambda: plain(radau="continue" if args.radau_continue else True)
-    elif args.compact_minutes > 0:
-        eng.integrate = lambda: eng.integrate_compacting(args.compact_minutes)
     wall, kernel_ms, gather_ms = timed_passes(eng, total, world, args.warmup, args.steps)
     cdev = _coll_device(eng.device) if grouped else eng.device
     attempts = torch.tensor([eng.total_attempts()], dtype=torch.float64, device=cdev)
@@ -908,11 +902,9 @@ def main():
                 % ("C3" if args.scaling == "weak" else "C4 (strong scaling, reference split rule)",
                    eng.ns, total, args.days, args.layout,
                    "no dense output" if nq == 0 else f"dense every {args.dense_stride} min (nq={nq})", args.math)
-                + (f", launches of {args.compact_minutes:g} min with compaction" if args.compact_minutes > 0 else "")
-                + (", lane refill" if args.lane_refill else "") + (f", {pieces} time pieces" if pieces else "") + (", WET surface store" if args.wet_surface else "") + (f", capacities: {args.hu}" if args.hu != "default" else "") + (f", T in [{args.tmin:g}, 15]" if args.tmin != 0.5 else "")
+                + (f", {pieces} time pieces" if pieces else "") + (", WET surface store" if args.wet_surface else "") + (f", capacities: {args.hu}" if args.hu != "default" else "") + (f", T in [{args.tmin:g}, 15]" if args.tmin != 0.5 else "")
                 + (", + Radau-IIA fallback" if args.radau else ""))
-    kernel_name = ("hlm::rk45_refill_kernel<Model204Dev>" if args.lane_refill and nq == 0 else
-                   "hlm::rk45_queue_kernel<Model204Dev>" if pieces else "hlm::rk45_multi_kernel<Model204Dev>")
+    kernel_name = "hlm::rk45_queue_kernel<Model204Dev>" if pieces else "hlm::rk45_multi_kernel<Model204Dev>"
     # HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/); only quoted
     # when they were collected on this same per-GPU workload
     traffic, traffic_source = None, None
@@ -1154,18 +1146,6 @@ def main():
             ca = copy.copy(args)
             ca.tmin, ca.group_tiles = -5.0, 8
             res["rk45"].update(_issue_fields(_per_gpu_key(ca, 0, e.ns)))   # active lanes per VALU instruction of the RK45 pass etc.
-            if not H.api.has_experimental_paths():   # (compaction between launches is a quarantined path: EXPERIMENTAL=1 builds)
-                return res
-            # the same RK45 pass in one-day launches with the survivors compacted between them (bit-identical)
-            e.integrate_compacting(1440.0)
-            torch.cuda.synchronize()
-            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            a.record()
-            nl = e.integrate_compacting(1440.0)
-            b.record()
-            torch.cuda.synchronize()
-            res["rk45_compacting"] = {"ms": a.elapsed_time(b), "launches": nl, "interval_minutes": 1440.0,
-                                      "steps_per_s": res["rk45"]["attempts"] / (a.elapsed_time(b) * 1e-3)}
             return res
         out["variant_survey_c3_cold_cells"] = _optional(_cold)
         torch.cuda.empty_cache()

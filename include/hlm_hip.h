@@ -81,13 +81,6 @@ typedef struct hlm_spatial_params {
 
 /* ---- library / device ------------------------------------------------------------ */
 int hlm_abi_version(void);
-/* Bit mask of optional parts compiled into this library.  HLM_BUILD_EXPERIMENTAL_PATHS: the launch paths that lost on
- * every workload measured so far and are quarantined by default (make -C tiger_hlm_gpu_amd/csrc EXPERIMENTAL=1):
- * lane refill (hlm_set_lane_refill / hlm_device_job.lane_refill), compaction between launches
- * (hlm_rk45_integrate_compacting), the tile-row dense layout (dense_tiled = 1, hlm_set_stream_path(1)).  Without the
- * bit those entry points return HLM_ERR_INVALID_ARGUMENT. */
-#define HLM_BUILD_EXPERIMENTAL_PATHS 1
-int hlm_build_flags(void);
 const char* hlm_last_error(void);
 int hlm_device_count(int* count);
 int hlm_set_device(int device); /* main.cpp:314-319 cudaSetDevice */
@@ -110,8 +103,6 @@ int hlm_get_model_parameters(int uid, double p[6]);
 int hlm_set_fixed_step(int uid, double h);
 int hlm_set_attempt_cap(uint32_t cap);
 int hlm_set_math_mode(int mode);
-/* 1: the host API's launches without dense output use lane refill (hlm_device_job.lane_refill). */
-int hlm_set_lane_refill(int enabled);
 /* hlm_device_job.time_pieces of the host API's launches without dense output: 0 / 1 = one wave per tile; negative
  * (the default) = automatic: from 4 096 hillslopes on, one piece per twelve simulated hours, at most 32, none
  * when that makes fewer than 8 (a 4-day window is the shortest that is cut). */
@@ -243,11 +234,11 @@ typedef struct hlm_device_job {
     /* Device layout of d_dense (W = window length, nq when no window):
      * 0: [ns][W][5], the host-facing order (free-running kernel, hlm_rk45_kernel.h: every lane stores its
      *    rows when it has them; 1.6x write amplification at 1-minute stride);
-     * 1: tile-major [ceil(ns/64)][W][64][5], same kernel;
      * 2: tile-major [ceil(ns/64)][W][5][64], written by the kernel with wave-synchronous stores
      *    (hlm_rk45_dense_kernel.h): every store instruction writes 512 contiguous bytes, HBM write traffic
      *    equals the algorithmic 40 B per row.  What the host API and hlm_rk45_integrate_streamed's
-     *    transfer-kernel path use; a caller using 1 or 2 transposes itself. */
+     *    transfer-kernel path use; a caller using it transposes itself.
+     * (1, tile-major [ceil(ns/64)][W][64][5], lost on every workload of rounds 1-4 and is refused since ABI 5.) */
     int dense_tiled;
     /* Time chunks / checkpoints (build feature).  use_t_stop != 0: every hillslope pauses the
      * first time its t reaches t_stop (before its next attempt; needs d_resume) and continues in
@@ -261,13 +252,6 @@ typedef struct hlm_device_job {
     double t_stop;
     uint64_t forc_first_index[HLM_MAX_FORCINGS];
     uint64_t forc_rows[HLM_MAX_FORCINGS];
-    /* 1: lane refill (build feature; hlm_rk45_refill_kernel.h).  A persistent grid in which a lane whose
-     * hillslope is finished or flagged takes the next one from a device queue instead of idling until the
-     * slowest hillslope of its wave is through (the reference's one-system-per-thread map,
-     * rk45_kernel.cu:33).  Bit-identical results; pays when trip counts within a wave differ (cold cells
-     * flagged early next to hillslopes that run 30 days).  Used for launches without dense output and
-     * without resume state; ignored otherwise. */
-    int lane_refill;
     /* Output selection (ABI 3; see hlm_set_output_states): dense_ncomp = K > 0 makes every dense row K doubles
      * wide, holding components dense_comp[0..K) (ascending, distinct, < N_EQ) -- d_dense is [ns][W][K],
      * [tiles][W][64][K] or [tiles][W][K][64] by dense_tiled; hlm_rk45_integrate_streamed then fills
@@ -406,20 +390,11 @@ int hlm_run_rk45_streamed(int uid, const double* h_y0, int num_systems, double t
 int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* const* h_tables,
                                         double chunk_minutes, void* hip_stream, int* chunks);
 
-/* The integration cut into launches of interval_minutes with the systems still integrating COMPACTED between
- * them (build feature; SURVEY 7 step 5a "keep divergent adaptive steppers converged").  A hillslope that is
- * flagged stiff after a few hundred attempts leaves its lane idle until the slowest hillslope of its wave is
- * through; here every launch but the first runs only the survivors of the one before, in their original order
- * (so that the lanes of a wave still share a forcing cell and the model's cheap RHS variants keep applying --
- * which in-kernel lane refill, hlm_device_job.lane_refill, loses).  Lanes pause at the interval ends exactly as
- * with t_stop: results are bit-identical to hlm_rk45_integrate_device.  For jobs without dense output.
- * Asynchronous on hip_stream like hlm_rk45_integrate_device.  *launches (nullable): RK45 launches made. */
-int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_minutes, void* hip_stream, int* launches);
-
 /* Transfer path of hlm_rk45_integrate_streamed.  0 (default): linear device windows +
- * hipMemcpy2DAsync on the copy engine (fastest end to end: 54.8 GB/s measured).  1: tile-major
- * device windows (coalesced kernel stores) + a transposing kernel that writes pinned host
- * memory directly (51.5 GB/s; falls back to path 0 when h_dense is not pinned). */
+ * hipMemcpy2DAsync on the copy engine (fastest end to end: 54.8 GB/s measured).  2: tile-major
+ * device windows (the layout of dense_tiled = 2, coalesced kernel stores) + a transposing kernel that writes
+ * pinned host memory directly (51.5 GB/s; falls back to path 0 when h_dense is not pinned).  (1 was the tile-row
+ * layout of rounds 1-4, removed in ABI 5.) */
 int hlm_set_stream_path(int path);
 int hlm_host_alloc_pinned(void** hptr, size_t bytes);
 int hlm_host_free_pinned(void* hptr);

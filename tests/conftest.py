@@ -33,14 +33,6 @@ def hlm():
     return H
 
 
-def need_experimental_paths(H):
-    """Skip unless the library carries the quarantined launch paths (lane refill, compaction between launches, the
-    tile-row dense layout): they lost on every workload measured in rounds 2-4 and are built only with
-    `make -C tiger_hlm_gpu_amd/csrc EXPERIMENTAL=1` (hlm_build_flags)."""
-    if not H.api.has_experimental_paths():
-        pytest.skip("quarantined path: library built without HLM_EXPERIMENTAL_PATHS")
-
-
 @pytest.fixture(scope="session")
 def golden():
     g = {}

@@ -19,7 +19,7 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 52
+    assert len(names) == 49
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
@@ -55,7 +55,7 @@ def test_struct_layouts_match_header(hlm, tmp_path):
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
-    assert len(hlm._lib.DeviceJob._fields_) == 41 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
+    assert len(hlm._lib.DeviceJob._fields_) == 40 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
 
 
 def test_registry_roundtrip_and_validation_without_gpu(hlm):
@@ -370,9 +370,9 @@ def test_model_info_and_toy_model_host_side(hlm, oracle):
 
 
 def test_piece_count_of_chunked_launches_is_bounded(hlm):
-    """hlm_rk45_integrate_compacting / _forcing_streamed cut [t0, tf] into pieces t0 + k * step: a step below the
-    ulp of t (which repeated addition would never get past) or one that asks for millions of launches is an
-    argument error, raised before anything touches a device (round-2 advisor finding)."""
+    """hlm_rk45_integrate_forcing_streamed cuts [t0, tf] into pieces t0 + k * step: a step below the ulp of t (which
+    repeated addition would never get past) or one that asks for millions of launches is an argument error, raised
+    before anything touches a device (round-2 advisor finding)."""
     L = hlm._lib.lib()
     j = hlm._lib.DeviceJob()
     j.uid, j.num_systems, j.num_queries, j.t0, j.tf = hlm.UID_DUMMY, 64, 0, 0.0, 43200.0
@@ -380,12 +380,6 @@ def test_piece_count_of_chunked_launches_is_bounded(hlm):
     for k, v in enumerate((0.01, 1e-6, 1e-9, 0.9, 0.2, 10.0)):
         j.params[k] = v
     j.math_mode = hlm.MATH_FAST
-    n = C.c_int(-1)
-    for step in (1e-30, 1e-3):
-        rc = L.hlm_rk45_integrate_compacting(C.byref(j), step, None, C.byref(n))
-        # (a quarantined entry point in the default build: refused as a whole, hlm_build_flags)
-        want = b"pieces" if hlm.api.has_experimental_paths() else b"HLM_EXPERIMENTAL_PATHS"
-        assert rc == 1 and want in L.hlm_last_error(), (step, rc, L.hlm_last_error())
     j.uid, j.nforc, j.forc_ld = hlm.UID_204, 1, 64
     j.d_sp = 4096
     j.forc_dt_hours[0], j.forc_nT[0] = 1.0, 720

@@ -45,11 +45,8 @@ def _engine(H, case, days, **kw):
 
 
 @pytest.mark.parametrize("math_mode", [0, 1])
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 2])
 def test_selected_rows_in_every_device_layout_vs_oracle_and_vs_the_full_run(gpu, oracle, layout, math_mode):
-    if layout == 1:
-        from conftest import need_experimental_paths
-        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     days = 2
@@ -76,12 +73,9 @@ def test_selected_rows_in_every_device_layout_vs_oracle_and_vs_the_full_run(gpu,
     assert np.array_equal(eng.results()["dense"], full["dense"])
 
 
-@pytest.mark.parametrize("path", ["copy-engine", "transfer-kernel", "transfer-kernel-tile-row", "pageable"])
+@pytest.mark.parametrize("path", ["copy-engine", "transfer-kernel", "pageable"])
 @pytest.mark.parametrize("window", [1, 37, 1000])
 def test_selected_rows_streamed_in_windows_equal_one_shot(gpu, window, path):
-    if path == "transfer-kernel-tile-row":
-        from conftest import need_experimental_paths
-        need_experimental_paths(gpu)
     H = gpu
     days = 2
     case = _case(H, ns=300, days=days)
@@ -91,7 +85,7 @@ def test_selected_rows_streamed_in_windows_equal_one_shot(gpu, window, path):
     one = full.results()
     for sel in ((2,), (0, 3), (0, 1, 3, 4)):
         eng = _engine(H, case, days, dense_states=sel)
-        H._lib.lib().hlm_set_stream_path({"transfer-kernel": 2, "transfer-kernel-tile-row": 1}.get(path, 0))
+        H._lib.lib().hlm_set_stream_path({"transfer-kernel": 2}.get(path, 0))
         try:
             host_out = np.full((300, len(q), len(sel)), np.nan) if path == "pageable" else None
             host, stats = eng.integrate_streamed(window, host_out=host_out)
@@ -320,14 +314,11 @@ def test_host_api_streamed_run_and_the_driver_stream_dense(gpu, golden, tmp_path
     assert blobs["streamed"] == blobs["whole"] and blobs["streamed_sel"] == blobs["whole_sel"]
 
 
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 2])
 def test_selection_on_the_three_state_model(gpu, layout):
     """The selecting kernels are templates over Model::N_EQ like everything else: ToyModel3 (N_EQ = 3, one forcing),
     every proper subset, all layouts and the Radau pass on its general (pivoted LU) route -- the selected columns of
     the full run, bit for bit."""
-    if layout == 1:
-        from conftest import need_experimental_paths
-        need_experimental_paths(gpu)
     H = gpu
     from test_parity_gpu import _toy_case
     from tiger_hlm_gpu_amd import synth

@@ -242,12 +242,11 @@ def test_three_phase_api_equals_run_rk45(gpu):
     assert np.array_equal(f1, f2) and np.array_equal(d1, d2)
 
 
-def test_host_api_defaults_fast_math_with_automatic_strict_and_lane_refill_switch(gpu, tmp_path):
+def test_host_api_defaults_fast_math_with_automatic_strict(gpu, tmp_path):
     """A reference-style run_rk45<Model204> call with no extra knobs runs the FAST kernels (the headline
     arithmetic); with tolerances FAST cannot take (atol = 0: its error norm multiplies the five
     tolerances) the library switches to STRICT by itself instead of failing -- as long as the caller has
-    not chosen a mode.  Run in a fresh process: the choice is process-global.  Also: hlm_set_lane_refill
-    changes which lane integrates which hillslope, nothing else."""
+    not chosen a mode.  Run in a fresh process: the choice is process-global."""
     import subprocess
     import sys
     from conftest import ROOT
@@ -274,17 +273,6 @@ def engine(mode, atol):
 # default parameters, no mode chosen: the FAST kernel's bits
 a = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5)
 assert np.array_equal(a, engine(H.MATH_FAST, 1e-9)) and not np.array_equal(a, engine(H.MATH_STRICT, 1e-9))
-# lane refill through the host API (a quarantined path: only in EXPERIMENTAL=1 builds): same bits -- else refused
-if H.api.has_experimental_paths():
-    H.api.set_lane_refill(True)
-    assert np.array_equal(H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5), a)
-    H.api.set_lane_refill(False)
-else:
-    try:
-        H.api.set_lane_refill(True)
-        raise SystemExit("expected a refusal")
-    except H.HlmError as e:
-        assert "HLM_EXPERIMENTAL_PATHS" in str(e)
 # atol = 0: still no mode chosen -> STRICT by itself
 H.api.set_model_parameters(H.Model204, H.Parameters(0.01, 1e-6, 0.0, 0.9, 0.2, 10.0))
 b = H.api.run_rk45(H.Model204, y0, 0.0, days * 1440.0, None, d_sp)[0].reshape(ns, 5)
@@ -677,15 +665,12 @@ def test_cpp_driver_time_pieces_same_final_csv(gpu, tmp_path):
 
 
 # ---- dense output in query windows (BASELINE config 5) ------------------------------------------
-@pytest.mark.parametrize("path", ["transfer-kernel", "transfer-kernel-tile-row", "copy-engine", "pageable"])
+@pytest.mark.parametrize("path", ["transfer-kernel", "copy-engine", "pageable"])
 @pytest.mark.parametrize("window", [1, 7, 48, 1000])
 def test_streamed_dense_equals_one_shot_bitwise(gpu, window, path):
     """The windowed run pauses a lane before it commits a step whose queries cross the
     window end and redoes that attempt in the next launch, so finals, flags, counters and
     every dense value equal the one-shot run bit for bit, for any window size."""
-    if path == "transfer-kernel-tile-row":
-        from conftest import need_experimental_paths
-        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     ns, days = 300, 2
@@ -696,7 +681,7 @@ def test_streamed_dense_equals_one_shot_bitwise(gpu, window, path):
     eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     eng.integrate()
     one = eng.results()
-    H._lib.lib().hlm_set_stream_path({"transfer-kernel": 2, "transfer-kernel-tile-row": 1}.get(path, 0))
+    H._lib.lib().hlm_set_stream_path({"transfer-kernel": 2}.get(path, 0))
     try:
         host_out = np.full((ns, len(q), 5), np.nan) if path == "pageable" else None
         host, stats = eng.integrate_streamed(window, host_out=host_out)
@@ -954,48 +939,6 @@ def test_full_size_idempotence_and_properties(gpu):
     assert a["n_attempt"][ok].min() > 500 and a["n_attempt"].max() < 2000
 
 
-@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step"])
-def test_lane_refill_is_bit_identical_to_the_fixed_map(gpu, case):
-    """hlm_device_job.lane_refill: a persistent grid whose lanes take the next hillslope from a queue
-    when theirs is finished or flagged.  Which lane integrates which hillslope changes, nothing else:
-    finals, flags and both counters of every hillslope equal the one-system-per-thread launch
-    (rk45_kernel.cu:33) bit for bit -- with early-flagged cold cells (lanes refill at different times),
-    on the benchmark workload (whole waves refill at once; 300 000 hillslopes = more than the 196 608 the
-    persistent grid starts with), on fewer hillslopes than one wave, with the attempt cap, in fixed-step mode."""
-    from conftest import need_experimental_paths
-    need_experimental_paths(gpu)
-    H = gpu
-    from tiger_hlm_gpu_amd import synth
-    kw = {}
-    if case == "cold-cells":
-        ns, days = 250_037, 6
-        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
-        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
-    elif case == "benchmark":
-        ns, days = 300_000, 2
-        pr, t2m, dt, nT = synth.forcing_tables(days=days)
-        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
-    elif case == "ragged-small":
-        ns, days = 37, 3
-        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
-        model, y0, sp, tf = H.Model204, synth.model204_y0(ns, wet_surface=True), synth.model204_params(0, ns), days * 1440.0
-    elif case == "dummy-capped":
-        ns = 1000
-        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 500.0, dict(attempt_cap=100)
-    else:
-        ns = 777
-        model, y0, sp, tf, kw = H.DummyModel, synth.dummy_y0(0, ns), None, 50.0, dict(fixed_step=0.05)
-    forcing = None if sp is None else (pr, t2m, synth.cell_of_system(0, ns, run_len=64), dt, nT)
-    a = _run_engine(H, model, y0, 0.0, tf, sp=sp, forcing=forcing, per_cell=True, time_pieces=0, **kw)
-    b = _run_engine(H, model, y0, 0.0, tf, sp=sp, forcing=forcing, per_cell=True, lane_refill=True, **kw)
-    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
-        assert np.array_equal(a[k], b[k]), (case, k)
-    if case == "cold-cells":
-        assert 0.05 < (a["stiff"] == 1).mean() < 0.95
-    if case == "dummy-capped":
-        assert (a["stiff"] == 2).all() and (a["n_attempt"] == 100).all()
-
-
 @pytest.mark.parametrize("case", ["cold-cells", "benchmark", "ragged-small", "dummy-capped", "fixed-step", "fixed-step-short", "toy", "strict-wet", "empty-window", "late-start"])
 def test_time_pieces_queue_is_bit_identical_to_the_fixed_map(gpu, case):
     """hlm_device_job.time_pieces (csrc/hlm_rk45_queue_kernel.h): the window cut into pieces, a persistent grid of
@@ -1168,15 +1111,12 @@ EXEMPT_TOY = 8   # of 300 (measured: 8 STRICT, 8 FAST; the growth by the feedbac
 
 
 @pytest.mark.parametrize("math_mode", [0, 1])
-@pytest.mark.parametrize("layout", [0, 1, 2])
+@pytest.mark.parametrize("layout", [0, 2])
 def test_toy_model_three_states_one_forcing_vs_oracle(gpu, oracle, math_mode, layout):
     """ToyModel3 (N_EQ = 3, NF = 1; include/hlm/models/model_toy3.hpp, csrc/hlm_models.h: ToyDev) through
     the same kernels as Model 204 -- they are templates over Model::N_EQ and Model::NF like the reference's
     rk45_kernel_multi<Model> (solver/rk45.h:51-66): finals, dense rows in every device layout, flags and
     step counts against the CPU oracle; per-cell forcing table; ragged last wave."""
-    if layout == 1:
-        from conftest import need_experimental_paths
-        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd import synth
     from tiger_hlm_gpu_amd.engine import ShardEngine
@@ -1270,58 +1210,6 @@ def test_cpp_driver_toy_model(gpu, tmp_path):
     assert np.allclose(got, ref["y_final"], rtol=2e-6, atol=0)  # 6 printed digits
     dh, drows = _read_csv(d)
     assert dh.startswith("time,Var0_sys0,Var1_sys0,Var2_sys0,Var0_sys1") and len(drows) == 5
-
-
-@pytest.mark.parametrize("case", ["cold-cells", "benchmark", "toy-ragged", "dummy-capped"])
-def test_compaction_between_launches_is_bit_identical(gpu, case):
-    """hlm_rk45_integrate_compacting: the window cut into launches, every launch but the first running only
-    the hillslopes that are still integrating, compacted in their original order.  Lanes pause at the
-    interval ends as with t_stop, so finals, flags and both counters equal the single launch bit for bit:
-    cold cells (42 % drop out along the way), the benchmark workload (nobody drops out), a 3-state model on
-    a ragged size, and the attempt cap (everybody drops out in the first launch)."""
-    from conftest import need_experimental_paths
-    need_experimental_paths(gpu)
-    H = gpu
-    from tiger_hlm_gpu_amd import synth
-    from tiger_hlm_gpu_amd.engine import ShardEngine
-    kw, forcing, sp = {}, None, None
-    if case == "cold-cells":
-        ns, days, interval = 100_003, 6, 700.0
-        pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
-        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
-        forcing = (pr, t2m, synth.cell_of_system(0, ns, run_len=64), dt, nT)
-    elif case == "benchmark":
-        ns, days, interval = 70_000, 3, 1440.0
-        pr, t2m, dt, nT = synth.forcing_tables(days=days)
-        model, y0, sp, tf = H.Model204, synth.model204_y0(ns), synth.model204_params(0, ns), days * 1440.0
-        forcing = (pr, t2m, synth.cell_of_system(0, ns), dt, nT)
-    elif case == "toy-ragged":
-        y0, sp, inflow, cells, tf = _toy_case(ns=1000, days=2)
-        model, interval = H.ToyModel3, 333.0
-    else:
-        ns = 5000
-        model, y0, tf, interval, kw = H.DummyModel, synth.dummy_y0(0, ns), 500.0, 50.0, dict(attempt_cap=100)
-
-    def engine():
-        eng = ShardEngine(model, y0, 0.0, tf, sp=sp, **kw)
-        if forcing is not None:
-            eng.set_forcings_per_cell(forcing[:2], forcing[2], forcing[3], forcing[4])
-        if case == "toy-ragged":
-            eng.set_forcings_per_cell((inflow,), cells, (1.0,), (inflow.shape[0],))
-        return eng
-
-    a = engine()
-    a.integrate()
-    one = a.results()
-    b = engine()
-    assert b.integrate_compacting(interval) == int(np.ceil(tf / interval))
-    two = b.results()
-    for k in ("y_final", "stiff", "n_attempt", "n_accept"):
-        assert np.array_equal(one[k], two[k]), (case, k)
-    if case == "cold-cells":
-        assert 0.05 < (one["stiff"] == 1).mean() < 0.95
-    with pytest.raises(H.HlmError):  # jobs with dense output keep the fixed map
-        ShardEngine(H.DummyModel, synth.dummy_y0(0, 10), 0.0, 5.0, query=[1.0, 2.0]).integrate_compacting(1.0)
 
 
 def test_c4_four_million_hillslopes_whole_equals_its_eight_shards(gpu):
@@ -1803,15 +1691,12 @@ def test_device_rhs_single_evaluations_vs_oracle(gpu, oracle, math_mode):
     assert np.allclose(outd.cpu().numpy()[::20], refd, rtol=1e-14, atol=2e-15)  # FMA-contracted products
 
 
-@pytest.mark.parametrize("layout", [1, 2])
+@pytest.mark.parametrize("layout", [2])
 def test_dense_tile_layout_holds_the_same_rows(gpu, layout):
-    """dense_tiled 1 ([tile][q][lane][c], free-running kernel) and 2 ([tile][q][c][lane], the kernel
-    with wave-synchronous stores) hold the same bits as the host layout of the free-running kernel
+    """dense_tiled 2 ([tile][q][c][lane], the kernel with wave-synchronous stores) holds the same bits as the host
+    layout of the free-running kernel
     for every (hillslope, query, state), flagged rows and tails zero alike, also after the Radau
     pass and for a ragged last tile."""
-    if layout == 1:
-        from conftest import need_experimental_paths
-        need_experimental_paths(gpu)
     H = gpu
     from tiger_hlm_gpu_amd.engine import ShardEngine
     sp, y0, cells, pr, t2m, dt, nT, q, tf = _cold_case(ns=200, days=5)

@@ -59,7 +59,6 @@ class DeviceJob(C.Structure):
         ("query_begin", C.c_int), ("query_end", C.c_int), ("d_resume", C.c_void_p), ("resume_in", C.c_int),
         ("dense_tiled", C.c_int), ("use_t_stop", C.c_int), ("t_stop", C.c_double),
         ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
-        ("lane_refill", C.c_int),
         ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
         ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int), ("queue_run_pieces", C.c_int), ("queue_group_tiles", C.c_int), ("dense_sub_windows", C.c_int),
         ("d_path_counts", C.c_void_p),
@@ -107,7 +106,6 @@ WINDOW_SINK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_d
 # name -> (restype, argtypes); every symbol include/hlm_hip.h declares
 SIGNATURES = {
     "hlm_abi_version": (C.c_int, []),
-    "hlm_build_flags": (C.c_int, []),
     "hlm_last_error": (C.c_char_p, []),
     "hlm_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "hlm_set_device": (C.c_int, [C.c_int]),
@@ -122,7 +120,6 @@ SIGNATURES = {
     "hlm_set_attempt_cap": (C.c_int, [C.c_uint32]),
     "hlm_set_math_mode": (C.c_int, [C.c_int]),
     "hlm_set_radau_fallback": (C.c_int, [C.c_int]),
-    "hlm_set_lane_refill": (C.c_int, [C.c_int]),
     "hlm_set_output_states": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "hlm_set_time_pieces": (C.c_int, [C.c_int]),
     "hlm_set_queue_shape": (C.c_int, [C.c_int, C.c_int]),
@@ -152,7 +149,6 @@ SIGNATURES = {
                                         C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hlm_rk45_integrate_forcing_streamed": (C.c_int, [C.POINTER(DeviceJob), C.POINTER(C.c_void_p), C.c_double,
                                                       C.c_void_p, C.POINTER(C.c_int)]),
-    "hlm_rk45_integrate_compacting": (C.c_int, [C.POINTER(DeviceJob), C.c_double, C.c_void_p, C.POINTER(C.c_int)]),
     "hlm_set_stream_path": (C.c_int, [C.c_int]),
     "hlm_host_alloc_pinned": (C.c_int, [C.POINTER(C.c_void_p), C.c_size_t]),
     "hlm_host_free_pinned": (C.c_int, [C.c_void_p]),

@@ -27,13 +27,6 @@ def _ptr(a):
     return None if a is None else a.ctypes.data
 
 
-def has_experimental_paths():
-    """True when the library was built with HLM_EXPERIMENTAL_PATHS (lane refill, compaction between launches, the
-    tile-row dense layout: quarantined by default, hlm_build_flags)."""
-    return bool(lib().hlm_build_flags() & 1)
-
-
-# ---- device helpers ---------------------------------------------------------------------
 def device_count():
     n = C.c_int(0)
     rc = lib().hlm_device_count(C.byref(n))
@@ -109,11 +102,6 @@ def set_attempt_cap(cap):
 
 def set_math_mode(mode):
     check(lib().hlm_set_math_mode(int(mode)))
-
-
-def set_lane_refill(enabled):
-    """Host API launches without dense output use the lane-refill kernel (hlm_device_job.lane_refill)."""
-    check(lib().hlm_set_lane_refill(int(bool(enabled))))
 
 
 def set_time_pieces(pieces):

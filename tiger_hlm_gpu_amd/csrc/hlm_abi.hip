@@ -22,14 +22,6 @@
 #include "hlm_rk45_kernel.h"
 #include "hlm_rk45_queue_kernel.h"
 #include "hlm_gather_rccl.h"
-// Paths that lost on every workload measured in rounds 2-4 (lane refill, compaction between launches, the tile-row
-// dense layout) are quarantined: built only with -DHLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1), refused otherwise.
-#ifdef HLM_EXPERIMENTAL_PATHS
-#include "hlm_rk45_refill_kernel.h"
-constexpr bool kExperimentalPaths = true;
-#else
-constexpr bool kExperimentalPaths = false;
-#endif
 
 namespace {
 
@@ -83,14 +75,13 @@ int model_nf(int uid) { return with_model<int>(uid, [](auto m) { return decltype
 bool model_needs_sp(int uid) { return uid == HLM_UID_204; }
 uint32_t g_cap = 1u << 24;
 int g_stream_path = 0;  // hlm_set_stream_path(): 0 copy engine (default), 1 / 2 transposing transfer kernel
-int g_stream_layout = hlm::DENSE_TILE_COMP;  // device layout of the tiled stream path (1 tile-row, 2 tile-comp)
+constexpr int g_stream_layout = hlm::DENSE_TILE_COMP;  // device layout of the tiled stream path
 // Default arithmetic of the host API: FAST (the measured-more-accurate and 2.4x faster of the two,
 // DESIGN.md "Math modes").  Until hlm_set_math_mode() is called the choice is automatic: FAST wherever
 // its one precondition holds (1e-60 <= atol <= 1e50), STRICT otherwise -- a reference-style caller
 // with any tolerances the reference accepts gets a result, and with the usual ones the fast kernel.
 int g_math = HLM_MATH_FAST;
 bool g_math_explicit = false;
-int g_refill = 0;  // hlm_set_lane_refill(): host-API launches without dense output use the refill kernel
 int g_time_pieces = -1;  // hlm_set_time_pieces(): < 0 = automatic (auto_time_pieces)
 int g_queue_run_pieces = 0, g_queue_group_tiles = 0;  // hlm_set_queue_shape(): hlm_device_job.queue_run_pieces / queue_group_tiles of the host API's launches
 constexpr int kMaxTimePieces = 4096;
@@ -259,23 +250,6 @@ DenseQueueFn pick_dense_queue(int uid, int math, bool sel)
     return with_model<DenseQueueFn>(uid, [&](auto m) { return pick_dense_queue<decltype(m)>(math, sel); });
 }
 
-#ifdef HLM_EXPERIMENTAL_PATHS
-// the kernels with lane refill (hlm_rk45_refill_kernel.h): no dense output, no resume state
-using RefillFn = void (*)(const hlm::Rk45Args, unsigned int*);
-template <class Model>
-RefillFn pick_refill(int math, bool fixed)
-{
-    using namespace hlm;
-    if (math == HLM_MATH_FAST) return fixed ? rk45_refill_kernel<Model, MATH_FAST, true> : rk45_refill_kernel<Model, MATH_FAST, false>;
-    return fixed ? rk45_refill_kernel<Model, MATH_STRICT, true> : rk45_refill_kernel<Model, MATH_STRICT, false>;
-}
-RefillFn pick_refill(int uid, int math, bool fixed)
-{
-    return with_model<RefillFn>(uid, [&](auto m) { return pick_refill<decltype(m)>(math, fixed); });
-}
-
-#endif
-
 // the persistent kernels over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): no dense output
 using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int, const hlm::QueueRuns);
 template <class Model>
@@ -361,10 +335,7 @@ int validate_job(const hlm_device_job* j)
     if (j->resume_in && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "resume_in without d_resume");
     if (j->dense_tiled < 0 || j->dense_tiled > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled must be 0, 1 or 2");
     if (const int rcs = validate_selection(j->uid, j->dense_ncomp, j->dense_comp); rcs != HLM_SUCCESS) return rcs;
-    if (j->lane_refill != 0 && j->lane_refill != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane_refill must be 0 or 1");
-    if (!kExperimentalPaths && (j->lane_refill || j->dense_tiled == hlm::DENSE_TILE_ROW))
-        return fail(HLM_ERR_INVALID_ARGUMENT, "%s: this library was built without HLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1)",
-                    j->lane_refill ? "lane_refill" : "dense_tiled = 1 (tile-row layout)");
+    if (j->dense_tiled == 1) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_tiled = 1 (the tile-row layout of rounds 1-4) was removed in ABI 5: use 0 or 2");
     if (j->time_pieces > kMaxTimePieces) return fail(HLM_ERR_INVALID_ARGUMENT, "time_pieces must be at most %d (negative = automatic)", kMaxTimePieces);
     // (the queue kernel numbers its (piece, tile) items with 32 bits)
     if (j->time_pieces > 1 && ((long long)j->num_systems + 63) / 64 * (long long)j->time_pieces >= (1ll << 32) - 1)
@@ -373,7 +344,7 @@ int validate_job(const hlm_device_job* j)
     if (j->dense_sub_windows < 0 || j->dense_sub_windows > 4096) return fail(HLM_ERR_INVALID_ARGUMENT, "dense_sub_windows must be within [0, 4096]");
     if (j->queue_group_tiles < 0 || j->queue_group_tiles > hlm::QUEUE_MAX_GROUP)
         return fail(HLM_ERR_INVALID_ARGUMENT, "queue_group_tiles must be within [0, %d]", hlm::QUEUE_MAX_GROUP);
-    if (j->lane_refill == 0 && j->d_path_counts &&
+    if (j->d_path_counts &&
         (j->math_mode != HLM_MATH_FAST || j->fixed_step > 0.0 || j->queue_group_tiles > 1 || j->num_queries > 0))
         return fail(HLM_ERR_INVALID_ARGUMENT, "d_path_counts: the counting instance is the queue kernel in FAST arithmetic with adaptive "
                                               "steps, no dense output and tiles as items (queue_group_tiles <= 1)");
@@ -443,37 +414,6 @@ hlm::Rk45Args make_args(const hlm_device_job* j)
     }
     return a;
 }
-
-#ifdef HLM_EXPERIMENTAL_PATHS
-// Persistent launch with lane refill: as many one-wave workgroups as the device holds at once, the
-// rest of the hillslopes handed out through a device counter (hlm_rk45_refill_kernel.h).
-int launch_refill(const hlm_device_job* j, hipStream_t stream)
-{
-    const bool fixed = j->fixed_step > 0.0;
-    RefillFn fn = pick_refill(j->uid, j->math_mode, fixed);
-    if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j->uid);
-    int dev = 0, cus = 0, per_cu = 0;
-    HLM_HIP_TRY(hipGetDevice(&dev));
-    HLM_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-    HLM_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(fn), hlm::WAVE, 0));
-    const long long resident = (long long)cus * (per_cu > 0 ? per_cu : 1);
-    const long long waves = ((long long)j->num_systems + hlm::WAVE - 1) / hlm::WAVE;
-    const unsigned blocks = (unsigned)(waves < resident ? waves : resident);
-    unsigned int* queue = nullptr;
-    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&queue), sizeof(unsigned int), stream));
-    if (hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(queue), (int)(blocks * (unsigned)hlm::WAVE), 1, stream); e != hipSuccess) {
-        (void)hipFreeAsync(queue, stream);
-        return fail(HLM_ERR_HIP, "hipMemsetD32Async failed: %s", hipGetErrorString(e));
-    }
-    const hlm::Rk45Args a = make_args(j);
-    hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue);
-    const hipError_t launched = hipGetLastError();
-    HLM_HIP_TRY(hipFreeAsync(queue, stream));  // stream-ordered: after the kernel
-    HLM_HIP_TRY(launched);
-    return HLM_SUCCESS;
-}
-
-#endif
 
 #ifdef HLM_QUEUE_DEBUG
 // experiment builds only (not in include/hlm_hip.h): where the last queue launch keeps its state, for a look at a
@@ -612,10 +552,10 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
 }
 int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream) { return launch_queue(j, pieces, stream, j->t0, j->tf, false); }
 
-// pieces of the queue kernel this job launches with; 0 = the fixed map (or lane refill)
+// pieces of the queue kernel this job launches with; 0 = the fixed map
 int job_time_pieces(const hlm_device_job* j)
 {
-    if (j->num_queries > 0 || j->lane_refill || job_is_resumable(j)) return 0;
+    if (j->num_queries > 0 || job_is_resumable(j)) return 0;
     const int pieces = j->time_pieces < 0 ? auto_time_pieces(j->num_systems, j->t0, j->tf) : j->time_pieces;
     return pieces > 1 ? pieces : 0;
 }
@@ -680,9 +620,6 @@ int launch(const hlm_device_job* j, hipStream_t stream)
     if (j->d_path_counts && job_time_pieces(j) <= 1)
         return fail(HLM_ERR_INVALID_ARGUMENT, "d_path_counts: this job does not launch in time pieces (set time_pieces > 1)");
     if (const int nsub = job_dense_sub_windows(j); nsub > 1) return launch_dense_queue(j, nsub, stream);
-#ifdef HLM_EXPERIMENTAL_PATHS
-    if (!dense && j->lane_refill && !job_is_resumable(j)) return launch_refill(j, stream);
-#endif
     if (const int pieces = job_time_pieces(j); pieces > 1) return launch_queue(j, pieces, stream);
     KernelFn fn = dense && job_selects(j) ? pick_selecting(j->uid, j->math_mode, fixed, j->dense_tiled == hlm::DENSE_TILE_COMP)
                   : dense && j->dense_tiled == hlm::DENSE_TILE_COMP
@@ -697,15 +634,12 @@ int launch(const hlm_device_job* j, hipStream_t stream)
 }
 
 // tile-major window -> host order, for the layout and N_EQ at hand (hlm_rk45_kernel.h: dense_tile_to_host)
-void launch_tile_to_host(int layout, int neq, dim3 grid, hipStream_t stream, const double* src, double* dst, int ns, int nq,
+void launch_tile_to_host(int /*layout: DENSE_TILE_COMP*/, int neq, dim3 grid, hipStream_t stream, const double* src, double* dst, int ns, int nq,
                          int q_begin, int W)
 {
     auto go = [&](auto n) {
         constexpr int N = decltype(n)::value;
-        if (layout == hlm::DENSE_TILE_COMP)
-            hipLaunchKernelGGL((hlm::dense_tile_to_host<true, N>), grid, dim3(256), 0, stream, src, dst, ns, nq, q_begin, W);
-        else
-            hipLaunchKernelGGL((hlm::dense_tile_to_host<false, N>), grid, dim3(256), 0, stream, src, dst, ns, nq, q_begin, W);
+        hipLaunchKernelGGL((hlm::dense_tile_to_host<N>), grid, dim3(256), 0, stream, src, dst, ns, nq, q_begin, W);
     };
     switch (neq) {  // neq = doubles per row: a model's N_EQ, or the width of an output selection
         case 1: go(std::integral_constant<int, 1>{}); break;
@@ -816,7 +750,6 @@ int fill_job_from_registry(hlm_device_job* j, int uid, const ForcingState& F)
     std::memcpy(j->params, m->p, sizeof(m->p));
     j->fixed_step = m->fixed_step;
     j->attempt_cap = g_cap;
-    j->lane_refill = g_refill;
     j->time_pieces = g_time_pieces;  // (< 0: resolved by the caller once it knows the number of systems)
     j->queue_run_pieces = g_queue_run_pieces;
     j->queue_group_tiles = g_queue_group_tiles;
@@ -849,7 +782,6 @@ int replace_forcings(const ForcingState& next)
 extern "C" {
 
 int hlm_abi_version(void) { return HLM_ABI_VERSION; }
-int hlm_build_flags(void) { return kExperimentalPaths ? HLM_BUILD_EXPERIMENTAL_PATHS : 0; }
 const char* hlm_last_error(void) { return g_err; }
 
 int hlm_device_count(int* count)
@@ -952,11 +884,9 @@ int hlm_set_attempt_cap(uint32_t cap)
 
 int hlm_set_stream_path(int path)
 {
-    if (path < 0 || path > 2) return fail(HLM_ERR_INVALID_ARGUMENT, "stream path %d", path);
-    if (path == 1 && !kExperimentalPaths) return fail(HLM_ERR_INVALID_ARGUMENT, "stream path 1 (tile-row layout): this library was built without HLM_EXPERIMENTAL_PATHS");
+    if (path != 0 && path != 2) return fail(HLM_ERR_INVALID_ARGUMENT, "stream path %d (0 copy engine, 2 transposing transfer kernel; 1 was removed in ABI 5)", path);
     std::lock_guard<std::mutex> lk(g_mu);
     g_stream_path = path ? 1 : 0;
-    if (path) g_stream_layout = path == 2 ? hlm::DENSE_TILE_COMP : hlm::DENSE_TILE_ROW;
     return HLM_SUCCESS;
 }
 
@@ -1025,15 +955,6 @@ int hlm_radau_fallback_device(const hlm_device_job* job, void* hip_stream)
     if (rc != HLM_SUCCESS) return rc;
     if (job->num_systems == 0) return HLM_SUCCESS;
     return launch_radau(job, static_cast<hipStream_t>(hip_stream));
-}
-
-int hlm_set_lane_refill(int enabled)
-{
-    if (enabled != 0 && enabled != 1) return fail(HLM_ERR_INVALID_ARGUMENT, "lane refill flag %d (want 0 or 1)", enabled);
-    if (enabled && !kExperimentalPaths) return fail(HLM_ERR_INVALID_ARGUMENT, "lane refill: this library was built without HLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1)");
-    std::lock_guard<std::mutex> lk(g_mu);
-    g_refill = enabled;
-    return HLM_SUCCESS;
 }
 
 int hlm_set_output_states(int n, const int* comps)
@@ -1435,7 +1356,7 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
         // (growing chunks: every chunk, also the short first ones, in 16 pieces -- measured on the headline workload:
         // 134.5 ms against 135.2 ms with the twelve-hour rule and 135.4 ms with 8; profiles/r04_streamed_probe.txt)
         int pieces = 0;
-        if (j.num_queries == 0 && !j.lane_refill) {
+        if (j.num_queries == 0) {
             if (j.time_pieces >= 0) pieces = growing ? j.time_pieces : 0;
             else if (growing) pieces = j.num_systems >= 4096 ? 16 : 0;
             else pieces = auto_time_pieces(j.num_systems, edge[k], edge[k + 1]);
@@ -1455,74 +1376,6 @@ int hlm_rk45_integrate_forcing_streamed(const hlm_device_job* job, const float* 
     if (e != hipSuccess) return fail(HLM_ERR_HIP, "integrate_forcing_streamed: %s", hipGetErrorString(e));
     if (chunks && rc == HLM_SUCCESS) *chunks = nchunk;
     return rc;
-}
-
-int hlm_rk45_integrate_compacting(const hlm_device_job* job, double interval_minutes, void* hip_stream, int* launches)
-{
-#ifndef HLM_EXPERIMENTAL_PATHS
-    (void)job; (void)interval_minutes; (void)hip_stream; (void)launches;
-    return fail(HLM_ERR_INVALID_ARGUMENT, "integrate_compacting: this library was built without HLM_EXPERIMENTAL_PATHS (make EXPERIMENTAL=1)");
-#else
-    if (!job) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
-    if (!(interval_minutes > 0.0)) return fail(HLM_ERR_INVALID_ARGUMENT, "interval_minutes must be > 0");
-    int rc = validate_job(job);
-    if (rc != HLM_SUCCESS) return rc;
-    if (job->num_queries > 0 || job_is_resumable(job))
-        return fail(HLM_ERR_INVALID_ARGUMENT, "integrate_compacting takes a plain job without dense output (no queries, "
-                                              "no d_resume / t_stop / query window / forcing chunk)");
-    if (launches) *launches = 0;
-    const int ns = job->num_systems;
-    if (ns == 0) return HLM_SUCCESS;
-    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
-    std::vector<double> edge;
-    if (const int rce = chunk_edges(job->t0, job->tf, interval_minutes, &edge, "integrate_compacting"); rce != HLM_SUCCESS) return rce;
-    const int nchunk = (int)edge.size() - 1;
-    if (nchunk <= 1) {  // one interval (or tf <= t0): nothing to compact
-        rc = launch(job, stream);
-        if (rc == HLM_SUCCESS && launches) *launches = 1;
-        return rc;
-    }
-    const int nb = (ns + hlm::COMPACT_BLOCK - 1) / hlm::COMPACT_BLOCK;
-    const size_t rbytes = hlm_resume_bytes_model(job->uid, ns);
-    const size_t ibytes = sizeof(int32_t) * ((size_t)ns + (size_t)nb + 1);  // index | block counts | count
-    char* pool = nullptr;
-    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&pool), rbytes + ibytes, stream));
-    void* resume = pool;
-    int32_t* index = reinterpret_cast<int32_t*>(pool + rbytes);
-    int* block_count = index + ns;
-    int* count = block_count + nb;
-    const int* status = reinterpret_cast<const int*>(static_cast<const double*>(resume) + (size_t)hlm::resume_f64(model_neq(job->uid)) * ns) + (size_t)4 * ns;
-    hipError_t e = hipSuccess;
-    int done = 0;
-    for (int k = 0; k < nchunk && rc == HLM_SUCCESS && e == hipSuccess; ++k) {
-        hlm_device_job j = *job;
-        j.d_resume = resume;
-        j.resume_in = k > 0;
-        j.use_t_stop = edge[k + 1] < job->tf;
-        j.t_stop = edge[k + 1];
-        KernelFn fn = pick(j.uid, j.math_mode, false, j.fixed_step > 0.0, true);
-        if (!fn) { e = hipSuccess; rc = fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d", j.uid); break; }
-        hlm::Rk45Args a = make_args(&j);
-        if (k > 0) {
-            // the systems still integrating, in their original order
-            hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, (int)hlm::SYS_PAUSED, ns, block_count);
-            hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, (int*)nullptr);
-            hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, status, (int)hlm::SYS_PAUSED, ns, block_count, index);
-            a.index = index;
-            a.index_count = count;
-        }
-        // (the grid stays ceil(ns / 64): waves beyond the survivor count read it from device memory and leave at
-        // once -- no host round trip between the launches)
-        hipLaunchKernelGGL(fn, dim3((unsigned)((ns + hlm::WAVE - 1) / hlm::WAVE)), dim3(hlm::WAVE), 0, stream, a);
-        e = hipGetLastError();
-        ++done;
-    }
-    const hipError_t ef = hipFreeAsync(pool, stream);  // stream-ordered: after the last kernel
-    if (e != hipSuccess) return fail(HLM_ERR_HIP, "integrate_compacting: %s", hipGetErrorString(e));
-    HLM_HIP_TRY(ef);
-    if (launches) *launches = done;
-    return rc;
-#endif
 }
 
 int hlm_rk45_time_device(const hlm_device_job* job, void* hip_stream, int iters, float* ms)

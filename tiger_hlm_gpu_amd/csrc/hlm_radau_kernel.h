@@ -347,13 +347,13 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     const int nflagged = *count;
     const double tf = A.tf;
 
-    // dense layouts as in hlm_rk45_dense_kernel.h: 0 / 3 [sys][q][c], 1 [tile][q][lane][c], 2 [tile][q][c][lane]
+    // dense layouts as in hlm_rk45_dense_kernel.h: 0 [sys][q][c], 2 [tile][q][c][lane]
     // output selection (hlm_device_job.dense_ncomp): rows of K components, component c at position pos(c) or absent
-    const bool tiled = A.dense_tiled == 1 || A.dense_tiled == 2;
+    const bool tiled = A.dense_tiled == 2;
     const int K = A.dense_k > 0 ? A.dense_k : NEQ;
     auto pos = [&](int c) -> int { return A.dense_k > 0 ? A.dense_pos[c] : c; };  // wave-uniform
     const size_t q_stride = tiled ? (size_t)WAVE * (size_t)K : (size_t)K;
-    const size_t c_stride = A.dense_tiled == 2 ? (size_t)WAVE : (size_t)1;
+    const size_t c_stride = tiled ? (size_t)WAVE : (size_t)1;
 
     // ---- the system a lane integrates.  LANE REFILL (round 4): the grid is persistent (as many one-wave workgroups as
     // the device holds) and a lane that finishes its system takes the next flagged one from a device counter -- no wave
@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         if (A.nq > 0)
             dense_row = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * (size_t)K
                                : A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride +
-                                     (size_t)(sys % WAVE) * (A.dense_tiled == 2 ? (size_t)1 : (size_t)K);
+                                     (size_t)(sys % WAVE);
         t = A.t0;
         h = A.h0;
         next_q = 0;

@@ -29,7 +29,6 @@ namespace hlm {
 
 // device layouts of the dense buffer (hlm_device_job.dense_tiled)
 constexpr int DENSE_LINEAR = 0;     // [sys][q][comp]: the host-facing order
-constexpr int DENSE_TILE_ROW = 1;   // [sys/64][q][sys%64][comp]            (free-running kernel only)
 constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte run per store instruction (this file)
 
 // rows of slack between the lanes of a wave (LDS: R x 2560 bytes per wave)

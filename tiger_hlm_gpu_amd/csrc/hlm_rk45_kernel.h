@@ -58,18 +58,13 @@ struct Rk45Args {
     uint32_t cap;
     double* y_final;     // [ns][N_EQ]
     double* dense;       // rows of this launch's query window, linear [ns][W][N_EQ] or tile-major
-    int dense_tiled;     // 1: [ceil(ns/64)][W][64][N_EQ], 2: [ceil(ns/64)][W][N_EQ][64] (W = q_end - q_begin)
+    int dense_tiled;     // 0: [ns][W][N_EQ]; 2: [ceil(ns/64)][W][N_EQ][64] (W = q_end - q_begin)
     int q_begin, q_end;  // global query indices [q_begin, q_end) written by this launch
     double* resume;      // nullable: per-system integrator state carried between launches
     int resume_in;       // 0 = start from y0, 1 = continue from `resume`
     int32_t* stiff;
     uint32_t* n_attempt;
     uint32_t* n_accept;
-    // RESUMABLE launches only: integrate the systems index[0 .. *index_count) instead of 0 .. ns-1 (slot s of
-    // the grid takes system index[s]): the survivors of earlier launches, compacted in their original order
-    // (hlm_rk45_integrate_compacting).  NULL: the identity.
-    const int32_t* index;
-    const int32_t* index_count;
     // Output selection (SEL kernel variants only; hlm_device_job.dense_ncomp): a dense row holds dense_k
     // components; dense_pos[c] = position of state component c in the row, or -1 when it is not written.
     int dense_k;
@@ -99,7 +94,7 @@ __device__ __forceinline__ Rk45Args load_args(Rk45ArgsConst* p)
     a.h0 = p->h0; a.rtol = p->rtol; a.atol = p->atol; a.safety = p->safety; a.min_scale = p->min_scale; a.max_scale = p->max_scale;
     a.fixed_step = p->fixed_step; a.cap = p->cap; a.y_final = p->y_final; a.dense = p->dense; a.dense_tiled = p->dense_tiled;
     a.q_begin = p->q_begin; a.q_end = p->q_end; a.resume = p->resume; a.resume_in = p->resume_in; a.stiff = p->stiff;
-    a.n_attempt = p->n_attempt; a.n_accept = p->n_accept; a.index = p->index; a.index_count = p->index_count; a.dense_k = p->dense_k;
+    a.n_attempt = p->n_attempt; a.n_accept = p->n_accept; a.dense_k = p->dense_k;
 #pragma unroll
     for (int c = 0; c < HLM_MAX_NEQ; ++c) a.dense_pos[c] = p->dense_pos[c];
     a.flag_state = p->flag_state;
@@ -673,15 +668,7 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     const unsigned nblk = gridDim.x, orig = blockIdx.x;
     const unsigned xcd = orig & 7u, qd = nblk >> 3, rm = nblk & 7u;
     const unsigned blk = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + (orig >> 3);
-    const int slot = (int)(blk * WAVE + threadIdx.x);
-    int sys_of_slot = slot;
-    if constexpr (RESUMABLE) {
-        if (A.index) {
-            if (slot >= *A.index_count) return;
-            sys_of_slot = A.index[slot];
-        }
-    }
-    const int sys = sys_of_slot;
+    const int sys = (int)(blk * WAVE + threadIdx.x);
     if (sys >= A.ns) return;
 
     const typename Model::Local P = Model::template load<MATH>(A.sp, sys);
@@ -725,17 +712,10 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
         // sequence of committed steps -- and every output bit -- equals the one-shot run.
         qb = A.q_begin;
         qe = A.q_end;
-        // row(q) = dense_row + q * q_stride.  Linear layout: the host-facing [sys][q][comp].
-        // Tile-major layout [sys/64][q][sys%64][comp]: the 64 lanes of a wave write one
-        // contiguous 2560-byte row block per query (full cache lines, no write
-        // amplification); dense_tile_to_host() transposes it on its way to host memory.
-        if (A.dense_tiled) {
-            q_stride = (size_t)WAVE * (SEL ? K : NEQ);
-            dense_row = A.dense + ((size_t)(sys / WAVE) * (size_t)(qe - qb) - (size_t)qb) * q_stride + (size_t)(sys % WAVE) * (SEL ? K : NEQ);
-        } else {
-            q_stride = SEL ? K : NEQ;
-            dense_row = A.dense + ((size_t)sys * (size_t)(qe - qb) - (size_t)qb) * (SEL ? K : NEQ);
-        }
+        // row(q) = dense_row + q * q_stride: the host-facing layout [sys][q][comp] (the tile-major layout is the ring
+        // kernel's, hlm_rk45_dense_kernel.h)
+        q_stride = SEL ? K : NEQ;
+        dense_row = A.dense + ((size_t)sys * (size_t)(qe - qb) - (size_t)qb) * (SEL ? K : NEQ);
     }
     // Integrator state carried between launches (query windows, time chunks of streamed
     // forcings, checkpoints): a paused lane continues exactly where it stopped.
@@ -928,12 +908,11 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !DENSE) ? HLM_MIN_
     }
 }
 
-// ---- ordered compaction of the systems still integrating (hlm_rk45_integrate_compacting) -------------
+// ---- ordered compaction (the Radau pass's list of flagged systems: launch_radau) ------------------------------
 // index[0 .. count) = the systems i with status[i] == want, in ascending order (neighbouring hillslopes
-// share a forcing cell: keeping the order keeps the waves of the next launch uniform -- which is what the
-// cheap RHS variants need, and what makes the lanes of a Radau wave take similar numbers of attempts).
+// share a forcing cell: keeping the order makes the lanes of a Radau wave take similar numbers of attempts).
 // Three small launches: per-block counts, a scan of the block counts by one block, the scatter.
-// status = the 5th int32 section of the resume record (want = SYS_PAUSED), or stiff[] (want = HLM_SYS_STIFF).
+// status = stiff[] (want = HLM_SYS_STIFF) or the flag-time bins of radau_flag_bin_kernel.
 constexpr int COMPACT_BLOCK = 1024;
 
 __global__ void __launch_bounds__(COMPACT_BLOCK) compact_count_kernel(const int* __restrict__ status, int want, int ns, int* __restrict__ block_count)
@@ -1140,22 +1119,22 @@ __global__ void __launch_bounds__(WAVE) selftest_attempt_kernel(const double* __
 // device: the kernel IS the device-to-host transfer (PCIe writes in 640-byte contiguous runs), running
 // on its own stream beside the integration of the next window -- or a device staging buffer
 // (hlm_retrieve_and_free).  One workgroup = 64 systems x TQ queries staged through LDS.
-// COMP_MAJOR: src is [blk][W][NEQ][64] (the wave-synchronous kernel's layout), else [blk][W][64][NEQ].
+// src is [blk][W][NEQ][64] (the wave-synchronous kernel's layout).
 constexpr int TILE_TQ = 16;
 
-template <bool COMP_MAJOR, int NEQ>
+template <int NEQ>
 __global__ void __launch_bounds__(256) dense_tile_to_host(const double* __restrict__ src, double* __restrict__ dst,
                                                           int ns, int nq, int q_begin, int W)
 {
-    // [ql][lane][c], or [ql][c][lane] with each 64-lane run padded to 65 so that the transposed reads
-    // below (consecutive threads = consecutive components of one lane) do not all hit one LDS bank
-    constexpr int RUN = COMP_MAJOR ? WAVE + 1 : WAVE;
+    // [ql][c][lane] with each 64-lane run padded to 65 so that the transposed reads below (consecutive threads =
+    // consecutive components of one lane) do not all hit one LDS bank
+    constexpr int RUN = WAVE + 1;
     __shared__ double tile[TILE_TQ * NEQ * RUN];  // ~41 KB
     const int blk = blockIdx.x, q0 = blockIdx.y * TILE_TQ;
     const int nql = (W - q0) < TILE_TQ ? (W - q0) : TILE_TQ;
     const int n_in = nql * WAVE * NEQ;
     const double* s = src + ((size_t)blk * (size_t)W + (size_t)q0) * (WAVE * NEQ);
-    for (int i = threadIdx.x; i < n_in; i += 256) tile[COMP_MAJOR ? (i / WAVE) * RUN + (i % WAVE) : i] = s[i];  // contiguous, coalesced
+    for (int i = threadIdx.x; i < n_in; i += 256) tile[(i / WAVE) * RUN + (i % WAVE)] = s[i];  // contiguous, coalesced
     __syncthreads();
     const int row_len = nql * NEQ;  // doubles each system contributes: contiguous in dst
     const int n_out = WAVE * row_len;
@@ -1165,7 +1144,7 @@ __global__ void __launch_bounds__(256) dense_tile_to_host(const double* __restri
         if (sys < ns) {
             const int ql = r / NEQ, c = r - ql * NEQ;
             dst[((size_t)sys * (size_t)nq + (size_t)(q_begin + q0)) * NEQ + r] =
-                tile[COMP_MAJOR ? (ql * NEQ + c) * RUN + l : (ql * WAVE + l) * NEQ + c];
+                tile[(ql * NEQ + c) * RUN + l];
         }
     }
 }

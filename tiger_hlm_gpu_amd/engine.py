@@ -15,7 +15,7 @@ from .models import Parameters, SP_DTYPE
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
                  math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
-                 dense_tiled=2, lane_refill=False, dense_states=None, time_pieces=None, queue_run_pieces=0, queue_group_tiles=0, dense_sub_windows=0):
+                 dense_tiled=2, dense_states=None, time_pieces=None, queue_run_pieces=0, queue_group_tiles=0, dense_sub_windows=0):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -24,7 +24,6 @@ class ShardEngine:
         self.t0, self.tf = float(t0), float(tf)
         self.params = params if params is not None else Parameters()
         self.math_mode, self.fixed_step, self.attempt_cap = math_mode, fixed_step, attempt_cap
-        self.lane_refill = int(bool(lane_refill))  # hlm_device_job.lane_refill (launches without dense output)
         # hlm_device_job.time_pieces (launches without dense output): a persistent grid over (time piece, tile) items
         # instead of one wave per tile; None = the host API's automatic rule (from 4 096 hillslopes on, one piece per
         # twelve simulated hours, at most 32, none below 8)
@@ -60,8 +59,7 @@ class ShardEngine:
         o = self.ns * 8 * model.N_EQ
         self.y_final = self.result_blob[:o].view(torch.float64).view(self.ns, model.N_EQ)
         # device layout of the dense buffer (hlm_device_job.dense_tiled): 2 (default) tile-major
-        # [tile][q][c][lane], the kernel with wave-synchronous stores; 0 host order and 1 [tile][q][lane][c],
-        # the free-running kernel.  results() / dense_host_order() deliver [ns][nq][5] whatever the layout.
+        # [tile][q][c][lane], the kernel with wave-synchronous stores; 0 host order, the free-running kernel.  results() / dense_host_order() deliver [ns][nq][5] whatever the layout.
         self.dense_tiled = int(dense_tiled)
         # output selection (hlm_device_job.dense_ncomp; the reference's output.states): the dense rows hold only
         # these state components -- K/N_EQ of the HBM and PCIe bytes; None = all
@@ -110,7 +108,6 @@ class ShardEngine:
             dense=self.dense, stiff=self.stiff, n_attempt=self.n_attempt, n_accept=self.n_accept,
             dense_states=self.dense_states)
         j.dense_tiled = self.dense_tiled if self.dense is not None else 0
-        j.lane_refill = self.lane_refill
         tp = self.time_pieces
         j.time_pieces = -1 if tp is None else int(tp)
         j.queue_run_pieces = self.queue_run_pieces
@@ -158,17 +155,6 @@ class ShardEngine:
         api.integrate_device(j, s)
         if radau:
             api.radau_fallback_device(j, s)
-
-    def integrate_compacting(self, interval_minutes, stream=None):
-        """One pass cut into launches of ``interval_minutes`` with the hillslopes still integrating
-        compacted between them (hlm_rk45_integrate_compacting): bit-identical results, no idle lanes
-        behind hillslopes that were flagged early.  Returns the number of RK45 launches."""
-        import ctypes as C
-        s = stream if stream is not None else torch.cuda.current_stream(self.device)
-        n = C.c_int(0)
-        j = self.job()
-        _lib.check(_lib.lib().hlm_rk45_integrate_compacting(C.byref(j), float(interval_minutes), s.cuda_stream, C.byref(n)))
-        return n.value
 
     def _resume_buffer(self):
         if getattr(self, "_resume", None) is None:
