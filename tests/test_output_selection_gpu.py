@@ -400,3 +400,46 @@ def test_dense_sub_windows_hold_the_same_rows(gpu, case):
     e = engine(3)
     host, _ = e.integrate_streamed(37)
     assert np.array_equal(host, one["dense"]) and np.array_equal(e.results()["y_final"], one["y_final"])
+
+
+def test_automatic_dense_sub_windows_hold_the_same_rows_at_their_threshold_sizes(gpu):
+    """hlm_device_job.dense_sub_windows = 0 (the default): the library cuts a dense launch in the tile layout into four
+    sub-windows by itself when it has fewer than five rounds of waves and at least 256 queries (auto_dense_sub_windows,
+    csrc/hlm_abi.hip) -- so the DEFAULT path of a config-5-sized run is the persistent (sub-window, tile) grid.  At
+    sizes on both sides of the rule (round-4 advisor): a ragged last tile, cold cells (hillslopes flagged in different
+    sub-windows), one launch and streamed query windows of 300 queries with the lanes in the caller's record (every
+    window again cut in four) and of 200 (below the rule: one wave per tile) -- rows, finals, flags and counters equal
+    the explicit one-wave-per-tile launch bit for bit."""
+    H = gpu
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 10_037, 3
+    sp, y0, cells, pr, t2m, dt, nT, q = _case(H, ns=ns, days=days, wet=False, tmin=-5.0)
+    assert len(q) >= 256
+
+    def engine(n):
+        eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, query=q, dense_tiled=2, dense_sub_windows=n)
+        eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+        return eng
+    e1 = engine(1)
+    e1.integrate()
+    one = e1.results()
+    assert 0.02 < (one["stiff"] == 1).mean() < 0.98
+    e0 = engine(0)
+    e0.dense.fill_(-7.0)
+    e0.integrate()
+    got = e0.results()
+    for k in ("dense", "y_final", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(got[k], one[k]), k
+    # streamed windows in the TILE layout (stream path 2: the transposing transfer kernel writes pinned host memory), so
+    # that every window launch is itself a candidate for the automatic rule; path 0 (linear windows) for comparison
+    for path, W in ((2, 300), (2, 200), (0, 300)):
+        H._lib.lib().hlm_set_stream_path(path)
+        try:
+            e = engine(0)
+            host, _ = e.integrate_streamed(W)
+        finally:
+            H._lib.lib().hlm_set_stream_path(0)
+        assert np.array_equal(host, one["dense"]), (path, W)
+        r = e.results()
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(r[k], one[k]), (path, W, k)

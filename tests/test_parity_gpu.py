@@ -870,9 +870,10 @@ def test_negative_capacities_disable_the_no_rain_path(gpu, oracle, math_mode):
     neither they nor the lanes that share a wave with them.  The ordinary hillslopes must meet
     the solver tolerance.  The leaking ones sit on the x3/x4 kinks all the time: a 1000x tighter
     tolerance moves the ORACLE's own answer by 1 % there, which the round-off yardstick of conftest.py
-    does not sample (it perturbs rtol and h0 by 1e-12 ... 1e-10) -- they are held to 5 % (round 4: 5e-3
-    until STRICT's correctly rounded powers put one of them 1.6e-2 away: other last bits, another step
-    sequence over the kinks; the worst deviation is printed)."""
+    does not sample (it perturbs rtol and h0 by 1e-12 ... 1e-10) -- they are held to 5e-3 relative, all but at
+    most two of them (of ~100), which may be up to 5 % away (round 4: STRICT's correctly rounded powers put one of
+    them 1.6e-2 away -- other last bits, another step sequence over the kinks; round-4 advisor: keep the tight bound
+    for the bulk).  The worst deviation and the hillslopes beyond the tight bound are printed."""
     H = gpu
     from tiger_hlm_gpu_amd import synth
     ns, days = 320, 3
@@ -890,9 +891,11 @@ def test_negative_capacities_disable_the_no_rain_path(gpu, oracle, math_mode):
     assert_parity(got["y_final"][~odd], ref["y_final"][~odd], "final, ordinary hillslopes")
     assert_parity(got["dense"][~odd], ref["dense"][~odd], "dense, ordinary hillslopes")
     for name in ("y_final", "dense"):
-        worst = float(np.max(np.abs(got[name][odd] - ref[name][odd]) / (1e-9 + 5e-2 * np.abs(ref[name][odd]))))
-        print(f"negative capacities, math {math_mode}, {name}: the leaking hillslopes' worst deviation {worst:.3f} of 1e-9 + 5e-2 |y|")
-        assert worst <= 1.0, (name, worst)
+        rel = (np.abs(got[name][odd] - ref[name][odd]) / (1e-9 + 5e-3 * np.abs(ref[name][odd]))).reshape(int(odd.sum()), -1).max(axis=1)
+        beyond = np.flatnonzero(odd)[rel > 1.0]
+        print(f"negative capacities, math {math_mode}, {name}: the leaking hillslopes' worst deviation {rel.max():.3f} of 1e-9 + 5e-3 |y|; "
+              f"beyond it: {beyond.tolist()}")
+        assert len(beyond) <= 2 and rel.max() <= 10.0, (name, beyond.tolist(), float(rel.max()))
     leak = sp["infil"] < 0
     assert np.all(got["y_final"][leak, 2] > 0) and np.all(got["y_final"][~odd, 2] == 0)
     assert np.array_equal(got["n_attempt"][~odd], ref["n_attempt"][~odd])

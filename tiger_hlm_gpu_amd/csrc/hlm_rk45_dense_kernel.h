@@ -69,6 +69,25 @@ constexpr int DENSE_TILE_COMP = 2;  // [sys/64][q][comp][sys%64]: one 512-byte r
 #ifndef HLM_DENSE_PRIO_LEVEL
 #define HLM_DENSE_PRIO_LEVEL 1
 #endif
+// Experiment knobs (round 5; tools/build_variants.sh + tools/dense_variant_probe.py; the defaults are the product):
+// HLM_EXTRA_SALU / HLM_EXTRA_VALU = n: n more scalar / vector instructions per attempt (results unchanged) -- the slope
+// of the launch time against the instruction count of each kind, i.e. what a diet of as many would buy.
+// HLM_SEL_KMAX = k > 0: the output-selecting instances hold rows of at most k components (ring slot of k + 1 columns
+// instead of N_EQ) and are built for HLM_SEL_WAVES waves per SIMD.
+#ifndef HLM_EXTRA_SALU
+#define HLM_EXTRA_SALU 0
+#endif
+#ifndef HLM_EXTRA_VALU
+#define HLM_EXTRA_VALU 0
+#endif
+#ifndef HLM_SEL_KMAX
+#define HLM_SEL_KMAX 0
+#endif
+#ifndef HLM_SEL_WAVES
+#define HLM_SEL_WAVES HLM_MIN_WAVES_PER_SIMD
+#endif
+#define HLM_STR2(x) #x
+#define HLM_STR(x) HLM_STR2(x)
 
 // rows r .. n-1 of a flush: `cur` holds row r (already read from the ring)
 template <int r, int R, int N, class Load, class Store>
@@ -117,12 +136,14 @@ __device__ __forceinline__ void dense_ring_tile(const Rk45Args& A, const unsigne
 
     using lds_double_ptr = __attribute__((address_space(3))) double*;
     // doubles per ring slot: N_EQ x 64, or (HLM_RING_POW2) the next power of two, so that a slot's offset is a shift
+    constexpr int RING_COLS = (SEL && HLM_SEL_KMAX > 0 && HLM_SEL_KMAX < NEQ) ? HLM_SEL_KMAX + 1 : NEQ;   // columns of a ring slot
 #if HLM_RING_POW2
-    constexpr int SLOT = (NEQ * WAVE <= 64) ? 64 : (NEQ * WAVE <= 128) ? 128 : (NEQ * WAVE <= 256) ? 256 : (NEQ * WAVE <= 512) ? 512 : 1024;
+    constexpr int SLOT = (RING_COLS * WAVE <= 64) ? 64 : (RING_COLS * WAVE <= 128) ? 128 : (RING_COLS * WAVE <= 256) ? 256 : (RING_COLS * WAVE <= 512) ? 512 : 1024;
 #else
-    constexpr int SLOT = NEQ * WAVE;
+    constexpr int SLOT = RING_COLS * WAVE;
 #endif
-    static_assert(SLOT >= NEQ * WAVE, "a ring slot holds one row of the wave");
+    static_assert(SLOT >= RING_COLS * WAVE, "a ring slot holds one row of the wave");
+    if (SEL && RING_COLS < NEQ && A.dense_k >= RING_COLS) return;   // (experiment builds: a wider selection does not fit this instance)
     __shared__ double ring_mem[R * SLOT];  // [row % R][comp][lane]
     __shared__ double lds_query[DENSE_QWIN];     // sliding window of query times (see rk45_multi_kernel)
     const lds_double_ptr ring = (lds_double_ptr)ring_mem + lane;
@@ -151,7 +172,7 @@ __device__ __forceinline__ void dense_ring_tile(const Rk45Args& A, const unsigne
     // ring column of component c (SEL: its position in the row, or the spare last column -- dense_k < N_EQ)
     [[maybe_unused]] int col[NEQ];
 #pragma unroll
-    for (int c = 0; c < NEQ; ++c) col[c] = SEL ? (A.dense_pos[c] < 0 ? NEQ - 1 : A.dense_pos[c]) * WAVE : c * WAVE;
+    for (int c = 0; c < NEQ; ++c) col[c] = SEL ? (A.dense_pos[c] < 0 ? RING_COLS - 1 : A.dense_pos[c]) * WAVE : c * WAVE;
 
     // live: still integrating in this launch.  Not live = reached tf, flagged, capped, paused at
     // t_stop ("stuck": it continues in the next launch), or finished in an earlier launch.
@@ -250,6 +271,12 @@ __device__ __forceinline__ void dense_ring_tile(const Rk45Args& A, const unsigne
             progress = 1;
             if (t + h > tf) h = tf - t;  // rk45_kernel.cu:54
             ++n_attempt;  // (the forcing samples held for this t were fetched before the loop or in (B'))
+#if HLM_EXTRA_SALU > 0
+            { unsigned int dummy_s = 0; asm volatile(".rept " HLM_STR(HLM_EXTRA_SALU) "\n s_add_u32 %0, %0, 1\n .endr" : "+s"(dummy_s) : : "scc"); }
+#endif
+#if HLM_EXTRA_VALU > 0
+            { unsigned int dummy_v = (unsigned)lane; asm volatile(".rept " HLM_STR(HLM_EXTRA_VALU) "\n v_add_u32 %0, %0, 1\n .endr" : "+v"(dummy_v)); }
+#endif
             double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ];
             [[maybe_unused]] double err = 0.0, jump = 0.0;
             attempt_on_cheapest_path<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
@@ -491,7 +518,7 @@ __device__ __forceinline__ void dense_ring_tile(const Rk45Args& A, const unsigne
 
 // One wave per tile for the launch's whole query window (grid = ceil(ns / 64)).
 template <class Model, int MATH, bool FIXED, bool RESUMABLE, int R, bool SEL = false>
-__global__ void __launch_bounds__(WAVE, HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
+__global__ void __launch_bounds__(WAVE, SEL ? HLM_SEL_WAVES : HLM_MIN_WAVES_PER_SIMD) rk45_dense_ring_kernel(const Rk45Args A)
 {
     // XCD-aware block -> hillslope-chunk map (see rk45_multi_kernel)
     const unsigned nblk = gridDim.x, orig = blockIdx.x;
