@@ -90,6 +90,8 @@ def parse():
                     help="static-store capacities: default = SURVEY's U[50, 300] (never overflows); active-surface = SURVEY's "
                          "U[0.005, 0.05] as written (overflows in the first minutes, most hillslopes flagged there); saturating = "
                          "log-uniform over synth.SATURATING_HU from a settled start (the storms fill the store again and again)")
+    ap.add_argument("--hybrid", type=int, default=0, choices=[-1, 0, 1],
+                    help="hlm_device_job.queue_hybrid: 1 = waves holding saturated lanes run one block of general stages, -1 = a block per RHS form, 0 = automatic")
     ap.add_argument("--attempt-cap", type=int, default=0, help="attempts per hillslope at most (0 = the library's 2^24)")
     ap.add_argument("--tmin", type=float, default=0.5,
                     help="lower end of the daily temperatures; -5 is SURVEY 8d's C3 generator (cold cells get flagged stiff)")
@@ -153,7 +155,7 @@ def build_engine(args, rank, world, wet, math=None, tmin=0.5):
                       math_mode=H.MATH_FAST if (math or args.math) == "fast" else H.MATH_STRICT,
                       device=f"cuda:{torch.cuda.current_device()}", dense_tiled=args.dense_tiled,
                       time_pieces=None if args.time_pieces < 0 else args.time_pieces, attempt_cap=args.attempt_cap,
-                      queue_run_pieces=args.queue_run_pieces, queue_group_tiles=args.group_tiles)
+                      queue_run_pieces=args.queue_run_pieces, queue_group_tiles=args.group_tiles, queue_hybrid=args.hybrid)
     if args.layout == "per-stream":
         eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     else:
@@ -192,7 +194,7 @@ def _issue_fields(per_gpu_key):
 
 def _per_gpu_key(args, nq, ns):
     """What one GPU's launch looks like (independent of the number of ranks)."""
-    extra = (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (f";runs={args.queue_run_pieces}" if args.queue_run_pieces else "") + (f";group={args.group_tiles}" if args.group_tiles else "") + (";wet" if args.wet_surface else "") + (f";hu={args.hu}" if args.hu != "default" else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
+    extra = (f";pieces={args.time_pieces}" if args.time_pieces >= 0 else "") + (f";runs={args.queue_run_pieces}" if args.queue_run_pieces else "") + (f";group={args.group_tiles}" if args.group_tiles else "") + (";wet" if args.wet_surface else "") + (f";hu={args.hu}" if args.hu != "default" else "") + (f";hybrid={args.hybrid}" if args.hybrid else "") + (f";tmin={args.tmin:g}" if args.tmin != 0.5 else "") + (";radau" if args.radau else "") + (";continue" if args.radau and args.radau_continue else "")
     return f"ns={ns};days={args.days};layout={args.layout};nq={nq};math={args.math}{extra}"
 
 
@@ -1045,6 +1047,15 @@ def main():
                 e.queue_group_tiles = 8
                 _, kg, _ = timed_passes(e, total, 1, 1, 2)
                 res["kernel_ms_queue_group_tiles_8"] = float(np.mean(kg))
+                # ... and the waves that hold saturated lanes running ONE block of general stages (hlm_device_job.queue_hybrid = 1:
+                # opt-in, two waves per SIMD instead of three -- it costs the headline workload 18 %)
+                e.queue_hybrid = 1
+                _, kh8, _ = timed_passes(e, total, 1, 1, 2)
+                e.queue_group_tiles = 0
+                _, kh, _ = timed_passes(e, total, 1, 1, 2)
+                res["kernel_ms_hybrid"] = float(np.mean(kh))
+                res["kernel_ms_hybrid_queue_group_tiles_8"] = float(np.mean(kh8))
+                e.queue_group_tiles = 8
                 # ... and the whole job: the Radau pass continuing every flagged hillslope from where RK45 left it
                 e.integrate(radau="continue")
                 torch.cuda.synchronize()

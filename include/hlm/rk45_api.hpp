@@ -145,6 +145,9 @@ inline void set_time_pieces(int pieces) { detail::check(hlm_set_time_pieces(piec
 // 0 = automatic, n = runs of n pieces, -n = automatic with runs of at most n; group_tiles G > 1 = the hillslopes of G
 // tiles that are still integrating share full waves -- for domains that lose hillslopes to the stiff flag.  Same results.
 inline void set_queue_shape(int run_pieces, int group_tiles) { detail::check(hlm_set_queue_shape(run_pieces, group_tiles), "set_queue_shape"); }
+// hlm_set_queue_hybrid: 1 = waves that hold saturated hillslopes run one block of general stages for all their lanes (domains
+// whose static stores the storms fill: -14 ... -19 %; +18 % where they never overflow), -1 / 0 = a block per RHS form.  Same results.
+inline void set_queue_hybrid(int mode) { detail::check(hlm_set_queue_hybrid(mode), "set_queue_hybrid"); }
 
 // ---- 1) allocate device buffers & copy inputs ------------------------------------------------
 template <class Model>

@@ -113,6 +113,10 @@ int hlm_set_time_pieces(int pieces);
  * hillslopes to the stiff flag: SURVEY's cold C3 runs its RK45 pass in 99 ms with (0, 8) against 118 ms with (0, 0)).
  * Results do not depend on either. */
 int hlm_set_queue_shape(int run_pieces, int group_tiles);
+/* (ABI 5) hlm_device_job.queue_hybrid of the host API's launches in time pieces: 1 = waves that hold saturated hillslopes
+ * run one block of general stages for all their lanes (domains whose static stores the storms fill: -14 ... -19 %;
+ * +18 % on domains where they never overflow: two waves per SIMD instead of three), -1 / 0 = a block per RHS form. */
+int hlm_set_queue_hybrid(int mode);
 /* 1: hlm_launch_rk45_kernel / hlm_run_rk45 follow the RK45 pass with the Radau-IIA pass below
  * (what rk45_api.hpp:189-247 attempts inside retrieve_and_free), every flagged system restarting at t0 as
  * radau_kernel.cu:44-52 does; 2: the same pass CONTINUING from the state each flagged system had reached
@@ -309,6 +313,16 @@ typedef struct hlm_device_job {
      * launch in time pieces, FAST arithmetic, adaptive steps, queue_group_tiles <= 1 (else HLM_ERR_INVALID_ARGUMENT).
      * Results are those of the plain instance bit for bit; bench.py's saturating variants read it. */
     uint64_t* d_path_counts;
+    /* (ABI 5) How a wave of the queue kernel integrates an attempt when its lanes need DIFFERENT forms of the RHS (FAST
+     * arithmetic; Model 204: unsaturated with a dry / a wet surface store, each with the two draining stores in closed
+     * form, and the general RHS once the static store overflows).  -1: a block per form present in the wave, each under
+     * its lanes' mask, and a lane that overflows inside the step computed twice (rounds 3-4).  1: a wave that held a
+     * saturated lane in its previous attempt and holds one now runs ONE block -- the general RHS through the seven
+     * stages for every lane -- and every lane keeps the result of its own form (the closed-form values where it
+     * qualifies for them): capacities the storms fill, where 40 % of the wave-attempts ran several blocks.  Same bits,
+     * lane by lane.  0: automatic = -1 (the one-block instances need two waves per SIMD instead of three: measured
+     * -14 ... -19 % where the storms fill the stores, +18 % where they never overflow; csrc/hlm_abi.hip: launch_queue). */
+    int queue_hybrid;
 } hlm_device_job;
 #define HLM_PATH_COUNTERS 7
 

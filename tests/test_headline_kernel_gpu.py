@@ -36,9 +36,9 @@ def gpu(hlm):
     return hlm
 
 
-def _engine_run(H, y0, tf, sp, forcing, math_mode, time_pieces, query=None, per_cell=False, attempt_cap=0, count_paths=False):
+def _engine_run(H, y0, tf, sp, forcing, math_mode, time_pieces, query=None, per_cell=False, attempt_cap=0, count_paths=False, **kw):
     from tiger_hlm_gpu_amd.engine import ShardEngine
-    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=query, math_mode=math_mode, time_pieces=time_pieces, attempt_cap=attempt_cap)
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=query, math_mode=math_mode, time_pieces=time_pieces, attempt_cap=attempt_cap, **kw)
     pr, t2m, cells, dt, nT = forcing
     if per_cell:
         eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
@@ -248,6 +248,25 @@ def test_saturating_workload_runs_the_general_rhs_and_the_counting_instance_chan
     with pytest.raises(H.HlmError):   # the counters exist for the queue kernel in FAST arithmetic only: refused, not ignored
         _engine_run(H, h["y0"][:4096], h["tf"], h["sp"][:4096], (h["forcing"][0], h["forcing"][1], h["forcing"][2][:4096], h["forcing"][3], h["forcing"][4]),
                     H.MATH_STRICT, None, count_paths=True)
+
+
+@pytest.mark.parametrize("name", ["intermittent-50k", "sat-10k", "mixed-10k", "wet-10k", "c3-50k"])
+def test_hybrid_waves_hold_the_bits_of_the_per_form_blocks(gpu, oracle, name):
+    """hlm_device_job.queue_hybrid = 1: a wave that holds saturated lanes runs ONE block of general stages for all its
+    lanes and every lane keeps the result of its own RHS form (rk_attempt_hybrid) -- finals, flags and both counters of
+    every hillslope equal the instance that runs a block per form (queue_hybrid = -1) BIT FOR BIT: on capacities the
+    storms fill (a tenth of the lane-attempts general, 40 % of the wave-attempts mixed), on SURVEY's active-surface
+    draw, with wet and dry surfaces mixed inside the waves, and on the headline workload (where the switch never
+    trips); also with the survivors of 8 tiles packed per piece."""
+    H = gpu
+    c = _case(oracle, name)
+    cap = SATURATING_CAP if name in SATURATING_CASES else 0
+    a, pieces = _engine_run(H, c["y0"], c["tf"], c["sp"], c["forcing"], H.MATH_FAST, None, attempt_cap=cap, queue_hybrid=-1)
+    assert pieces == 32
+    for kw in (dict(queue_hybrid=1), dict(queue_hybrid=1, queue_group_tiles=8)):
+        b, _ = _engine_run(H, c["y0"], c["tf"], c["sp"], c["forcing"], H.MATH_FAST, None, attempt_cap=cap, **kw)
+        for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(a[k], b[k]), (name, kw, k, int((a[k] != b[k]).sum()))
 
 
 def test_no_dense_launch_shapes_agree_bitwise_on_these_cases(gpu, oracle):

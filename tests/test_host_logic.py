@@ -19,7 +19,7 @@ def _declared_functions():
 
 def test_library_exports_every_declared_symbol(hlm):
     names = _declared_functions()
-    assert len(names) == 49
+    assert len(names) == 50
     lib = C.CDLL(hlm.LIB_PATH)
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/hlm_hip.h but not exported"
@@ -55,7 +55,7 @@ def test_struct_layouts_match_header(hlm, tmp_path):
         assert int(got[cname]) == C.sizeof(ct), cname
         for fname, _ in ct._fields_:
             assert int(got[f"{cname}.{fname}"]) == getattr(ct, fname).offset, (cname, fname)
-    assert len(hlm._lib.DeviceJob._fields_) == 40 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
+    assert len(hlm._lib.DeviceJob._fields_) == 41 and len(hlm._lib.GpuBuffers._fields_) == 13  # (as many as the header has)
 
 
 def test_registry_roundtrip_and_validation_without_gpu(hlm):

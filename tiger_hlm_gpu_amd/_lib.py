@@ -61,7 +61,7 @@ class DeviceJob(C.Structure):
         ("forc_first_index", C.c_uint64 * HLM_MAX_FORCINGS), ("forc_rows", C.c_uint64 * HLM_MAX_FORCINGS),
         ("dense_ncomp", C.c_int), ("dense_comp", C.c_int * HLM_MAX_NEQ),
         ("d_flag_state", C.c_void_p), ("time_pieces", C.c_int), ("queue_run_pieces", C.c_int), ("queue_group_tiles", C.c_int), ("dense_sub_windows", C.c_int),
-        ("d_path_counts", C.c_void_p),
+        ("d_path_counts", C.c_void_p), ("queue_hybrid", C.c_int),
     ]
 
 
@@ -123,6 +123,7 @@ SIGNATURES = {
     "hlm_set_output_states": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "hlm_set_time_pieces": (C.c_int, [C.c_int]),
     "hlm_set_queue_shape": (C.c_int, [C.c_int, C.c_int]),
+    "hlm_set_queue_hybrid": (C.c_int, [C.c_int]),
     "hlm_time_pieces_for": (C.c_int, [C.POINTER(DeviceJob)]),
     "hlm_set_forcings": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64), C.c_int,
                                    C.c_int64, C.c_void_p]),

@@ -117,6 +117,12 @@ def set_queue_shape(run_pieces=0, group_tiles=0):
     check(lib().hlm_set_queue_shape(int(run_pieces), int(group_tiles)))
 
 
+def set_queue_hybrid(mode=0):
+    """hlm_set_queue_hybrid: 1 = waves holding saturated hillslopes run one block of general stages (domains whose static
+    stores the storms fill), -1 / 0 = a block per RHS form (the default)."""
+    check(lib().hlm_set_queue_hybrid(int(mode)))
+
+
 def time_pieces_for(job):
     """The number of time pieces integrate_device(job) launches with (0 = one wave per tile)."""
     return int(lib().hlm_time_pieces_for(C.byref(job)))

@@ -84,6 +84,7 @@ int g_math = HLM_MATH_FAST;
 bool g_math_explicit = false;
 int g_time_pieces = -1;  // hlm_set_time_pieces(): < 0 = automatic (auto_time_pieces)
 int g_queue_run_pieces = 0, g_queue_group_tiles = 0;  // hlm_set_queue_shape(): hlm_device_job.queue_run_pieces / queue_group_tiles of the host API's launches
+int g_queue_hybrid = 0;  // hlm_set_queue_hybrid(): hlm_device_job.queue_hybrid of the host API's launches
 constexpr int kMaxTimePieces = 4096;
 // The automatic launch shape of a run without dense output: from 4 096 hillslopes on, one piece per twelve simulated
 // hours, at most 32 -- and none at all when that makes fewer than 8: FEW pieces cost more than the drain they remove
@@ -253,9 +254,13 @@ DenseQueueFn pick_dense_queue(int uid, int math, bool sel)
 // the persistent kernels over a queue of (time piece, tile) items (hlm_rk45_queue_kernel.h): no dense output
 using QueueFn = void (*)(const hlm::Rk45Args, unsigned int*, int, const hlm::QueueRuns);
 template <class Model>
-QueueFn pick_queue(int math, bool fixed, bool retile, bool count = false)
+QueueFn pick_queue(int math, bool fixed, bool retile, bool count = false, bool hybrid = false)
 {
     using namespace hlm;
+    if (hybrid && !count && !fixed && math == HLM_MATH_FAST) {   // (FAST, adaptive, a model with per-hillslope RHS forms; else the plain instances)
+        if constexpr (Model::HAS_NORAINPATH && Model::NORAIN_LINEAR > 0)
+            return retile ? rk45_queue_kernel<Model, MATH_FAST, false, true, false, true> : rk45_queue_kernel<Model, MATH_FAST, false, false, false, true>;
+    }
     // (the counting instance: FAST, adaptive, tiles as items -- validate_job refuses d_path_counts on anything else)
     if (count) {   // (only a model with per-hillslope RHS forms has anything to count: Model 204)
         if constexpr (Model::HAS_NORAINPATH && Model::NORAIN_LINEAR > 0) return rk45_queue_kernel<Model, MATH_FAST, false, false, true>;
@@ -266,9 +271,9 @@ QueueFn pick_queue(int math, bool fixed, bool retile, bool count = false)
     if (math == HLM_MATH_FAST) return fixed ? rk45_queue_kernel<Model, MATH_FAST, true> : rk45_queue_kernel<Model, MATH_FAST, false>;
     return fixed ? rk45_queue_kernel<Model, MATH_STRICT, true> : rk45_queue_kernel<Model, MATH_STRICT, false>;
 }
-QueueFn pick_queue(int uid, int math, bool fixed, bool retile, bool count = false)
+QueueFn pick_queue(int uid, int math, bool fixed, bool retile, bool count = false, bool hybrid = false)
 {
-    return with_model<QueueFn>(uid, [&](auto m) { return pick_queue<decltype(m)>(math, fixed, retile, count); });
+    return with_model<QueueFn>(uid, [&](auto m) { return pick_queue<decltype(m)>(math, fixed, retile, count, hybrid); });
 }
 
 KernelFn pick(int uid, int math, bool dense, bool fixed, bool resumable = false)
@@ -348,6 +353,7 @@ int validate_job(const hlm_device_job* j)
         (j->math_mode != HLM_MATH_FAST || j->fixed_step > 0.0 || j->queue_group_tiles > 1 || j->num_queries > 0))
         return fail(HLM_ERR_INVALID_ARGUMENT, "d_path_counts: the counting instance is the queue kernel in FAST arithmetic with adaptive "
                                               "steps, no dense output and tiles as items (queue_group_tiles <= 1)");
+    if (j->queue_hybrid < -1 || j->queue_hybrid > 1) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_hybrid must be -1, 0 or 1");
     if (j->use_t_stop && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop needs d_resume");
     if (j->use_t_stop && !(j->t_stop == j->t_stop)) return fail(HLM_ERR_INVALID_ARGUMENT, "t_stop is NaN");
     for (int k = 0; reads_forcings && k < j->nforc; ++k)
@@ -492,7 +498,12 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
 {
     const bool fixed = j->fixed_step > 0.0;
     const int group = j->queue_group_tiles > 1 && !fixed ? j->queue_group_tiles : 1;
-    QueueFn fn = pick_queue(j->uid, j->math_mode, fixed, group > 1, j->d_path_counts != nullptr);
+    // queue_hybrid = 0 (automatic) is "a block per RHS form": the hybrid instances need 252 VGPRs for their four blocks (two
+    // waves per SIMD instead of three; capped at 168 they spill 117 and lose everywhere), which costs the workloads whose
+    // static stores never overflow 18 % (headline 127.4 -> 149.9 ms, wet surface +6 %) and gains 14-19 % where the storms
+    // fill them (369.8 -> 317.0 ms, 261.4 -> 212.2 ms with 8 tiles packed per piece: profiles/r05_hybrid_ab.txt) -- a choice
+    // only the caller, who knows the domain, can make (hlm_set_queue_hybrid / rk45_solver --hybrid).
+    QueueFn fn = pick_queue(j->uid, j->math_mode, fixed, group > 1, j->d_path_counts != nullptr, j->queue_hybrid > 0);
     if (!fn) return fail(HLM_ERR_UNKNOWN_MODEL, "no kernel for UID %d%s", j->uid, j->d_path_counts ? " (d_path_counts: the model has no per-hillslope RHS forms to count)" : "");
     if (windowed && !j->d_resume) return fail(HLM_ERR_INVALID_ARGUMENT, "a window launch needs d_resume");
     int dev = 0, cus = 0, per_cu = 0;
@@ -753,6 +764,7 @@ int fill_job_from_registry(hlm_device_job* j, int uid, const ForcingState& F)
     j->time_pieces = g_time_pieces;  // (< 0: resolved by the caller once it knows the number of systems)
     j->queue_run_pieces = g_queue_run_pieces;
     j->queue_group_tiles = g_queue_group_tiles;
+    j->queue_hybrid = g_queue_hybrid;
     j->math_mode = g_math;
     if (!g_math_explicit && !(m->p[2] >= 1e-60 && m->p[2] <= 1e50)) j->math_mode = HLM_MATH_STRICT;
     j->d_forc = F.d_forc;
@@ -993,6 +1005,14 @@ int hlm_set_queue_shape(int run_pieces, int group_tiles)
     std::lock_guard<std::mutex> lk(g_mu);
     g_queue_run_pieces = run_pieces;
     g_queue_group_tiles = group_tiles;
+    return HLM_SUCCESS;
+}
+
+int hlm_set_queue_hybrid(int mode)
+{
+    if (mode < -1 || mode > 1) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_hybrid must be -1, 0 or 1");
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_queue_hybrid = mode;
     return HLM_SUCCESS;
 }
 

@@ -304,6 +304,22 @@ struct Model204Dev {
     {
         (void)rhs_impl<MATH, false>(P, F, y, dydt);
     }
+    // For the hybrid attempt (rk_attempt_hybrid): may this hillslope take an unsaturated form at all (norainpath_ok ||
+    // wetupath_ok), is its static store overflowing at this state under the held forcing -- the test rhs_norain and
+    // rhs_wetu make in every call, same expression, same decision -- and the general RHS reporting that test.
+    static __device__ __forceinline__ bool unsat_eligible(const Local& P, const double (&y)[N_EQ]) { return y[2] >= 0.0 && P.nonneg; }
+    static __device__ __forceinline__ bool saturated_at(const Local& P, const Forc& F, const double (&y)[N_EQ])
+    {
+        const double snowmelt = __longlong_as_double(__double_as_longlong(vmin(y[0], F.melt_pot)) & (long long)F.warm_mask);
+        const double x1 = F.rain + snowmelt;
+        return x1 + y[1] > P.Hu;
+    }
+    template <int MATH>
+    static __device__ __forceinline__ bool rhs_report_wet(const Local& P, const Forc& F, const double (&y)[N_EQ], double (&dydt)[N_EQ])
+    {
+        (void)rhs_impl<MATH, false>(P, F, y, dydt);
+        return saturated_at(P, F, y);   // (the same sub-expressions as inside the RHS: formed once)
+    }
     template <int MATH>
     static __device__ __forceinline__ bool rhs_fast(const Local& P, const Forc& F, const double (&y)[N_EQ],
                                                     double (&dydt)[N_EQ])

@@ -222,6 +222,9 @@ __device__ __forceinline__ void record_flag_state(double* flag_state, int sys, c
 // drains: -h w(h)), nothing is pinned, the cascade below the static store is idle as on PATH_NORAIN.  Only the
 // per-lane selection (attempt_per_lane_path) takes it.
 constexpr int PATH_GENERAL = 0, PATH_DRY = 1, PATH_NORAIN = 2, PATH_WETU = 3;
+// PATH_GENERAL_WET: Model::rhs as PATH_GENERAL, and the return value tells whether any evaluated stage found the static
+// store overflowing (Model::rhs_report_wet) -- what PATH_NORAIN / PATH_WETU report as "left the regime" (rk_attempt_hybrid)
+constexpr int PATH_GENERAL_WET = 4;
 constexpr bool path_pins(int path) { return path == PATH_DRY || path == PATH_NORAIN; }
 
 // index of the c-th moving component when component Z is pinned (identity for Z >= N)
@@ -257,6 +260,7 @@ __device__ __forceinline__ bool rk_stages(const typename Model::Local& P, const 
         if constexpr (PATH == PATH_NORAIN) broke |= Model::template rhs_norain<MATH>(P, FV, state, slope);
         else if constexpr (PATH == PATH_WETU) broke |= Model::template rhs_wetu<MATH>(P, FV, state, slope);
         else if constexpr (PATH == PATH_DRY) broke |= Model::template rhs_fast<MATH>(P, FV, state, slope);
+        else if constexpr (PATH == PATH_GENERAL_WET) broke |= Model::template rhs_report_wet<MATH>(P, FV, state, slope);
         else Model::template rhs<MATH>(P, FV, state, slope);
     };
     // components that stand still in the stage states: the pinned one, and (CLOSED) the linear ones, whose slopes the
@@ -510,6 +514,135 @@ __device__ __forceinline__ void attempt_per_lane_path(const typename Model::Loca
         }
         if (general) rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
     }
+    have_k0 = true;
+}
+
+// ---- one attempt on the GENERAL stages for the whole wave, every lane keeping the result of ITS form -------------------
+// attempt_per_lane_path runs a block per RHS form present in the wave, each under its lanes' mask, and a lane that
+// leaves its unsaturated form inside the step is computed twice: on capacities the storms fill (10 % of the
+// lane-attempts on the general RHS, all of them computed twice; 40 % of the wave-attempts on several forms) a
+// wave-attempt costs 726 VALU instructions against 476 of the wet unsaturated form alone (profiles/r05_pmc_issue.json).
+// Here the wave runs ONE block: the general RHS through all seven stages for every lane -- for an unsaturated lane its
+// snow / static / surface stores see exactly the operations of its own form (the idle cascade contributes literal
+// zeros; the stage-wise forms agree with the general one bit for bit, tests) -- plus the closed form of the two
+// draining stores, and each lane keeps what attempt_per_lane_path would have given it: the closed-form values if it
+// qualifies for an unsaturated form and no stage found its static store overflowing (the regime test of rhs_norain /
+// rhs_wetu, Model::saturated_at) and the carried k0 is that form's, the stage values otherwise.  Same bits per lane,
+// whatever its neighbours do.  FAST arithmetic, models with linear stores (Model 204).
+template <class Model, int MATH, bool FIXED>
+__device__ __forceinline__ void rk_attempt_hybrid(const typename Model::Local& P, const typename Model::Forc& FV, const Rk45Args& A,
+                                                  const double (&y)[Model::N_EQ], double h, bool have_k0, double (&k0)[Model::N_EQ],
+                                                  double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ], double (&k3)[Model::N_EQ],
+                                                  double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ], double (&k6)[Model::N_EQ],
+                                                  double (&yt)[Model::N_EQ], double& err, double& jump)
+{
+    using namespace dp;
+    constexpr int NEQ = Model::N_EQ, NL = Model::NORAIN_LINEAR;
+    static_assert(MATH == MATH_FAST && NEQ == 5 && NL > 0, "the forms this replaces exist in FAST arithmetic for the 5-store model");
+    const bool wet_any = rk_stages<Model, MATH, PATH_GENERAL_WET, false>(P, FV, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt);
+    // would attempt_per_lane_path have kept this lane's closed-form attempt?  (its `broke`, term by term)
+    bool closed_ok = Model::unsat_eligible(P, y) && !wet_any;
+    if (y[Model::FAST_ZERO_COMP] == 0.0) closed_ok = closed_ok && k0[Model::FAST_ZERO_COMP] == 0.0;   // (the dry-surface form pins that store)
+#pragma unroll
+    for (int k = 0; k < NL; ++k)   // (a slope carried over from a general attempt may hold an inflow the closed form does not have)
+        closed_ok = closed_ok && k0[Model::NORAIN_LINEAR_COMP[k]] == Model::norain_rate(P, k) * y[Model::NORAIN_LINEAR_COMP[k]];
+    double e_lin[NL], j_lin[NL];
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const int i = Model::NORAIN_LINEAR_COMP[k];
+        const double lam = Model::norain_rate(P, k), z = lam * h, z2 = z * z, z5 = z2 * z2 * z;
+        double q = __builtin_fma(LIN_R[6], z, LIN_R[5]);
+        q = __builtin_fma(q, z, LIN_R[4]);
+        q = __builtin_fma(q, z, LIN_R[3]);
+        q = __builtin_fma(q, z, LIN_R[2]);
+        q = __builtin_fma(q, z, LIN_R[1]);
+        const double yc = __builtin_fma(y[i], q * z, y[i]);   // y R(z): rk_stages, CLOSED
+        e_lin[k] = (y[i] * z5) * __builtin_fma(__builtin_fma(LIN_E7, z, LIN_E6), z, LIN_E5);
+        j_lin[k] = k0[i] * (A10 * z);
+        // (k6 of the closed form: the unsaturated RHS at the new state, 0 - y / alpha = lam y)
+        if (closed_ok) { yt[i] = yc; k6[i] = lam * yc; }
+    }
+    if constexpr (!FIXED) {
+        const double he0 = h * E0, he2 = h * E2, he3 = h * E3, he4 = h * E4, he5 = h * E5, he6 = h * E6;
+        double e[NEQ], tl[NEQ];
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) {
+            e[i] = lc(he0 * k0[i], he2, k2[i], he3, k3[i], he4, k4[i], he5, k5[i], he6, k6[i]);
+            tl[i] = __builtin_fma(A.rtol, vmax_abs(y[i], yt[i]), A.atol);
+        }
+        jump = 0.0;
+        double jd[NEQ];
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) jd[i] = k0[i] - k1[i];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int i = Model::NORAIN_LINEAR_COMP[k];
+            e[i] = closed_ok ? e_lin[k] : e[i];
+            jd[i] = closed_ok ? j_lin[k] : jd[i];
+        }
+        const double a = tl[0] * tl[1], b = tl[2] * tl[3];
+        const double ab = a * b, all = ab * tl[4], bt4 = b * tl[4], at4 = a * tl[4];
+        const double others[NEQ] = {tl[1] * bt4, tl[0] * bt4, tl[3] * at4, tl[2] * at4, ab};
+        double num = 0.0;
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) num = vmax_abs2(num, e[i] * others[i]);
+        err = num * fast_rcp(all);
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) jump = vmax_abs2(jump, jd[i]);
+    }
+}
+
+// attempt_per_lane_path for waves that may hold saturated lanes (the HYBRID instances of the queue kernel).  wave_sat
+// (wave-uniform, the caller's; false at the start of an item): some lane of this wave needed the general RHS in its
+// previous attempt.  While it is clear the attempt is attempt_per_lane_path's, unchanged -- the headline workload never
+// sets it.  Once set, the wave asks before every attempt whether a lane's static store overflows at its CURRENT state
+// (or cannot take an unsaturated form at all): if so the whole wave runs rk_attempt_hybrid, one block instead of up to
+// three; if not, the per-lane blocks again (a lane may still overflow inside the step: recomputed as before).
+template <class Model, int MATH, bool FIXED>
+__device__ __forceinline__ void attempt_per_lane_path_hybrid(const typename Model::Local& P, const typename Model::Forc& FV,
+                                                             const Rk45Args& A, const double (&y)[Model::N_EQ], double h, bool& have_k0,
+                                                             double (&k0)[Model::N_EQ], double (&k1)[Model::N_EQ], double (&k2)[Model::N_EQ],
+                                                             double (&k3)[Model::N_EQ], double (&k4)[Model::N_EQ], double (&k5)[Model::N_EQ],
+                                                             double (&k6)[Model::N_EQ], double (&yt)[Model::N_EQ], double& err, double& jump,
+                                                             bool& wave_sat)
+{
+    if (wave_sat) {
+        const bool needs_general = !Model::unsat_eligible(P, y) || Model::saturated_at(P, FV, y);
+        if (__builtin_amdgcn_ballot_w64(needs_general) != 0ull) {
+            rk_attempt_hybrid<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+            have_k0 = true;
+            return;   // (wave_sat stays set: the next attempt asks again)
+        }
+    }
+    bool stagewise = true;
+    if (Model::norainpath_ok(P, FV, y)) {
+        const bool had_k0 = have_k0;
+        const bool broke = rk_attempt<Model, MATH, PATH_NORAIN, FIXED, true>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        stagewise = broke;
+        have_k0 = broke ? had_k0 : true;
+    }
+    else if (Model::wetupath_ok(P, FV, y)) {
+        const bool had_k0 = have_k0;
+        const bool broke = rk_attempt<Model, MATH, PATH_WETU, FIXED, true>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+        stagewise = broke;
+        have_k0 = broke ? had_k0 : true;
+    }
+    bool ran_general = false;
+    if (stagewise) {
+        bool general = true;
+        if constexpr (Model::HAS_FASTPATH) {
+            if (__builtin_amdgcn_ballot_w64(!Model::fastpath_ok(y)) == 0ull) {
+                const bool broke = rk_attempt<Model, MATH, PATH_DRY, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+                have_k0 = true;
+                general = __builtin_amdgcn_ballot_w64(broke) != 0ull;
+            }
+        }
+        if (general) {
+            rk_attempt<Model, MATH, PATH_GENERAL, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
+            ran_general = true;
+        }
+    }
+    wave_sat = __builtin_amdgcn_ballot_w64(ran_general) != 0ull;
     have_k0 = true;
 }
 

@@ -133,8 +133,10 @@ __global__ void queue_init_kernel(unsigned int* __restrict__ queue, unsigned int
 // (hlm_device_job.queue_group_tiles).  The plain instances (RETILE = false) carry none of that code: the headline
 // kernel's register allocation is sensitive to it (+1 ... 5 % with it compiled in).
 // COUNT: the diagnostic instances that also count lane-attempts per RHS form (Rk45Args.path_counts; LanePathCount).
-template <class Model, int MATH, bool FIXED, bool RETILE = false, bool COUNT = false>
-__global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
+// HYBRID: the instances whose attempt is attempt_per_lane_path_hybrid -- a wave that holds saturated lanes runs ONE
+// block of general stages for all its lanes instead of a block per RHS form (hlm_device_job.queue_hybrid; same bits).
+template <class Model, int MATH, bool FIXED, bool RETILE = false, bool COUNT = false, bool HYBRID = false>
+__global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !HYBRID) ? HLM_MIN_WAVES_PER_SIMD_LEAN : HLM_MIN_WAVES_PER_SIMD)
     rk45_queue_kernel(const Rk45Args A, unsigned int* __restrict__ queue, int nchunk, const QueueRuns R)
 {
     using namespace dp;
@@ -284,6 +286,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                     bool have_k0 = false;  // k0 = rhs(t, y, F) is a pure function: recomputed, it has the bits of the carried one
                     double k0[NEQ];
                     [[maybe_unused]] typename std::conditional<COUNT, LanePathCount, int>::type pc{};
+                    [[maybe_unused]] bool wave_sat = false;   // (HYBRID; wave-uniform) a lane of this wave needed the general RHS last time
 
                     // ---- the loop of rk45_multi_kernel, piece by piece --------------------------------------------
                     // lanes pause the first time t reaches the end of their piece (the last piece runs to tf) and go on
@@ -303,6 +306,7 @@ __global__ void __launch_bounds__(WAVE, MATH == MATH_FAST ? HLM_MIN_WAVES_PER_SI
                             double k1[NEQ], k2[NEQ], k3[NEQ], k4[NEQ], k5[NEQ], k6[NEQ], yt[NEQ];
                             [[maybe_unused]] double err = 0.0, jump = 0.0;
                             if constexpr (COUNT) attempt_per_lane_path_counted<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump, pc);
+                            else if constexpr (HYBRID) attempt_per_lane_path_hybrid<Model, MATH, FIXED>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump, wave_sat);
                             else attempt_on_cheapest_path<Model, MATH, FIXED, false>(P, FV, A, y, h, have_k0, k0, k1, k2, k3, k4, k5, k6, yt, err, jump);
                             [[maybe_unused]] double fac = 1.0;
                             if constexpr (!FIXED) {

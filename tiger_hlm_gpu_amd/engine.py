@@ -15,7 +15,7 @@ from .models import Parameters, SP_DTYPE
 class ShardEngine:
     def __init__(self, model, y0, t0, tf, sp=None, query=None, params=None, device="cuda:0",
                  math_mode=_lib.MATH_FAST, fixed_step=0.0, attempt_cap=0, alloc_dense=True,
-                 dense_tiled=2, dense_states=None, time_pieces=None, queue_run_pieces=0, queue_group_tiles=0, dense_sub_windows=0):
+                 dense_tiled=2, dense_states=None, time_pieces=None, queue_run_pieces=0, queue_group_tiles=0, dense_sub_windows=0, queue_hybrid=0):
         _lib.lib()  # fail loudly if the extension is not built
         if not torch.cuda.is_available():
             raise RuntimeError("ShardEngine needs a HIP device (torch.cuda.is_available() is False)")
@@ -35,6 +35,8 @@ class ShardEngine:
         self.queue_group_tiles = int(queue_group_tiles)
         # hlm_device_job.dense_sub_windows: n > 1 = a dense launch (tile layout) as a persistent grid over (sub-window, tile) items
         self.dense_sub_windows = int(dense_sub_windows)
+        # hlm_device_job.queue_hybrid: 1 = waves holding saturated lanes run one block of general stages, -1 = a block per form
+        self.queue_hybrid = int(queue_hybrid)
         # hlm_device_job.d_path_counts (diagnostic): count_paths() allocates the 7 counters and the launches add to them
         self.path_counts = None
         y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, model.N_EQ)
@@ -113,6 +115,7 @@ class ShardEngine:
         j.queue_run_pieces = self.queue_run_pieces
         j.queue_group_tiles = self.queue_group_tiles
         j.dense_sub_windows = self.dense_sub_windows
+        j.queue_hybrid = self.queue_hybrid
         if self.dense is not None or self.nq:
             j.time_pieces = 0
         if self.path_counts is not None:
