@@ -47,7 +47,7 @@ while i < len(text):
                     break
     pback = [ln.strip() for ln in body for h in phdr if re.search(r"s_c?branch\w*\s+%s$" % re.escape(h), ln.strip())]
     pmasked = [b for b in pback if "execz" in b or "execnz" in b or "vcc" in b]
-    counting = bool(re.search(r"ELb[01]ELb[01]ELb1EEEv", name))   # the COUNT instances add their 7 path counters at the end of an item
+    counting = bool(re.search(r"ELb[01]ELb[01]ELb1ELb[01]EEEv", name))   # the COUNT instances (template arguments FIXED, RETILE, COUNT, HYBRID) add their 7 path counters at the end of an item
     ok = not depth3 and 1 <= len(atom) <= (2 + 7 if counting else 2) and hdr is not None and back and not masked and len(phdr) >= 1 and len(pback) >= len(phdr) and not pmasked
     print(("ok  " if ok else "BAD ") + name, "loops<=4" if not depth3 else "DEPTH 5", f"draws={len(atom)}", "item-loop latch:", back,
           "pass / piece loop latches:", pback)
