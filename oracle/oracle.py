@@ -153,7 +153,8 @@ def rk45_dense(y, k, h, theta):
 
 def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT=None,
         params=DEFAULT_PARAMS, forc_stub_f64=None, fixed_step=0.0, attempt_cap=0, nthreads=0,
-        reorder=True, radau=False, radau_only=False, fma=False, radau_continue=False, start_t=None, start_h=None, t_stop=None):
+        reorder=True, radau=False, radau_only=False, fma=False, radau_continue=False, start_t=None, start_h=None, t_stop=None,
+        continue_from=None):
     """Integrate; returns dict(y_final[ns,5], dense[ns,nq,5] (or raw [ns,5,nq]), stiff, n_attempt, n_accept).
 
     radau=True re-integrates the systems RK45 flagged with the Radau-IIA fallback
@@ -162,6 +163,8 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     restarting at t0 (hlm_oracle_job.radau_continue).
     fma=True runs the FMA-contracted build instead: NOT a reference, only the yardstick for how far
     two valid roundings of the same computation separate on this input.
+    continue_from = (t[ns], y[ns, N_EQ]) with radau_only: the Radau pass takes every system over at the GIVEN state (what
+    another implementation's RK45 pass left when it flagged the system), as radau_continue does with the oracle's own.
     start_t / start_h ([ns]) and t_stop: segment replay (hlm_oracle.h) -- every system enters the loop at (start_t, y0)
     with the step start_h and leaves it paused (stiff = PAUSED = 3, state in t_reached / y_reached / h_reached) before
     the first attempt that starts at or after t_stop."""
@@ -211,6 +214,11 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     if t_stop is not None:
         j.use_t_stop, j.t_stop = 1, float(t_stop)
     j.radau_continue = 1 if (radau_continue and not radau_only) else 0
+    if continue_from is not None:
+        assert radau_only, "continue_from hands given states to the Radau pass alone"
+        treach[:] = np.asarray(continue_from[0], dtype=np.float64)
+        yreach[:] = np.asarray(continue_from[1], dtype=np.float64).reshape(ns, n)
+        j.radau_continue = 1
     if radau_only:
         stiff[:] = 1
         yf[:] = 0.0

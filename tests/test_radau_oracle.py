@@ -169,3 +169,27 @@ def test_analytic_jacobian_equals_finite_differences(oracle):
     assert checked > n // 2 and worst < 1e-5, (checked, worst)
     M = np.array([[-0.5, 0, 0, 0, 0], [0.5, -0.9, 0, 0, 0], [0, 0.3, 0, 0, 0], [0, 0.6, 0, -0.4, 0], [0, 0, 0, 0.4, 0]])
     assert np.array_equal(oracle.jacobian(oracle.UID_DUMMY, np.ones(5)), M)
+
+
+def test_radau_pass_from_given_flag_states_equals_the_continue_mode(oracle):
+    """oracle.run(radau_only=True, continue_from=(t, y)): the implicit pass alone, taking every system over at a GIVEN
+    state -- with the states the oracle's own RK45 run reached when it flagged them it must reproduce
+    radau=True, radau_continue=True bit for bit (the GPU test hands it the GPU's flag states instead)."""
+    from tiger_hlm_gpu_amd import synth
+    O = oracle
+    ns, days = 96, 6
+    sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns)
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    tf = days * 1440.0
+    q = synth.minute_queries(0.0, tf, 45.0)
+    kw = dict(sp=sp, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt, forc_nT=nT)
+    plain = O.run(O.UID_204, y0, 0.0, tf, query=q, **kw)
+    ref = O.run(O.UID_204, y0, 0.0, tf, query=q, radau=True, radau_continue=True, **kw)
+    idx = np.flatnonzero(plain["stiff"] == 1)
+    assert 5 < len(idx) < ns
+    own = O.run(O.UID_204, y0[idx], 0.0, tf, query=q, sp=sp[idx], forc=kw["forc"][:, idx], forc_dt_h=dt, forc_nT=nT, radau_only=True,
+                continue_from=(plain["t_reached"][idx], plain["y_reached"][idx]))
+    assert np.array_equal(own["y_final"], ref["y_final"][idx])
+    after = q[None, :] > plain["t_reached"][idx][:, None]
+    assert np.array_equal(own["dense"][after], ref["dense"][idx][after])
