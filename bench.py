@@ -348,6 +348,21 @@ def dense_section(args):
             ms.append(a.elapsed_time(b))
         k = float(np.mean(ms))
         ab = 40.0 * ns2 * len(q2) + ns2 * B_SYS + 4.0 * sum(e2.forc_nT) * ns2
+        # HBM bytes of this launch from the committed rocprofv3 PMC passes of the same command (tools/profile_dense.sh:
+        # WRITE_SIZE and FETCH_SIZE in separate passes, KiB; FETCH_SIZE doubled on gfx950, MI355X_MICROARCH.md "HBM")
+        dtraffic, dwrite_ratio, dsrc = None, None, None
+        if ns2 == 1_000_000:
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_dense_pmc.json")), reverse=True):
+                try:
+                    pj = json.load(open(path))
+                except Exception:
+                    continue
+                if "WRITE_SIZE" in pj and "FETCH_SIZE" in pj:
+                    wr, rd = pj["WRITE_SIZE"] * 1024.0, pj["FETCH_SIZE"] * 1024.0 * 2.0
+                    dtraffic, dwrite_ratio = wr + rd, wr / (40.0 * ns2 * len(q2))
+                    dsrc = "not measured in this run: rocprofv3 --pmc passes committed as profiles/%s (tools/profile_dense.sh)" % os.path.basename(path)
+                    break
         out["in_hbm_kernel"] = {
             "workload": f"Model 204, {ns2} hillslopes, {days2} day, query every 1 min (nq={len(q2)}): {40.0 * ns2 * len(q2) / 1e9:.1f} GB "
                         "of rows kept in HBM, tile layout, wave-synchronous stores",
@@ -355,6 +370,7 @@ def dense_section(args):
             "steps_per_s": e2.total_attempts() / (k * 1e-3),
             "roofline": {"bound": "hbm", "achieved": ab / (k * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
                          "frac": ab / (k * 1e-3) / 1e9 / PEAK_HBM_GBS, "algorithmic_bytes": ab,
+                         "traffic": dtraffic, "write_size_over_algorithmic_rows": dwrite_ratio, "traffic_source": dsrc,
                          "kernel": "hlm::rk45_dense_ring_kernel<Model204Dev>",
                          "note": "write-only traffic; NOT measured in this run: a pure fill of the same bytes reached 4.8 TB/s "
                                  "on an MI355X of this pool (tools/hbm_write_probe.py, profiles/r02_hbm_write_probe.txt)"}}
