@@ -319,6 +319,18 @@ def dense_section(args):
                                          "kernel_ms_sum": st1["kernel_ms"], "d2h_ms_sum": st1["copy_ms"],
                                          "wall_speedup_vs_all_states": st["wall_ms"] / st1["wall_ms"]}}
     out["dense_output_MBps"] = out["streamed"]["dense_output_MBps"]
+    # the same rows through the sharded C entry (hlm_run_rk45_sharded_streamed: config 5 on the GPUs of a node in one call;
+    # here 8 shards on the one device, one after the other, each through its own windows -- inputs from HOST arrays, upload
+    # included in the wall time): what the per-shard pipeline start-up costs against the single pipeline above
+    def sharded_streamed():
+        forc = (np.ascontiguousarray(pr[:, cells]), np.ascontiguousarray(t2m[:, cells]))
+        t0 = time.perf_counter()
+        _, stt = H.api.run_rk45_sharded_streamed(H.Model204, y0, 0.0, tf, q, W, sp=sp, tables=forc, dt_hours=dt, num_shards=8, num_devices=1, sink=None)
+        wall = time.perf_counter() - t0
+        return {"shards": 8, "devices": 1, "dense_bytes": stt["dense_bytes"], "wall_ms_incl_upload": wall * 1e3, "upload_ms": stt["upload_ms"],
+                "pipeline_ms_sum_over_shards": stt["integrate_ms"], "dense_kernel_ms": stt["dense_kernel_ms"],
+                "dense_output_MBps": stt["dense_bytes"] / (stt["integrate_ms"] * 1e-3) / 1e6}
+    out["sharded_streamed"] = _optional(sharded_streamed)
     del sp, y0, cells
 
     # ---- the dense kernel by itself, output kept in HBM: 1 M hillslopes x 1 day at 1-minute stride (57.6 GB of

@@ -524,13 +524,13 @@ def run_rk45_sharded_streamed(model, y0, t0, tf, query, window_queries, sp=None,
         except Exception as e:  # noqa: BLE001 -- an exception must not cross the C boundary
             errors.append(e)
             return 1
-    cb = _lib.SHARD_WINDOW_SINK(trampoline)
+    cb = _lib.SHARD_WINDOW_SINK(trampoline) if sink is not None else None   # (NULL: the library discards the rows)
     yf = np.empty((ns, neq))
     stiff = np.empty(ns, dtype=np.int32)
     na, nacc = np.empty(ns, dtype=np.uint32), np.empty(ns, dtype=np.uint32)
     st = _lib.ShardedStats()
     rc = lib().hlm_run_rk45_sharded_streamed(C.byref(r), int(num_shards), dev_arr, nd, _ptr(q), int(q.shape[0]), int(window_queries),
-                                             C.cast(cb, C.c_void_p), None, _ptr(yf), _ptr(stiff), _ptr(na), _ptr(nacc), C.byref(st))
+                                             C.cast(cb, C.c_void_p) if cb else None, None, _ptr(yf), _ptr(stiff), _ptr(na), _ptr(nacc), C.byref(st))
     if errors:
         raise errors[0]
     check(rc)

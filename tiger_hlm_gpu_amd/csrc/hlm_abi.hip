@@ -1179,8 +1179,65 @@ int hlm_rk45_integrate_streamed(const hlm_device_job* job, int window_queries, d
     return rc;
 }
 
+// The two device windows, the two pinned staging buffers and the state record of hlm_rk45_integrate_streamed_sink, kept
+// by a caller that runs several such pipelines one after the other on one device (the shards of a device in
+// hlm_run_rk45_sharded_streamed: pinned allocations cost ~0.1 s per GB, 0.6 s of a 1.65 s run of 8 shards) -- they grow
+// to the largest request and are freed by release().
+struct StreamScratch {
+    double* buf[2] = {nullptr, nullptr};
+    double* hbuf[2] = {nullptr, nullptr};
+    void* resume = nullptr;
+    size_t win_bytes = 0, resume_bytes = 0;
+    bool two = false;
+    hipError_t ensure(size_t need_win, bool need_two, size_t need_resume)
+    {
+        hipError_t e = hipSuccess;
+        if (need_win > win_bytes || (need_two && !two)) {
+            const size_t nb = need_win > win_bytes ? need_win : win_bytes;
+            for (int b = 0; b < 2; ++b) {
+                if (buf[b]) (void)hipFree(buf[b]);
+                if (hbuf[b]) (void)hipHostFree(hbuf[b]);
+                buf[b] = hbuf[b] = nullptr;
+            }
+            two = two || need_two;
+            win_bytes = nb;
+            for (int b = 0; b < (two ? 2 : 1) && e == hipSuccess; ++b) {
+                e = hipMalloc((void**)&buf[b], nb);
+                if (e == hipSuccess) e = hipHostMalloc((void**)&hbuf[b], nb, hipHostMallocDefault);
+            }
+        }
+        if (e == hipSuccess && need_resume > resume_bytes) {
+            if (resume) (void)hipFree(resume);
+            resume = nullptr;
+            e = hipMalloc(&resume, need_resume);
+            resume_bytes = e == hipSuccess ? need_resume : 0;
+        }
+        return e;
+    }
+    void release()
+    {
+        for (int b = 0; b < 2; ++b) {
+            if (buf[b]) (void)hipFree(buf[b]);
+            if (hbuf[b]) (void)hipHostFree(hbuf[b]);
+            buf[b] = hbuf[b] = nullptr;
+        }
+        if (resume) (void)hipFree(resume);
+        resume = nullptr;
+        win_bytes = resume_bytes = 0;
+        two = false;
+    }
+};
+static int streamed_sink_impl(const hlm_device_job* job, int window_queries, hlm_window_sink sink, void* user, void* hip_stream,
+                              hlm_stream_stats* stats, StreamScratch* keep);
+
 int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queries, hlm_window_sink sink, void* user,
                                      void* hip_stream, hlm_stream_stats* stats)
+{
+    return streamed_sink_impl(job, window_queries, sink, user, hip_stream, stats, nullptr);
+}
+
+static int streamed_sink_impl(const hlm_device_job* job, int window_queries, hlm_window_sink sink, void* user, void* hip_stream,
+                              hlm_stream_stats* stats, StreamScratch* keep)
 {
     if (!job) return fail(HLM_ERR_INVALID_ARGUMENT, "job is NULL");
     hlm_device_job probe = *job;  // d_dense / window fields of the caller's job are ignored
@@ -1199,24 +1256,22 @@ int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queri
     const size_t win_bytes = (size_t)ns * (size_t)W * row;
 
     hipStream_t compute = static_cast<hipStream_t>(hip_stream), copy = nullptr;
-    double* buf[2] = {nullptr, nullptr};   // device windows [ns][W][K] (host order: one contiguous copy each)
-    double* hbuf[2] = {nullptr, nullptr};  // pinned host staging
-    void* resume = nullptr;
+    StreamScratch own;                      // (a caller's scratch outlives this call; the call's own does not)
+    StreamScratch& sc = keep ? *keep : own;
     hipEvent_t done_k[2] = {nullptr, nullptr}, done_c[2] = {nullptr, nullptr};
     const bool timed = nwin <= kMaxTimedWindows;  // per-window timing events (a run cut into more windows gets wall time only)
     std::vector<hipEvent_t> ev(timed ? (size_t)nwin * 4 : 0, nullptr);
     hipError_t e = hipSuccess;
     auto ok = [&](hipError_t x) { if (e == hipSuccess) e = x; return e == hipSuccess; };
     ok(hipStreamCreateWithFlags(&copy, hipStreamNonBlocking));
+    ok(sc.ensure(win_bytes, nwin > 1, hlm_resume_bytes_model(job->uid, ns)));
+    double* const* buf = sc.buf;    // device windows [ns][W][K] (host order: one contiguous copy each)
+    double* const* hbuf = sc.hbuf;  // pinned host staging
+    void* const resume = sc.resume;
     for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-        if (b == 0 || nwin > 1) {
-            ok(hipMalloc((void**)&buf[b], win_bytes));
-            ok(hipHostMalloc((void**)&hbuf[b], win_bytes, hipHostMallocDefault));
-        }
         ok(hipEventCreateWithFlags(&done_k[b], hipEventDisableTiming));
         ok(hipEventCreateWithFlags(&done_c[b], hipEventDisableTiming));
     }
-    ok(hipMalloc(&resume, hlm_resume_bytes_model(job->uid, ns)));
     for (auto& x : ev) ok(hipEventCreate(&x));
     if (e == hipSuccess) ok(hipStreamSynchronize(compute));  // setup done: the clock starts here
     const auto host_t0 = std::chrono::steady_clock::now();
@@ -1267,12 +1322,10 @@ int hlm_rk45_integrate_streamed_sink(const hlm_device_job* job, int window_queri
     }
     for (auto& x : ev) if (x) (void)hipEventDestroy(x);
     for (int b = 0; b < 2; ++b) {
-        if (buf[b]) (void)hipFree(buf[b]);
-        if (hbuf[b]) (void)hipHostFree(hbuf[b]);
         if (done_k[b]) (void)hipEventDestroy(done_k[b]);
         if (done_c[b]) (void)hipEventDestroy(done_c[b]);
     }
-    if (resume) (void)hipFree(resume);
+    if (!keep) own.release();
     if (copy) (void)hipStreamDestroy(copy);
     if (e != hipSuccess) return fail(HLM_ERR_HIP, "integrate_streamed_sink: %s", hipGetErrorString(e));
     if (sink_rc != 0) return fail(HLM_ERR_STATE, "integrate_streamed_sink: the sink returned %d", sink_rc);
@@ -2356,6 +2409,7 @@ int hlm_run_rk45_sharded_streamed(const hlm_sharded_run* run, int num_shards, co
         auto hip_bad = [&](const char* what, hipError_t e) { D.rc = HLM_ERR_HIP; D.error = std::string(what) + " failed: " + hipGetErrorString(e); };
         if (hipError_t e = hipSetDevice(S.devs[(size_t)d]); e != hipSuccess) return hip_bad("hipSetDevice", e);
         double* d_query = nullptr;
+        StreamScratch scratch;   // the device's windows and pinned staging buffers, shared by its shards
         if (hipError_t e = hipMalloc((void**)&d_query, sizeof(double) * (size_t)num_queries); e != hipSuccess) return hip_bad("hipMalloc(query)", e);
         hipError_t e = hipMemcpyAsync(d_query, h_query_times, sizeof(double) * (size_t)num_queries, hipMemcpyHostToDevice, D.stream);
         for (int s = d; s < num_shards && e == hipSuccess && D.rc == HLM_SUCCESS; s += num_devices) {
@@ -2370,7 +2424,7 @@ int hlm_run_rk45_sharded_streamed(const hlm_sharded_run* run, int num_shards, co
             std::memcpy(j.dense_comp, out_comp, sizeof(out_comp));
             SinkCtx ctx{sink, user, s, sh.start, sh.count};
             hlm_stream_stats st;
-            const int rc1 = hlm_rk45_integrate_streamed_sink(&j, window_queries, tramp, &ctx, D.stream, &st);
+            const int rc1 = streamed_sink_impl(&j, window_queries, tramp, &ctx, D.stream, &st, &scratch);
             if (rc1 != HLM_SUCCESS) { D.rc = rc1; D.error = g_err; break; }   // (g_err is thread-local: this thread's message)
             wall[(size_t)d] += st.wall_ms;
             kern[(size_t)d] += st.kernel_ms;
@@ -2382,6 +2436,7 @@ int hlm_run_rk45_sharded_streamed(const hlm_sharded_run* run, int num_shards, co
             if (e == hipSuccess && h_n_accept) e = hipMemcpy(h_n_accept + o, sh.n_accept, sizeof(uint32_t) * n, hipMemcpyDeviceToHost);
         }
         (void)hipStreamSynchronize(D.stream);
+        scratch.release();
         (void)hipFree(d_query);
         if (e != hipSuccess && D.rc == HLM_SUCCESS) hip_bad("sharded streamed run", e);
     };
