@@ -496,8 +496,10 @@ int hlm_set_sharded_upload(int mode);
 /* The end-of-run gather of hlm_run_rk45_sharded as a LIST (no device is touched): piece k moves `bytes` bytes of
  * shard `shard`'s result array `array` (0 = y_final, N_EQ doubles per hillslope; 1 = stiff; 2 = n_attempt; 3 = n_accept)
  * from rank `from_rank` (= shard % num_devices) into the root's gathered array at byte offset `dst_offset_bytes`
- * (source offset 0: a shard's arrays are its own).  Four pieces per non-empty shard, in shard order; pieces == NULL
- * only counts.  The run builds its ncclSend / ncclRecv group from exactly this list. */
+ * (source offset 0: a shard's arrays are its own).  Four pieces per non-empty shard, in shard order.  pieces == NULL
+ * only counts (*num_pieces = the length of the plan); else *num_pieces holds the number of entries `pieces` has room
+ * for on entry (too few: HLM_ERR_INVALID_ARGUMENT, *num_pieces = the length needed) and the length of the plan on
+ * return.  The run builds its ncclSend / ncclRecv group from exactly this list. */
 typedef struct hlm_gather_piece {
     int shard, from_rank, array;
     uint64_t dst_offset_bytes, bytes;

@@ -577,3 +577,7 @@ def test_gather_plan_covers_every_array_once_for_uneven_shards_over_several_devi
         assert odd, "expected 4-byte pieces at offsets that are not multiples of 8"
     with pytest.raises(hlm.HlmError):
         api.gather_plan(10, 0, 1, 5)
+    # an array that is too short is refused, not overrun; the length needed comes back
+    L = hlm._lib.lib()
+    arr, n = (hlm._lib.GatherPiece * 3)(), C.c_int(3)
+    assert L.hlm_gather_plan(1001, 7, 3, 5, arr, C.byref(n)) == 1 and n.value == 28

@@ -1881,13 +1881,14 @@ int hlm_gather_plan(int num_systems, int num_shards, int num_devices, int neq, h
     if (num_systems < 0 || num_shards < 1 || num_devices < 1 || neq < 1 || neq > HLM_MAX_NEQ || !num_pieces)
         return fail(HLM_ERR_INVALID_ARGUMENT, "gather_plan: %d hillslopes, %d shards, %d devices, N_EQ %d", num_systems, num_shards, num_devices, neq);
     const uint64_t width[4] = {sizeof(double) * (uint64_t)neq, sizeof(int32_t), sizeof(uint32_t), sizeof(uint32_t)};
+    const int capacity = pieces ? *num_pieces : 0;   // (in: entries `pieces` can hold; out: entries of the plan)
     int n = 0;
     for (int s = 0; s < num_shards; ++s) {
         int start = 0, count = 0;
         (void)hlm_shard_bounds(num_systems, num_shards, s, &start, &count);
         if (count == 0) continue;   // (more shards than hillslopes: the empty ones send nothing)
         for (int a = 0; a < 4; ++a, ++n) {
-            if (!pieces) continue;
+            if (!pieces || n >= capacity) continue;
             pieces[n].shard = s;
             pieces[n].from_rank = s % num_devices;
             pieces[n].array = a;
@@ -1896,6 +1897,7 @@ int hlm_gather_plan(int num_systems, int num_shards, int num_devices, int neq, h
         }
     }
     *num_pieces = n;
+    if (pieces && n > capacity) return fail(HLM_ERR_INVALID_ARGUMENT, "gather_plan: %d pieces, the array holds %d", n, capacity);
     return HLM_SUCCESS;
 }
 
