@@ -552,7 +552,10 @@ int launch_queue(const hlm_device_job* j, int pieces, hipStream_t stream, double
     hlm::QueueRuns runs = make_queue_runs(pieces, tiles, resident, group > 1 && j->queue_run_pieces == 0 ? 1 : j->queue_run_pieces);
     runs.group = group;
     if (group > 1)   // test hook: sibling passes of a group staggered in time (hlm_rk45_queue_kernel.h)
-        if (const char* e = std::getenv("HLM_QUEUE_STAGGER_TICKS")) runs.stagger_ticks = (unsigned int)std::strtoul(e, nullptr, 10);
+        if (const char* e = std::getenv("HLM_QUEUE_STAGGER_TICKS")) {
+            const unsigned long v = std::strtoul(e, nullptr, 10);
+            runs.stagger_ticks = (unsigned int)(v < 1000000ul ? v : 1000000ul);   // (at most 10 ms per pass index: a stray variable cannot hang a launch)
+        }
     runs.t_begin = w0;
     runs.piece_len = (w1 - w0) / (double)pieces;
     hipLaunchKernelGGL(fn, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, queue, pieces, runs);
