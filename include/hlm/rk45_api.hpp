@@ -137,6 +137,8 @@ inline void set_radau_fallback(bool on) { detail::check(hlm_set_radau_fallback(o
 // mode 2: the pass continues every flagged system from the state it had reached instead of restarting it at t0
 // (radau_kernel.cu:44-52 restarts); 0 / 1 as set_radau_fallback(false / true)
 inline void set_radau_mode(int mode) { detail::check(hlm_set_radau_fallback(mode), "set_radau_mode"); }
+// hlm_set_radau_pieces: the Radau pass's work queue in time pieces (0 = automatic, 1 = whole systems, at most 16); same results
+inline void set_radau_pieces(int pieces) { detail::check(hlm_set_radau_pieces(pieces), "set_radau_pieces"); }
 // Launch shape of the runs without dense output (build feature, hlm_set_time_pieces): 0 = one wave per tile (the
 // reference's map, rk45_kernel.cu:33), P > 1 = a persistent grid over P time pieces x tiles, negative = automatic
 // (the default).  Same results bit for bit either way.

@@ -123,6 +123,12 @@ int hlm_set_queue_hybrid(int mode);
  * (hlm_device_job.d_flag_state); 0 (default): flagged systems keep stiff = 1 and zero rows, the reference's
  * observable behaviour. */
 int hlm_set_radau_fallback(int enabled);
+/* (ABI 5) The Radau pass's work queue hands out (time piece, flagged system) items: pieces = 1 ... 16 equal parts of
+ * [t0, tf] (1: whole systems), 0 (default) = automatic -- 16 when the flagged systems restart at t0, whole systems when
+ * they continue from their flag states ("continue" mode in pieces always takes 16, the bins its list is ordered by).  A system pauses before the first
+ * implicit attempt that starts at or after its piece's end and goes on from that state in the next one: no step is clipped to
+ * a piece, results do not depend on the count.  (Why: hlm_radau_kernel.h "TIME PIECES".) */
+int hlm_set_radau_pieces(int pieces);
 /* Output selection of the host API: the reference's run configuration lists the state variables to write
  * (data/config.yaml:44-52 "output.states", parsed by I_O/config_loader.cpp:19-84; the writers take the variable
  * list, I_O/output_series.cpp:18-72).  n > 0: dense rows carry only the n components comps[0..n) (ascending,

@@ -1856,6 +1856,62 @@ def test_radau_continue_from_the_flag_state_matches_oracle(gpu, oracle, layout):
         assert np.array_equal(again[k], got[k]), k
 
 
+@pytest.mark.parametrize("layout", [0, 2])
+def test_radau_time_pieces_leave_every_result_as_it_is(gpu, layout):
+    """The Radau pass's work queue hands out (time piece, flagged hillslope) items (hlm_set_radau_pieces; hlm_radau_kernel.h
+    "TIME PIECES"): a hillslope pauses before the first implicit attempt at or after its piece's end and another lane --
+    of another wave, maybe another XCD -- continues from the 68-byte record.  No step is clipped to a piece, so finals,
+    dense rows, flags and both counters are the same bit for bit whatever the count: whole systems (1), 2, 5, 16 pieces,
+    restart and continue mode (whose queue is ordered by rounds: the k-th piece of every system that has one)."""
+    H = gpu
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    sp, y0, cells, pr, t2m, dt, nT, q, tf = _cold_case()
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, dense_tiled=layout)
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    try:
+        for mode in (True, "continue"):
+            ref = None
+            for pieces in (1, 2, 5, 16, 0):
+                H.api.set_radau_pieces(pieces)
+                eng.integrate(radau=mode)
+                got = eng.results()
+                assert (got["stiff"] == 1).sum() > 20 and not (got["stiff"] == 2).any()
+                if ref is None:
+                    ref = got
+                    continue
+                for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
+                    assert np.array_equal(got[k], ref[k]), (mode, pieces, k)
+        with pytest.raises(Exception):
+            H.api.set_radau_pieces(17)
+    finally:
+        H.api.set_radau_pieces(0)
+
+
+def test_radau_attempt_cap_inside_an_early_piece(gpu, oracle):
+    """A hillslope the attempt cap stops in an early piece is through: its later items find the ENDED mark and skip it,
+    the outputs are the capped ones (flag 2, zero finals) whatever the piece count, as the oracle's."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    sp, y0, cells, pr, t2m, dt, nT, q, tf = _cold_case()
+    try:
+        outs = []
+        for pieces in (1, 16):
+            H.api.set_radau_pieces(pieces)
+            eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, attempt_cap=300)
+            eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+            eng.integrate(radau=True)
+            outs.append(eng.results())
+        for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
+            assert np.array_equal(outs[0][k], outs[1][k]), k
+        ref = oracle.run(oracle.UID_204, y0, 0.0, tf, query=q, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells),
+                         forc_dt_h=dt, forc_nT=nT, radau=True, attempt_cap=300)
+        assert (outs[1]["stiff"] == 2).sum() > 0 and np.array_equal(outs[1]["stiff"], ref["stiff"])
+        assert np.all(outs[1]["y_final"][outs[1]["stiff"] == 2] == 0.0)
+    finally:
+        H.api.set_radau_pieces(0)
+
+
 def test_radau_only_dummy_vs_oracle_and_exact_flow(gpu, oracle):
     """Send every DummyModel system through the implicit solver (flags forced to 1): checks the
     kernel on ragged wave counts against the oracle and against the linear system's exact flow."""

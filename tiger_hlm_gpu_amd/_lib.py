@@ -120,6 +120,7 @@ SIGNATURES = {
     "hlm_set_attempt_cap": (C.c_int, [C.c_uint32]),
     "hlm_set_math_mode": (C.c_int, [C.c_int]),
     "hlm_set_radau_fallback": (C.c_int, [C.c_int]),
+    "hlm_set_radau_pieces": (C.c_int, [C.c_int]),
     "hlm_set_output_states": (C.c_int, [C.c_int, C.POINTER(C.c_int)]),
     "hlm_set_time_pieces": (C.c_int, [C.c_int]),
     "hlm_set_queue_shape": (C.c_int, [C.c_int, C.c_int]),

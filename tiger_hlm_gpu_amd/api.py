@@ -136,6 +136,12 @@ def set_radau_fallback(enabled):
     check(lib().hlm_set_radau_fallback(mode))
 
 
+def set_radau_pieces(pieces=0):
+    """hlm_set_radau_pieces: the Radau pass's work queue in `pieces` time pieces (1 = whole systems, at most 16); 0 =
+    automatic (16 restarting at t0, whole systems continuing from the flag states).  Results do not depend on it."""
+    check(lib().hlm_set_radau_pieces(int(pieces)))
+
+
 def set_output_states(comps=None):
     """Output selection of the host API (hlm_set_output_states; the reference's ``output.states``,
     data/config.yaml:44-52): the dense rows of setup_gpu_buffers / run_rk45 carry only the state components

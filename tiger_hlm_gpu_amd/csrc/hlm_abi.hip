@@ -112,6 +112,7 @@ int auto_dense_sub_windows(int num_systems, int window_queries)
     return 4;
 }
 int g_sharded_upload = HLM_UPLOAD_THREADS;  // hlm_set_sharded_upload()
+int g_radau_pieces = 0;  // hlm_set_radau_pieces(): time pieces of the Radau pass's work queue, 0 = automatic
 int g_radau = 0;  // hlm_set_radau_fallback(): host API re-integrates flagged systems with Radau IIA
 // hlm_set_output_states(): the dense rows of the host API carry only these state components (0 = all)
 int g_out_ncomp = 0;
@@ -680,30 +681,44 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     // the flagged systems, compacted IN ORDER: neighbours share a forcing cell and take similar numbers of
     // implicit attempts, so the lanes of a Radau wave finish together (an atomic append scatters them)
     const int nb = (ns + hlm::COMPACT_BLOCK - 1) / hlm::COMPACT_BLOCK;
-    int* scratch = nullptr;  // [0 .. ns) indices of flagged systems | [ns .. ns+nb) block counts | count | base | next slot | [ns] time bins
+    // the pass's work queue (hlm_radau_kernel.h "TIME PIECES"): items (piece of the window, list entry), kRadauPieces
+    // equal pieces; a system paused at a piece's end waits in a record by list entry (y, t, h | two counters, the next query)
+    constexpr int kRadauPieces = 16;
+    const int neq = model_neq(j->uid);
     const bool by_flag_time = j->d_flag_state != nullptr;
-    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch), sizeof(int) * ((size_t)ns + (size_t)nb + 3 + (by_flag_time ? (size_t)ns : 0)), stream));
+    // ints: [0 .. ns) the list | [nb] block counts | count, base, next item | [kRadauPieces] entries per piece | [ns] done
+    //       | [3][ns] record | ([ns] time bins);  doubles behind them: [neq + 2][ns] record
+    const size_t n_int = (size_t)ns + (size_t)nb + 3 + (size_t)kRadauPieces + (size_t)ns + 3 * (size_t)ns + (by_flag_time ? (size_t)ns : 0);
+    const size_t int_bytes = (n_int * sizeof(int) + 15) / 16 * 16;
+    char* scratch_raw = nullptr;
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch_raw), int_bytes + sizeof(double) * (size_t)(neq + 2) * (size_t)ns, stream));
+    int* const scratch = reinterpret_cast<int*>(scratch_raw);
     int* const list = scratch;
     int* const block_count = scratch + ns;
     int* const count = block_count + nb;
-    int* const next_slot = count + 2;   // (count + 1 = the appending passes' base)
+    int* const next_item = count + 2;   // (count + 1 = the appending passes' base)
+    int* const cum = next_item + 1;
+    int* const done = cum + kRadauPieces;
+    int* const rec_i32 = done + ns;
+    int* const bin = rec_i32 + 3 * (size_t)ns;
+    double* const rec_f64 = reinterpret_cast<double*>(scratch_raw + int_bytes);
+    // count, base, next item, the entries per piece and every list entry's counter of finished pieces start at 0
+    HLM_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * (3 + (size_t)kRadauPieces + (size_t)ns), stream));
     if (!by_flag_time) {
         hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count);
-        hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, (int*)nullptr);
+        hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, (int*)nullptr, (int*)nullptr);
         hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count, list);
     } else {
-        // "continue" mode: the work left is tf - t_flag.  The list is built bin by bin of the flag time (earliest
-        // first: the longest jobs start first, and the lanes of a wave have similar amounts left), in index order
-        // within a bin -- kRadauBins stable compaction passes appending to one list, no host round trip
-        constexpr int kRadauBins = 16;
+        // "continue" mode: the work left is tf - t_flag.  The list is built piece by piece of the flag time (earliest
+        // first: the longest jobs start first), in index order within a piece -- kRadauPieces stable compaction passes
+        // appending to one list, no host round trip; cum[p] = the entries flagged in the pieces up to p, i.e. the list
+        // entries that exist in piece p of the queue
         int* const base = count + 1;
-        int* const bin = next_slot + 1;
-        HLM_HIP_TRY(hipMemsetAsync(count, 0, 2 * sizeof(int), stream));
         hipLaunchKernelGGL(hlm::radau_flag_bin_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, j->d_flag_state,
-                           model_neq(j->uid), ns, j->t0, j->tf, kRadauBins, bin);
-        for (int b = 0; b < kRadauBins; ++b) {
+                           neq, ns, j->t0, j->tf, kRadauPieces, bin);
+        for (int b = 0; b < kRadauPieces; ++b) {
             hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, bin, b, ns, block_count);
-            hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, base);
+            hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, base, cum + b);
             hipLaunchKernelGGL(hlm::compact_scatter_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, bin, b, ns, block_count, list);
         }
     }
@@ -711,26 +726,39 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     // an implicit attempt costs ~30 us of a wave: the default cap of this pass is 2^20 attempts per
     // system (half a minute), not the RK45 loop's 2^24, so a hopeless system cannot hold a wave for long
     if (!j->attempt_cap) a.cap = 1u << 20;
-    using RadauFn = void (*)(const hlm::Rk45Args, const int*, const int*, int*);
+    using RadauFn = void (*)(const hlm::Rk45Args, const int*, const int*, int*, const hlm::RadauQueue);
     const bool fast = j->math_mode == HLM_MATH_FAST;
     RadauFn rf = with_model<RadauFn>(j->uid, [&](auto m) -> RadauFn {
         using M = decltype(m);
         return fast ? hlm::radau_fallback_kernel<M, hlm::MATH_FAST> : hlm::radau_fallback_kernel<M, hlm::MATH_STRICT>;
     });
-    if (!rf) { (void)hipFreeAsync(scratch, stream); return fail(HLM_ERR_UNKNOWN_MODEL, "no Radau kernel for UID %d", j->uid); }
-    // a persistent grid with lane refill: as many one-wave workgroups as the device holds (or as there could be full
-    // waves of flagged systems); the lanes draw further list slots from next_slot, which starts behind the grid's own
+    if (!rf) { (void)hipFreeAsync(scratch_raw, stream); return fail(HLM_ERR_UNKNOWN_MODEL, "no Radau kernel for UID %d", j->uid); }
+    // a persistent grid: as many one-wave workgroups as the device holds (or as there could be full waves of flagged
+    // systems); every lane draws its items from next_item
     int dev = 0, cus = 0, per_cu = 0;
     hipError_t eq = hipGetDevice(&dev);
     if (eq == hipSuccess) eq = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     if (eq == hipSuccess) eq = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(rf), hlm::WAVE, 0);
     const long long resident = (long long)cus * (per_cu > 0 ? per_cu : 1), waves = ((long long)ns + hlm::WAVE - 1) / hlm::WAVE;
     const unsigned blocks = (unsigned)(waves < resident ? waves : resident);
-    if (eq == hipSuccess) eq = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(next_slot), (int)(blocks * (unsigned)hlm::WAVE), 1, stream);
-    if (eq != hipSuccess) { (void)hipFreeAsync(scratch, stream); return fail(HLM_ERR_HIP, "Radau launch set-up failed: %s", hipGetErrorString(eq)); }
-    hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, list, count, next_slot);
+    if (eq != hipSuccess) { (void)hipFreeAsync(scratch_raw, stream); return fail(HLM_ERR_HIP, "Radau launch set-up failed: %s", hipGetErrorString(eq)); }
+    hlm::RadauQueue q{};
+    // Automatic: 16 pieces when every flagged system restarts at t0 (all items are equally long: whole systems leave
+    // a fifth of the launch to its tail); whole systems when they continue from their flag states -- the list is then
+    // ordered longest job first, which has no tail to speak of, and a system stays in the lane, among the neighbours, it
+    // started with (measured with 16 pieces: 41 instead of 44 of 64 lanes per instruction, the late rounds' few items
+    // scatter over all waves).  hlm_set_radau_pieces() forces a count for both.
+    q.npieces = g_radau_pieces > 0 ? g_radau_pieces : (by_flag_time ? 1 : kRadauPieces);
+    // "continue" mode in pieces: the list is ordered by the kRadauPieces bins of the flag time, so the queue's pieces are those
+    if (by_flag_time && q.npieces > 1) q.npieces = kRadauPieces;
+    q.cum = by_flag_time && q.npieces > 1 ? cum : nullptr;
+    q.rec_f64 = rec_f64;
+    q.rec_i32 = rec_i32;
+    q.done = done;
+    q.cap = ns;
+    hipLaunchKernelGGL(rf, dim3(blocks), dim3(hlm::WAVE), 0, stream, a, list, count, next_item, q);
     const hipError_t launched = hipGetLastError();
-    HLM_HIP_TRY(hipFreeAsync(scratch, stream));  // stream-ordered: after the kernels above
+    HLM_HIP_TRY(hipFreeAsync(scratch_raw, stream));  // stream-ordered: after the kernels above
     HLM_HIP_TRY(launched);
     return HLM_SUCCESS;
 }
@@ -1016,6 +1044,13 @@ int hlm_set_queue_hybrid(int mode)
     if (mode < -1 || mode > 1) return fail(HLM_ERR_INVALID_ARGUMENT, "queue_hybrid must be -1, 0 or 1");
     std::lock_guard<std::mutex> lk(g_mu);
     g_queue_hybrid = mode;
+    return HLM_SUCCESS;
+}
+
+int hlm_set_radau_pieces(int pieces)
+{
+    if (pieces < 0 || pieces > 16) return fail(HLM_ERR_INVALID_ARGUMENT, "radau pieces %d (0 = automatic, 1 ... 16)", pieces);
+    g_radau_pieces = pieces;
     return HLM_SUCCESS;
 }
 

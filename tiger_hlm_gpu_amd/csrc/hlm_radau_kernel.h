@@ -337,13 +337,49 @@ __device__ unsigned long long g_radau_ctr[8];
 #define HLM_RADAU_SETUP_DEN 8
 #endif
 constexpr int RADAU_SETUP_NUM = HLM_RADAU_SETUP_NUM, RADAU_SETUP_DEN = HLM_RADAU_SETUP_DEN;
+
+// TIME PIECES (round 5).  The window [t0, tf] is cut into npieces equal parts and what a lane draws from the device
+// counter is an ITEM (piece p, list slot): it integrates that system from where piece p - 1 left it until the first
+// attempt that would start at or after the piece's end -- the pause protocol of the RK45 queue kernel: no step is
+// clipped to a piece's end, so every system's step sequence, and with it every result, is what it was -- leaves
+// {y, t, h, the two counters, the next query} in a 68-byte record by list slot and draws again.  Items are numbered
+// piece-major, so (p, slot) is drawn a whole piece of the list after (p - 1, slot).
+// Why: a lane that takes whole systems (round 4's refill) holds its last one for a third of the launch -- 419 003
+// flagged systems on 131 072 lanes are 3.2 systems per lane, the lanes that finish their third first take a fourth, and
+// the launch ends ~3.9 system-times after it began with 3.2 of work per lane: a fifth of the machine idles in the
+// tail (measured: waves resident 90 % of the launch, and DONE lanes inside the resident ones).  With 16 pieces the
+// tail is that of an item 1/16 as long.  "Continue" mode (the systems start at their flag times): the list is ordered
+// by the piece of the flag time, cum[p] = the entries flagged in pieces <= p exist in piece p, and a system's first
+// item starts it from its flag state.
+constexpr int RADAU_MAX_PIECES = 32;
+// The state machine is left for the queue (records out, the next items in: an atomic and three dependent loads with all
+// 64 lanes waiting, ~5 us) once this many lanes have ended their items, or one of them has waited this many trips
+#ifndef HLM_RADAU_BREAK_LANES
+#define HLM_RADAU_BREAK_LANES 16
+#endif
+#ifndef HLM_RADAU_BREAK_TRIPS
+#define HLM_RADAU_BREAK_TRIPS 48
+#endif
+constexpr int RADAU_ENDED = 0x40000000;   // done[slot]: the system is through (the attempt cap, or a lost predecessor): later items skip it
+struct RadauQueue {
+    int npieces;       // >= 1
+    const int* cum;    // [npieces] list entries that exist in piece p; null: all of them in every piece (restart at t0)
+    double* rec_f64;   // [N_EQ + 2][cap]: y, t, h of a system paused at a piece's end, by list slot
+    int* rec_i32;      // [3][cap]: n_attempt, n_accept, next_q
+    int* done;         // [cap], zeroed: p + 1 once piece p of the slot's system is through (| RADAU_ENDED)
+    int cap;
+};
+#ifndef HLM_RADAU_WAIT_LIMIT_TICKS
+#define HLM_RADAU_WAIT_LIMIT_TICKS 2000000000ull  // 20 s of wall_clock64() (100 MHz)
+#endif
+
 template <class Model, int MATH>
 __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR) ? HLM_RADAU_TRI_WAVES : 1) radau_fallback_kernel(const Rk45Args A, const int* __restrict__ list,
-                                                                 const int* __restrict__ count, int* __restrict__ next_slot)
+                                                                 const int* __restrict__ count, int* __restrict__ next_item, const RadauQueue Q)
 {
     using namespace radau;
     constexpr int NEQ = Model::N_EQ, NFA = Model::NF > 0 ? Model::NF : 1;
-    const int lane = (int)threadIdx.x;
+    [[maybe_unused]] const int lane = (int)threadIdx.x;   // (the counter builds)
     const int nflagged = *count;
     const double tf = A.tf;
 
@@ -355,43 +391,98 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     const size_t q_stride = tiled ? (size_t)WAVE * (size_t)K : (size_t)K;
     const size_t c_stride = tiled ? (size_t)WAVE : (size_t)1;
 
-    // ---- the system a lane integrates.  LANE REFILL (round 4): the grid is persistent (as many one-wave workgroups as
-    // the device holds) and a lane that finishes its system takes the next flagged one from a device counter -- no wave
-    // idles behind its longest system and the launch does not end on a partial round of waves (6 547 waves of 64
-    // flagged systems on 2 048 slots are 3.2 rounds: a fifth of the last one's machine stood idle).  What made lane
-    // refill lose in the RK45 loop -- neighbours of different forcing cells in one wave defeat its wave-uniform cheap
-    // RHS paths -- does not exist here: every lane evaluates the general RHS with its own forcing samples.
-    int sys = 0;
+    // ---- the system a lane integrates.  The grid is persistent (as many one-wave workgroups as the device holds) and a
+    // lane that has ended its item draws the next one from a device counter (round 4: whole systems; round 5: time
+    // pieces of them, above) -- no wave idles behind its longest lane.  What made lane refill lose in the RK45 loop --
+    // neighbours of different forcing cells in one wave defeat its wave-uniform cheap RHS paths -- does not exist here:
+    // every lane evaluates the general RHS with its own forcing samples.
+    // `item` = slot | piece << ITEM_PIECE_SHIFT is all the lane keeps of where its system came from (one register across
+    // the state machine, where the system number was before the pieces: the list gives that back when the item ends)
+    constexpr int ITEM_PIECE_SHIFT = 26, ITEM_SLOT_MASK = (1 << ITEM_PIECE_SHIFT) - 1;
     typename Model::Local P{};
     double y[NEQ];
-    size_t fcol = 0;
-    double tb[NFA], F[NFA];
     typename Model::Forc FV{};
-    double* dense_row = nullptr;
     double t = A.t0, h = A.h0;
-    int next_q = 0;
-    uint32_t n_attempt = 0, n_accept = 0;
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) y[i] = 0.0;
+    // LANE MEMORY IN LDS (round 5).  What a lane touches once per attempt or less lives in LDS, [word][lane] (a lane's own
+    // 8-byte column of every word: no bank conflicts, no synchronisation -- nobody else reads it): the slope at the step's
+    // start (set-up -> error estimate), the controller's proposal and the step's end (set-up -> commit), the held
+    // samples and their ends, the counters, where the system came from and where its rows go.  ~16 doubles per lane =
+    // 8 KB per wave of the CU's 160 KB, for 31 registers the state machine no longer holds across its trips: the two
+    // hot sections (300+ instructions each with 30 doubles of temporaries) spilled to scratch inside themselves before.
+    constexpr int LM_HCTL = NEQ, LM_TEND = NEQ + 1, LM_TB = NEQ + 2, LM_F = LM_TB + NFA, LM_FCOL = LM_F + NFA, LM_ROW = LM_FCOL + 1, LM_WORDS = LM_ROW + 1;
+    __shared__ double lane_f64[LM_WORDS][WAVE];   // [0, NEQ) f0 | h_ctl (0 unless the step was clipped) | t_end | tb[NF] | F[NF] | fcol, dense_row (as bits)
+    __shared__ int lane_i32[4][WAVE];             // n_attempt, n_accept, next_q, item
+#define f0_(i) lane_f64[(i)][lane]
+#define h_ctl_ lane_f64[LM_HCTL][lane]
+#define t_end_ lane_f64[LM_TEND][lane]
+#define tb_(j) lane_f64[LM_TB + (j)][lane]
+#define F_(j) lane_f64[LM_F + (j)][lane]
+#define fcol_ reinterpret_cast<unsigned long long*>(&lane_f64[LM_FCOL][0])[lane]
+#define dense_row_ reinterpret_cast<double**>(&lane_f64[LM_ROW][0])[lane]
+#define n_attempt_ reinterpret_cast<uint32_t*>(&lane_i32[0][0])[lane]
+#define n_accept_ reinterpret_cast<uint32_t*>(&lane_i32[1][0])[lane]
+#define next_q_ lane_i32[2][lane]
+#define item_ lane_i32[3][lane]
+    auto held_forcing = [&]() -> typename Model::Forc {
+        double F[NFA];
 #pragma unroll
-    for (int j = 0; j < NFA; ++j) { tb[j] = -__builtin_inf(); F[j] = 0.0; }
+        for (int j = 0; j < NFA; ++j) F[j] = F_(j);
+        return Model::prep_forcing(P, F);
+    };
 
-    auto load_system = [&](int slot) {
-        sys = list[slot];
+    // entries(p): the list entries that exist in piece p.  The queue numbers its items ROUND-major: round k holds the
+    // (k + 1)-th piece of every system that has one -- piece first(slot) + k of the entries below entries(P - 1 - k) --
+    // so round 0 starts every flagged system at once, each where its own integration starts, and the item a record waits
+    // for was drawn a whole round earlier.  (Restart at t0: round = piece.  Numbered piece-major, "continue" mode began
+    // with the few systems flagged in the first piece and left the machine waiting for their records.)
+    // (the counts sit in LDS: a draw walks them, and from global memory that was up to 32 dependent loads -- 50 us with
+    // the whole wave waiting -- per item in "continue" mode)
+    __shared__ int q_entries[RADAU_MAX_PIECES];
+    if (lane < Q.npieces) q_entries[lane] = Q.cum ? Q.cum[lane] : nflagged;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // read by the other lanes of this wave
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    auto entries = [&](int p) -> int { return q_entries[p]; };
+    auto decode = [&](int i) -> bool {
+        long long before = 0;
+        for (int k = 0; k < Q.npieces; ++k) {
+            const int c = entries(Q.npieces - 1 - k);
+            if ((long long)i < before + (long long)c) {
+                const int slot = (int)((long long)i - before);
+                int first = 0;   // the piece the entry's system starts in
+                while (first + 1 < Q.npieces && slot >= entries(first)) ++first;
+                item_ = slot | (first + k) << ITEM_PIECE_SHIFT;
+                return true;
+            }
+            before += (long long)c;
+        }
+        return false;
+    };
+    // the end of piece p (tf for the last one): a lane pauses before the first attempt that starts at or after it
+    const double piece_len = (tf - A.t0) / (double)Q.npieces;
+    auto piece_end = [&](int p) -> double { return p + 1 < Q.npieces ? vmin(A.t0 + (double)(p + 1) * piece_len, tf) : tf; };
+    // what every item of a system needs, whatever its piece
+    auto begin_item = [&](int sys) {
         P = Model::template load<MATH>(A.sp, sys);
-        if constexpr (Model::NF > 0) fcol = A.forc_col ? (size_t)A.forc_col[sys] : (size_t)sys;
+        if constexpr (Model::NF > 0) fcol_ = A.forc_col ? (unsigned long long)A.forc_col[sys] : (unsigned long long)sys;
 #pragma unroll
-        for (int j = 0; j < NFA; ++j) { tb[j] = -__builtin_inf(); F[j] = 0.0; }
-        FV = Model::prep_forcing(P, F);
-        dense_row = nullptr;
+        for (int j = 0; j < NFA; ++j) { tb_(j) = -__builtin_inf(); F_(j) = 0.0; }   // (the first set-up samples at the lane's t: the held value is a function of t alone)
+        FV = held_forcing();
+        dense_row_ = nullptr;
         if (A.nq > 0)
-            dense_row = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * (size_t)K
-                               : A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride +
-                                     (size_t)(sys % WAVE);
+            dense_row_ = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * (size_t)K
+                                : A.dense + (size_t)(sys / WAVE) * (size_t)A.nq * q_stride +
+                                      (size_t)(sys % WAVE);
+    };
+    // the first item of a system: its start
+    auto start_system = [&](int sys) {
         t = A.t0;
         h = A.h0;
-        next_q = 0;
-        n_attempt = n_accept = 0;
+        int next_q = 0;
+        n_attempt_ = n_accept_ = 0u;
+        double* const dense_row = dense_row_;
         if (A.flag_state) {
             // "continue" mode (hlm_device_job.d_flag_state): take over from the state at which RK45 gave up; the rows
             // it wrote up to there stay, the later ones (zero so far) are this pass's
@@ -411,18 +502,39 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 ++next_q;
             }
         }
+        next_q_ = next_q;
+    };
+    // a later item: the record piece - 1 left (device-coherent loads: another wave, maybe of another XCD, stored it)
+    auto resume_system = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) y[i] = coherent_load(&Q.rec_f64[(size_t)i * Q.cap + slot]);
+        t = coherent_load(&Q.rec_f64[(size_t)NEQ * Q.cap + slot]);
+        h = coherent_load(&Q.rec_f64[(size_t)(NEQ + 1) * Q.cap + slot]);
+        n_attempt_ = (uint32_t)coherent_load(&Q.rec_i32[(size_t)0 * Q.cap + slot]);
+        n_accept_ = (uint32_t)coherent_load(&Q.rec_i32[(size_t)1 * Q.cap + slot]);
+        next_q_ = coherent_load(&Q.rec_i32[(size_t)2 * Q.cap + slot]);
+    };
+    auto pause_system = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < NEQ; ++i) coherent_store(&Q.rec_f64[(size_t)i * Q.cap + slot], y[i]);
+        coherent_store(&Q.rec_f64[(size_t)NEQ * Q.cap + slot], t);
+        coherent_store(&Q.rec_f64[(size_t)(NEQ + 1) * Q.cap + slot], h);
+        coherent_store(&Q.rec_i32[(size_t)0 * Q.cap + slot], (int)n_attempt_);
+        coherent_store(&Q.rec_i32[(size_t)1 * Q.cap + slot], (int)n_accept_);
+        coherent_store(&Q.rec_i32[(size_t)2 * Q.cap + slot], next_q_);
     };
     // the outputs of a finished system (capped: the attempt cap ended it before tf)
-    auto store_system = [&](bool capped) {
+    auto store_system = [&](int sys, bool capped) {
         // both counters ACCUMULATE: after the fallback they hold the RK45 work spent on the system up to
         // its flag plus the implicit attempts / accepted steps of this pass
-        if (A.n_attempt) A.n_attempt[sys] += n_attempt;
-        if (A.n_accept) A.n_accept[sys] += n_accept;
+        if (A.n_attempt) A.n_attempt[sys] += n_attempt_;
+        if (A.n_accept) A.n_accept[sys] += n_accept_;
+        double* const dense_row = dense_row_;
         const bool failed = capped && t < tf;
         if (failed) A.stiff[sys] = HLM_SYS_CAPPED;  // success leaves the RK45 flag in place (rk45_api.hpp:189-247 does)
 #pragma unroll
         for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = failed ? 0.0 : y[i];
-        for (; next_q < A.nq; ++next_q) {  // rows never reached (later than tf, or after the cap): zero
+        for (int next_q = next_q_; next_q < A.nq; ++next_q) {  // rows never reached (later than tf, or after the cap): zero
 #pragma unroll
             for (int c = 0; c < NEQ; ++c)
                 if (c < K) dense_row[(size_t)next_q * q_stride + (size_t)c * c_stride] = 0.0;
@@ -435,7 +547,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         unsigned long long idx = forcing_index(t, A.forc_dtmin[j], A.forc_nT[j]);
         while (idx + 1ull < A.forc_nT[j] && (double)(idx + 1ull) * A.forc_dtmin[j] <= t) ++idx;
         tbj = (idx + 1ull < A.forc_nT[j]) ? (double)(idx + 1ull) * A.forc_dtmin[j] : __builtin_inf();
-        return (double)A.forc[A.forc_base[j] + (size_t)idx * (size_t)A.forc_ld + fcol];
+        return (double)A.forc[A.forc_base[j] + (size_t)idx * (size_t)A.forc_ld + (size_t)fcol_];
     };
 
     // ---- the attempts, as a state machine whose trip is ONE simplified-Newton iteration (round 4) ----------------------
@@ -450,30 +562,25 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     // iteration) and sets up its next one (forcing samples, clipping, f0, Jacobian, the 15 reciprocals), then iterates
     // again.  Each lane executes exactly the operation sequence of the nested loops, so every result is the same bit
     // for bit; only WHEN a lane does what differs, and the Newton iterations run with the lanes that need them.
-    enum : int { PH_NEWTON = 0, PH_SETUP = 1, PH_DONE = 2, PH_FINISHED = 3 };
+    // the other phases are the queue's: PH_FINISHED the lane's item has ended (results or the record go out), PH_DRAW it
+    // needs an item, PH_LOAD it has one and waits for the record of the piece before (never, normally: that piece was
+    // drawn a whole list earlier), PH_DONE the queue is empty
+    enum : int { PH_NEWTON = 0, PH_SETUP = 1, PH_DONE = 2, PH_FINISHED = 3, PH_DRAW = 4, PH_LOAD = 5 };
     enum : int { END_NONE = 0, END_CONVERGED = 1, END_FAILED = 2 };
-    int phase = PH_DONE, ended = END_NONE;
-    {
-        const int slot0 = (int)(blockIdx.x * WAVE) + lane;
-        if (slot0 < nflagged) {
-            load_system(slot0);
-            phase = PH_SETUP;
-        }
-    }
-    if (__builtin_amdgcn_ballot_w64(phase != PH_DONE) == 0ull) return;
+    int phase = PH_DRAW, ended = END_NONE;
+    unsigned long long waiting_since = 0ull;   // (wave-uniform) since when a lane of this wave has been waiting for a record, 0 = none is
     // state of the attempt a lane is in
     constexpr bool TRI = Model::HAS_JACOBIAN && Model::JACOBIAN_LOWER_TRIANGULAR;
-    double f0[NEQ], Jm[NEQ][NEQ];
+    double Jm[NEQ][NEQ];
     [[maybe_unused]] double Mr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Cr[TRI ? 1 : NEQ][TRI ? 1 : NEQ], Ci[TRI ? 1 : NEQ][TRI ? 1 : NEQ];
     double inv_r[NEQ], inv_cr[NEQ], inv_ci[NEQ];
     [[maybe_unused]] int piv_r[NEQ], piv_c[NEQ];
     double Z[NS][NEQ], W[NS][NEQ], inv_sc[NEQ];
-    double inv_h = 0.0, g_h = 0.0, a_h = 0.0, b_h = 0.0, h_ctl = h, t_end = t, prev = __builtin_inf();
-    bool clipped = false;
+    double inv_h = 0.0, g_h = 0.0, a_h = 0.0, b_h = 0.0, prev = __builtin_inf();
     int it = 0;
 #pragma unroll
     for (int i = 0; i < NEQ; ++i) {
-        f0[i] = inv_r[i] = inv_cr[i] = inv_ci[i] = inv_sc[i] = 0.0;
+        inv_r[i] = inv_cr[i] = inv_ci[i] = inv_sc[i] = 0.0;
 #pragma unroll
         for (int j = 0; j < NEQ; ++j) Jm[i][j] = 0.0;
 #pragma unroll
@@ -486,24 +593,71 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         if constexpr (TRI) solve_cplx_tri<Model, MATH>(Jm, inv_cr, inv_ci, br, bi); else solve_cplx(Cr, Ci, piv_c, inv_cr, inv_ci, br, bi);
     };
 
-    // Two loops.  The inner one is the state machine; it is left whenever a lane has finished its system (once per ~90
-    // trips of a wave), and the outer one's body -- results of the finished systems out, the next flagged systems in
-    // -- runs between: kept out of the hot loop so that its operands (the launch's pointers, the parameter record) are
-    // not live registers in there.
+    // Two loops.  The inner one is the state machine; it is left when enough lanes have ended their items (HLM_RADAU_BREAK_*),
+    // and the outer one's body -- results or records of the ended items out, the next items in -- runs between: kept out
+    // of the hot loop so that its operands (the launch's pointers, the parameter record) are not live registers in there.
 #pragma unroll 1
     while (true) {
     if (phase == PH_FINISHED) {
-        store_system(t < tf);
-        const int slot = atomicAdd(next_slot, 1);
-        if (slot < nflagged) {
-            load_system(slot);
+        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = item >> ITEM_PIECE_SHIFT;
+        if (!(t < tf) || n_attempt_ >= A.cap) {
+            store_system(list[slot], t < tf);   // the system is through (tf, or the attempt cap before it)
+            if (piece + 1 < Q.npieces) coherent_store(&Q.done[slot], RADAU_ENDED);   // (the cap, in an earlier piece: its later items have nothing to do)
+        } else {
+            // paused at the end of its piece: the record, its stores acknowledged at device scope, then the counter
+            pause_system(slot);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            coherent_store(&Q.done[slot], piece + 1);
+        }
+        phase = PH_DRAW;
+    }
+    // ---- the queue: a small loop of its own (as `continue`s of the outer loop its paths cost the state machine 300 spilled registers)
+#pragma unroll 1
+    while (true) {
+    if (phase == PH_DRAW) {
+        const int drawn = atomicAdd(next_item, 1);
+        phase = decode(drawn) ? PH_LOAD : PH_DONE;
+    }
+    if (phase == PH_LOAD) {
+        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = item >> ITEM_PIECE_SHIFT;
+        const int sys = list[slot];
+        const bool first = piece == 0 || slot >= entries(piece - 1);   // no earlier piece held this list entry
+        if (first) {
+            begin_item(sys);
+            start_system(sys);
             phase = PH_SETUP;
         } else {
-            phase = PH_DONE;
+            const int v = coherent_load(&Q.done[slot]);
+            if (v >= piece) {
+                asm volatile("" ::: "memory");   // (the record is loaded after the counter, also as the compiler sees it)
+                if (v & RADAU_ENDED) {
+                    phase = PH_DRAW;
+                } else {
+                    begin_item(sys);
+                    resume_system(slot);
+                    phase = PH_SETUP;
+                }
+            } else if (waiting_since != 0ull && wall_clock64() - waiting_since > HLM_RADAU_WAIT_LIMIT_TICKS) {
+                // a lost predecessor (never seen): the system comes back as stopped by a resource limit
+                A.stiff[sys] = HLM_SYS_CAPPED;
+#pragma unroll
+                for (int i = 0; i < NEQ; ++i) A.y_final[(size_t)sys * NEQ + i] = 0.0;
+                coherent_store(&Q.done[slot], RADAU_ENDED);
+                phase = PH_DRAW;
+            }
         }
+    }
+    // again while a lane must draw once more (a skipped item; every draw moves the counter) or all that is left to the
+    // wave is waiting for records
+    const bool some_wait = __builtin_amdgcn_ballot_w64(phase == PH_LOAD) != 0ull;
+    waiting_since = !some_wait ? 0ull : (waiting_since != 0ull ? waiting_since : wall_clock64());
+    if (__builtin_amdgcn_ballot_w64(phase == PH_DRAW) != 0ull) continue;
+    if (__builtin_amdgcn_ballot_w64(phase == PH_SETUP || phase == PH_NEWTON) != 0ull || !some_wait) break;
+    __builtin_amdgcn_s_sleep(16);
     }
     if (__builtin_amdgcn_ballot_w64(phase != PH_DONE) == 0ull) break;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): no load of the block above is waited for inside the loop, behind the row stores
+    int polls_in = 0, ended_trips = 0;
 #pragma unroll 1
     while (true) {
         const unsigned long long m_setup = __builtin_amdgcn_ballot_w64(phase == PH_SETUP);
@@ -522,7 +676,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll
                     for (int i = 0; i < NEQ; ++i) {
                         y_new[i] = y[i] + Z[2][i];
-                        ev[i] = f0[i] + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) * inv_h;
+                        ev[i] = f0_(i) + (E[0] * Z[0][i] + E[1] * Z[1][i] + E[2] * Z[2][i]) * inv_h;
                     }
                     solve_r(ev);
                     double err = 0.0;
@@ -541,6 +695,10 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                         const double root4 = inv_fourth_root<MATH>(err + 1e-16);
                         const double fac = A.safety * root4;
                         if (err <= 1.0) {
+                            const double t_end = t_end_;
+                            if (A.nq > 0) {   // (wave-uniform)
+                            int next_q = next_q_;
+                            double* const dense_row = dense_row_;
                             while (next_q < A.nq) {
                                 const double tq = A.query[next_q];
                                 if (!(tq <= t_end)) break;
@@ -560,12 +718,14 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                                 }
                                 ++next_q;
                             }
+                            next_q_ = next_q;
+                            }
 #pragma unroll
                             for (int i = 0; i < NEQ; ++i) y[i] = y_new[i];
                             t = t_end;
-                            ++n_accept;
+                            ++n_accept_;
                             h *= vclamp_uniform(fac, A.min_scale, A.max_scale);
-                            if (clipped && h < h_ctl) h = h_ctl;
+                            h = vmax(h, h_ctl_);   // (h_ctl_ = the controller's proposal if the step was clipped, else 0: "if (clipped && h < h_ctl) h = h_ctl")
                         } else {
                             h *= vclamp_uniform(vmin(fac, 1.0), A.min_scale, A.max_scale);
                         }
@@ -573,8 +733,9 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 }
                 ended = END_NONE;
                 // ---- the next attempt -- of this system, or (in the section after this one) of the next one ----------
-                if (!(t < tf) || n_attempt >= A.cap) {
-                    phase = PH_FINISHED;   // (tf reached, or the attempt cap: the outer loop takes it from here)
+                const uint32_t n_attempt = n_attempt_;
+                if (!(t < piece_end(item_ >> ITEM_PIECE_SHIFT)) || n_attempt >= A.cap) {
+                    phase = PH_FINISHED;   // (the end of the piece -- tf in the last one -- or the attempt cap: the outer loop takes it from here)
                 } else {
                     HLM_RCOUNT(0);
                     double t_b = __builtin_inf();  // the next sample boundary of any stream
@@ -583,19 +744,23 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll
                         for (int j = 0; j < Model::NF; ++j) {
                             if (j < A.nforc) {
-                                if (!(t < tb[j])) { F[j] = sample(j, tb[j]); moved = true; }
-                                t_b = vmin(t_b, tb[j]);
+                                double tbj = tb_(j);
+                                if (!(t < tbj)) { F_(j) = sample(j, tbj); tb_(j) = tbj; moved = true; }
+                                t_b = vmin(t_b, tbj);
                             }
                         }
-                        if (moved) FV = Model::prep_forcing(P, F);
+                        if (moved) FV = held_forcing();
                     }
-                    h_ctl = h;
-                    t_end = t + h;
-                    clipped = false;
+                    const double h_ctl = h;
+                    double t_end = t + h;
+                    bool clipped = false;
                     if (t_end > tf) { t_end = tf; clipped = true; }
                     if (t_end > t_b) { t_end = t_b; clipped = true; }
                     if (clipped) h = t_end - t;
-                    ++n_attempt;
+                    h_ctl_ = clipped ? h_ctl : 0.0;
+                    t_end_ = t_end;
+                    n_attempt_ = n_attempt + 1u;
+                    double f0[NEQ];
 
                     // f0 and the Jacobian: the model's exact one-sided derivative where it supplies one, else the
                     // reference's finite differences (approx_jacobian, radau_step_dense.cuh:13-31: 5 more RHS calls)
@@ -620,6 +785,8 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                     }
                     // (g/h) I - J (Newton's real block and the error estimator) and ((a - ib)/h) I - J: LU with partial
                     // pivoting in general; for a lower-triangular J just the reciprocals of the diagonals
+#pragma unroll
+                    for (int i = 0; i < NEQ; ++i) f0_(i) = f0[i];   // (for the error estimate, in the section that finishes this attempt)
                     inv_h = recip<MATH>(h);
                     g_h = MU_REAL * inv_h;
                     a_h = MU_CRE * inv_h;
@@ -742,9 +909,23 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 phase = PH_SETUP;
             }
         }
-        if (__builtin_amdgcn_ballot_w64(phase == PH_FINISHED) != 0ull) break;
+        const unsigned long long m_ended = __builtin_amdgcn_ballot_w64(phase == PH_FINISHED);
+        if (m_ended != 0ull && (__builtin_popcountll(m_ended) >= HLM_RADAU_BREAK_LANES || ++ended_trips >= HLM_RADAU_BREAK_TRIPS)) break;
+        // (a lane that waits for a record asks again every 16 trips)
+        if (__builtin_amdgcn_ballot_w64(phase == PH_LOAD) != 0ull && (++polls_in & 15) == 0) break;
     }
     }
+#undef f0_
+#undef h_ctl_
+#undef t_end_
+#undef tb_
+#undef F_
+#undef fcol_
+#undef dense_row_
+#undef n_attempt_
+#undef n_accept_
+#undef next_q_
+#undef item_
 
 }
 

@@ -1069,8 +1069,9 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) compact_count_kernel(const int*
 // base (nullable, in/out): the list already holds *base entries -- the offsets start there and *base becomes the new
 // total, so that several passes with different `want` append to one list (the Radau pass orders the flagged systems
 // by the time of their flag that way: radau_flag_bin_kernel)
+// total_out (nullable): the new total once more, where the caller wants it kept (the Radau pass's entries per time piece)
 __global__ void __launch_bounds__(COMPACT_BLOCK) compact_scan_kernel(int* __restrict__ block_count, int nb, int* __restrict__ count,
-                                                                     int* __restrict__ base = nullptr)
+                                                                     int* __restrict__ base = nullptr, int* __restrict__ total_out = nullptr)
 {
     __shared__ int part[COMPACT_BLOCK];
     const int per = (nb + COMPACT_BLOCK - 1) / COMPACT_BLOCK;
@@ -1084,6 +1085,7 @@ __global__ void __launch_bounds__(COMPACT_BLOCK) compact_scan_kernel(int* __rest
         for (int i = 0; i < COMPACT_BLOCK; ++i) { const int v = part[i]; part[i] = run; run += v; }
         *count = run;
         if (base) *base = run;
+        if (total_out) *total_out = run;
     }
     __syncthreads();
     int run = part[threadIdx.x];
