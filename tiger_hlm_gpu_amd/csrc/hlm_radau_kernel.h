@@ -43,6 +43,7 @@ constexpr double PD[NS][3] = {
     {13.0 / 3.0 + 7.0 * SQRT6 / 3.0, -23.0 / 3.0 - 22.0 * SQRT6 / 3.0, 10.0 / 3.0 + 5.0 * SQRT6},
     {13.0 / 3.0 - 7.0 * SQRT6 / 3.0, -23.0 / 3.0 + 22.0 * SQRT6 / 3.0, 10.0 / 3.0 - 5.0 * SQRT6},
     {1.0 / 3.0, -8.0 / 3.0, 10.0 / 3.0}};
+static_assert(T[0][0] != 0.0 && T[0][1] != 0.0 && T[0][2] != 0.0, "the FAST NaN / Inf guard of the Newton increments reads all three W through Z_1");
 static_assert(T[2][0] == 1.0 && T[2][1] == 1.0 && T[2][2] == 0.0 && TI[1][0] == -TI[0][0] && TI[1][1] == -TI[0][1],
               "the shortcuts of stage_increments / transformed_residuals (FAST) read these entries off the matrices");
 // Z = (T (x) I) W for one component.  FAST: the last row of T is (1, 1, 0) -- Z_3 = W_1 + W_2, no product with 0.
@@ -843,13 +844,14 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                         double nrm = 0.0, chk = 0.0;
 #pragma unroll
                         for (int i = 0; i < NEQ; ++i) {
-                            chk += d0[i] + d1[i] + d2[i];
+                            if constexpr (MATH != MATH_FAST) chk += d0[i] + d1[i] + d2[i];
                             W[0][i] = d0[i];
                             W[1][i] = d1[i];
                             W[2][i] = d2[i];
                             const double r = vmax_abs2(vmax_abs(d0[i], d1[i]), d2[i]) * inv_sc[i];
                             nrm = vmax(nrm, r);
                             stage_increments<MATH>(W[0][i], W[1][i], W[2][i], Z[0][i], Z[1][i], Z[2][i]);
+                            if constexpr (MATH == MATH_FAST) chk += Z[0][i];   // (see the Newton section)
                         }
                         HLM_RCOUNT(1);
                         prev = nrm;
@@ -886,13 +888,17 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
             double nrm = 0.0, chk = 0.0;
 #pragma unroll
             for (int i = 0; i < NEQ; ++i) {
-                chk += d0[i] + d1[i] + d2[i];
+                // the NaN / Inf guard of the increments.  FAST: on the sum of the first stage's new increments instead --
+                // Z_1 = T_11 W_1 + T_12 W_2 + T_13 W_3 with three nonzero weights is finite only if all three W are, and
+                // W = W + d is not finite as soon as a d is not: the same decision from 5 additions instead of 15
+                if constexpr (MATH != MATH_FAST) chk += d0[i] + d1[i] + d2[i];
                 W[0][i] += d0[i];
                 W[1][i] += d1[i];
                 W[2][i] += d2[i];
                 const double r = vmax_abs2(vmax_abs(d0[i], d1[i]), d2[i]) * inv_sc[i];
                 nrm = vmax(nrm, r);
                 stage_increments<MATH>(W[0][i], W[1][i], W[2][i], Z[0][i], Z[1][i], Z[2][i]);
+                if constexpr (MATH == MATH_FAST) chk += Z[0][i];
             }
             // the exits of the nested Newton loop, in its order
             int end = END_NONE;
