@@ -98,6 +98,12 @@ typedef struct {
     int use_t_stop;
     double t_stop;
     double* h_reached;       /* [ns] nullable: the step the next attempt would have used */
+    /* hlm_oracle_radau_run only, diagnostic (tests/radau_wave_sim.py: what a wave of the GPU's state machine is made of):
+     * one byte per implicit attempt of system s at radau_trace[s * radau_trace_cap + k], k < radau_trace_cap -- low nibble
+     * the simplified-Newton iterations it took, 0x10 accepted and landed on a forcing sample boundary, 0x20 Newton did
+     * not converge, 0x40 rejected by the error test.  NULL = no trace. */
+    uint8_t* radau_trace;
+    int64_t radau_trace_cap;
 } hlm_oracle_job;
 #define HLM_ORACLE_PAUSED 3
 

@@ -155,6 +155,9 @@ static void radau_one(const hlm_oracle_job* J, int sys)
     int next_q = 0, capped = 0;
     uint32_t n_attempt = 0, n_accept = 0;
     while (next_q < J->nq && J->query[next_q] <= t) ++next_q; /* never produced: stay 0 */
+    /* diagnostic trace (hlm_oracle.h): one byte per attempt */
+    uint8_t* const trace = J->radau_trace ? J->radau_trace + (size_t)sys * (size_t)J->radau_trace_cap : NULL;
+#define TRACE(byte) do { if (trace && (int64_t)n_attempt <= J->radau_trace_cap) trace[n_attempt - 1] = (uint8_t)(byte); } while (0)
 
     while (t < J->tf) {
         if (n_attempt >= cap) { capped = 1; break; }
@@ -178,9 +181,9 @@ static void radau_one(const hlm_oracle_job* J, int sys)
         }
         const double h_ctl = h; /* the controller's proposal, restored after a clipped step */
         double t_end = t + h;   /* the step lands exactly on tf / t_b when clipped to them */
-        int clipped = 0;
+        int clipped = 0, on_boundary = 0;
         if (t_end > J->tf) { t_end = J->tf; clipped = 1; }
-        if (t_end > t_b) { t_end = t_b; clipped = 1; }
+        if (t_end > t_b) { t_end = t_b; clipped = 1; on_boundary = 1; }
         if (clipped) h = t_end - t;
         ++n_attempt;
 
@@ -219,10 +222,11 @@ static void radau_one(const hlm_oracle_job* J, int sys)
         double Z[NS][NEQ], W[NS][NEQ];
         memset(Z, 0, sizeof(Z));
         memset(W, 0, sizeof(W));
-        int converged = 0;
+        int converged = 0, its = 0;
         double prev = INFINITY;
         for (int it = 0; ok && it < NEWTON_MAXITER; ++it) {
             double Fs[NS][NEQ], d0[NEQ], d1[NEQ], d2[NEQ];
+            ++its;
             for (int s = 0; s < NS; ++s) {
                 double Y[NEQ];
                 for (int i = 0; i < n; ++i) Y[i] = y[i] + Z[s][i];
@@ -251,7 +255,7 @@ static void radau_one(const hlm_oracle_job* J, int sys)
             prev = nrm;
             if (nrm <= NEWTON_TOL) { converged = 1; break; }
         }
-        if (!converged) { h *= 0.5; continue; }
+        if (!converged) { TRACE(its | 0x20); h *= 0.5; continue; }
 
         /* stiffly accurate: y_new = y + Z_3; RADAU5 error estimate */
         double y_new[NEQ], ev[NEQ];
@@ -265,7 +269,7 @@ static void radau_one(const hlm_oracle_job* J, int sys)
             const double r = fabs(ev[i]) / (P->atol + P->rtol * fmax(fabs(y[i]), fabs(y_new[i])));
             if (r > err) err = r;
         }
-        if (!(err == err)) { h *= 0.5; continue; } /* NaN estimate: treat like a failed Newton */
+        if (!(err == err)) { TRACE(its | 0x20); h *= 0.5; continue; } /* NaN estimate: treat like a failed Newton */
         const double fac = P->safety * pow(1.0 / (err + 1e-16), 0.25);
         if (err <= 1.0) {
             const double t1 = t_end;
@@ -284,12 +288,15 @@ static void radau_one(const hlm_oracle_job* J, int sys)
             for (int i = 0; i < n; ++i) y[i] = y_new[i];
             t = t1;
             ++n_accept;
+            TRACE(its | (on_boundary ? 0x10 : 0));
             h *= fmin(fmax(fac, P->minScale), P->maxScale);
             if (clipped && h < h_ctl) h = h_ctl;
         } else {
+            TRACE(its | 0x40);
             h *= fmin(fmax(fmin(fac, 1.0), P->minScale), P->maxScale);
         }
     }
+#undef TRACE
 
     if (J->n_attempt) J->n_attempt[sys] += n_attempt;
     if (J->n_accept) J->n_accept[sys] += n_accept;

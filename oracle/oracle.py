@@ -51,6 +51,7 @@ class _Job(C.Structure):
         ("n_attempt", C.c_void_p), ("n_accept", C.c_void_p), ("t_reached", C.c_void_p),
         ("y_reached", C.c_void_p), ("radau_continue", C.c_int),
         ("start_t", C.c_void_p), ("start_h", C.c_void_p), ("use_t_stop", C.c_int), ("t_stop", C.c_double), ("h_reached", C.c_void_p),
+        ("radau_trace", C.c_void_p), ("radau_trace_cap", C.c_int64),
     ]
 
 
@@ -154,7 +155,7 @@ def rk45_dense(y, k, h, theta):
 def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT=None,
         params=DEFAULT_PARAMS, forc_stub_f64=None, fixed_step=0.0, attempt_cap=0, nthreads=0,
         reorder=True, radau=False, radau_only=False, fma=False, radau_continue=False, start_t=None, start_h=None, t_stop=None,
-        continue_from=None):
+        continue_from=None, radau_trace_cap=0):
     """Integrate; returns dict(y_final[ns,5], dense[ns,nq,5] (or raw [ns,5,nq]), stiff, n_attempt, n_accept).
 
     radau=True re-integrates the systems RK45 flagged with the Radau-IIA fallback
@@ -167,7 +168,8 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
     another implementation's RK45 pass left when it flagged the system), as radau_continue does with the oracle's own.
     start_t / start_h ([ns]) and t_stop: segment replay (hlm_oracle.h) -- every system enters the loop at (start_t, y0)
     with the step start_h and leaves it paused (stiff = PAUSED = 3, state in t_reached / y_reached / h_reached) before
-    the first attempt that starts at or after t_stop."""
+    the first attempt that starts at or after t_stop.
+    radau_trace_cap > 0: the result carries "radau_trace" [ns, cap] uint8, one byte per implicit attempt (hlm_oracle.h)."""
     n = neq(uid)
     y0 = np.ascontiguousarray(y0, dtype=np.float64).reshape(-1, n)
     ns = y0.shape[0]
@@ -219,6 +221,10 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
         treach[:] = np.asarray(continue_from[0], dtype=np.float64)
         yreach[:] = np.asarray(continue_from[1], dtype=np.float64).reshape(ns, n)
         j.radau_continue = 1
+    trace = None
+    if radau_trace_cap > 0:
+        trace = np.zeros((ns, int(radau_trace_cap)), dtype=np.uint8)
+        j.radau_trace, j.radau_trace_cap = _p(trace), int(radau_trace_cap)
     if radau_only:
         stiff[:] = 1
         yf[:] = 0.0
@@ -235,4 +241,4 @@ def run(uid, y0, t0, tf, query=None, sp=None, forc=None, forc_dt_h=None, forc_nT
         dense = np.empty((ns, nq, n))
         lib().hlm_oracle_reorder_dense_n(_p(raw), _p(dense), ns, nq, n)
     return {"y_final": yf, "dense": dense, "stiff": stiff, "n_attempt": na, "n_accept": nacc, "t_reached": treach,
-            "y_reached": yreach, "h_reached": hreach}
+            "y_reached": yreach, "h_reached": hreach, "radau_trace": trace}

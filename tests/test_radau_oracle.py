@@ -193,3 +193,26 @@ def test_radau_pass_from_given_flag_states_equals_the_continue_mode(oracle):
     assert np.array_equal(own["y_final"], ref["y_final"][idx])
     after = q[None, :] > plain["t_reached"][idx][:, None]
     assert np.array_equal(own["dense"][after], ref["dense"][idx][after])
+
+
+def test_radau_attempt_trace_accounts_for_every_attempt(oracle):
+    """hlm_oracle_job.radau_trace (the diagnostic behind tests/radau_wave_sim.py): one byte per implicit attempt -- as many as
+    n_attempt counts, as many accepted ones as n_accept, every attempt with 1 ... 10 Newton iterations, and a landing on a
+    forcing boundary for every sample of the finest stream but the last (the final step lands on tf instead)."""
+    from tiger_hlm_gpu_amd import synth
+    ns, days = 6, 3
+    sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns)
+    cells = synth.cell_of_system(0, ns, run_len=2)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    r = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt,
+                   forc_nT=nT, radau_only=True, radau_trace_cap=20000)
+    plain = oracle.run(oracle.UID_204, y0, 0.0, days * 1440.0, sp=sp, forc=synth.expand_per_stream(pr, t2m, cells), forc_dt_h=dt,
+                       forc_nT=nT, radau_only=True)
+    assert np.array_equal(r["y_final"], plain["y_final"]) and plain["radau_trace"] is None
+    for s in range(ns):
+        n = int(r["n_attempt"][s])
+        b = r["radau_trace"][s]
+        assert 0 < n < 20000 and np.all(b[n:] == 0) and np.all((b[:n] & 15) >= 1) and np.all((b[:n] & 15) <= 10)
+        accepted = (b[:n] & 0x60) == 0
+        assert accepted.sum() == r["n_accept"][s]
+        assert ((b[:n] & 0x10) != 0).sum() == 24 * days - 1
