@@ -120,7 +120,8 @@ int hlm_oracle_rk45_run(const hlm_oracle_job* job);
  * re-derived on the reference's skeleton (radau_kernel.cu:20-140): finite-difference Jacobian
  * as approx_jacobian (radau_step_dense.cuh:13-31), <= 10 simplified-Newton iterations on the
  * 15x15 system (pivoted LU), the RADAU5 error estimator and collocation dense output, the same
- * forcing hold / query / controller conventions as the RK45 loop.  Parity for this row is
+ * forcing hold / query / controller conventions as the RK45 loop, plus the build's own: steps clipped to the forcing
+ * sample boundaries, and a step memory across changes of a held sample (hlm_oracle_radau.c).  Parity for this row is
  * NOT pinned by any reference artifact; it is validated against SciPy's Radau. */
 int hlm_oracle_radau_run(const hlm_oracle_job* job);
 

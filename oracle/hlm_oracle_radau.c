@@ -159,6 +159,16 @@ static void radau_one(const hlm_oracle_job* J, int sys)
     uint8_t* const trace = J->radau_trace ? J->radau_trace + (size_t)sys * (size_t)J->radau_trace_cap : NULL;
 #define TRACE(byte) do { if (trace && (int64_t)n_attempt <= J->radau_trace_cap) trace[n_attempt - 1] = (uint8_t)(byte); } while (0)
 
+    /* STEP MEMORY ACROSS FORCING CHANGES.  A step that lands on a sample boundary keeps the controller's proposal (h_ctl
+     * below), typically the whole sample interval; when the next sample differs, the store it feeds starts a transient of
+     * minutes and that proposal is rejected three or four times in a row (min scale 0.2 each) before a step fits --
+     * measured on SURVEY's cold cells: 10.6 % of all implicit attempts are these rejects.  The first attempt after a
+     * CHANGE of any held sample therefore starts from the step that was accepted first after the previous change
+     * (h_change; none yet: the proposal stands): rejected attempts 12 % -> 1.5 %, attempts per system -6 %.  Every
+     * accepted step still passes the error test; only the controller's first guess differs. */
+    double F_held[HLM_ORACLE_MAX_FORCINGS], h_change = 0.0;
+    int have_held = 0, change_pending = 0;
+
     while (t < J->tf) {
         if (n_attempt >= cap) { capped = 1; break; }
 
@@ -178,6 +188,18 @@ static void radau_one(const hlm_oracle_job* J, int sys)
             for (int kk = 0; kk < j; ++kk) base += (size_t)J->forc_nT[kk] * (size_t)J->ns;
             F[j] = (double)J->forc[base + idx * (size_t)J->ns + (size_t)sys];
             if (idx + 1 < nS) t_b = fmin(t_b, (double)(idx + 1) * dt_min);
+        }
+        if (!J->forc_stub_f64) {
+            int changed = 0;
+            for (int j = 0; j < J->nforc; ++j) {
+                if (have_held && F[j] != F_held[j]) changed = 1;
+                F_held[j] = F[j];
+            }
+            have_held = 1;
+            if (changed) {
+                if (h_change > 0.0 && h > h_change) h = h_change;
+                change_pending = 1;
+            }
         }
         const double h_ctl = h; /* the controller's proposal, restored after a clipped step */
         double t_end = t + h;   /* the step lands exactly on tf / t_b when clipped to them */
@@ -289,6 +311,7 @@ static void radau_one(const hlm_oracle_job* J, int sys)
             t = t1;
             ++n_accept;
             TRACE(its | (on_boundary ? 0x10 : 0));
+            if (change_pending) { h_change = h; change_pending = 0; } /* the first step the new sample accepted */
             h *= fmin(fmax(fac, P->minScale), P->maxScale);
             if (clipped && h < h_ctl) h = h_ctl;
         } else {

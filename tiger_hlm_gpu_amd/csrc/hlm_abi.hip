@@ -687,11 +687,11 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     const int neq = model_neq(j->uid);
     const bool by_flag_time = j->d_flag_state != nullptr;
     // ints: [0 .. ns) the list | [nb] block counts | count, base, next item | [kRadauPieces] entries per piece | [ns] done
-    //       | [3][ns] record | ([ns] time bins);  doubles behind them: [neq + 2][ns] record
+    //       | [3][ns] record | ([ns] time bins);  doubles behind them: [neq + 3 + NF][ns] record
     const size_t n_int = (size_t)ns + (size_t)nb + 3 + (size_t)kRadauPieces + (size_t)ns + 3 * (size_t)ns + (by_flag_time ? (size_t)ns : 0);
     const size_t int_bytes = (n_int * sizeof(int) + 15) / 16 * 16;
     char* scratch_raw = nullptr;
-    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch_raw), int_bytes + sizeof(double) * (size_t)(neq + 2) * (size_t)ns, stream));
+    HLM_HIP_TRY(hipMallocAsync(reinterpret_cast<void**>(&scratch_raw), int_bytes + sizeof(double) * (size_t)(neq + 3 + hlm::HLM_KERNEL_MAX_NF) * (size_t)ns, stream));
     int* const scratch = reinterpret_cast<int*>(scratch_raw);
     int* const list = scratch;
     int* const block_count = scratch + ns;

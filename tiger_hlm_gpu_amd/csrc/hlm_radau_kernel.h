@@ -365,7 +365,7 @@ constexpr int RADAU_ENDED = 0x40000000;   // done[slot]: the system is through (
 struct RadauQueue {
     int npieces;       // >= 1
     const int* cum;    // [npieces] list entries that exist in piece p; null: all of them in every piece (restart at t0)
-    double* rec_f64;   // [N_EQ + 2][cap]: y, t, h of a system paused at a piece's end, by list slot
+    double* rec_f64;   // [N_EQ + 3 + max(NF, 1)][cap]: y, t, h, the step memory and the held samples of a system paused at a piece's end, by list slot
     int* rec_i32;      // [3][cap]: n_attempt, n_accept, next_q
     int* done;         // [cap], zeroed: p + 1 once piece p of the slot's system is through (| RADAU_ENDED)
     int cap;
@@ -412,9 +412,10 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     // samples and their ends, the counters, where the system came from and where its rows go.  ~16 doubles per lane =
     // 8 KB per wave of the CU's 160 KB, for 31 registers the state machine no longer holds across its trips: the two
     // hot sections (300+ instructions each with 30 doubles of temporaries) spilled to scratch inside themselves before.
-    constexpr int LM_HCTL = NEQ, LM_TEND = NEQ + 1, LM_TB = NEQ + 2, LM_F = LM_TB + NFA, LM_FCOL = LM_F + NFA, LM_ROW = LM_FCOL + 1, LM_WORDS = LM_ROW + 1;
-    __shared__ double lane_f64[LM_WORDS][WAVE];   // [0, NEQ) f0 | h_ctl (0 unless the step was clipped) | t_end | tb[NF] | F[NF] | fcol, dense_row (as bits)
-    __shared__ int lane_i32[4][WAVE];             // n_attempt, n_accept, next_q, item
+    constexpr int LM_HCTL = NEQ, LM_TEND = NEQ + 1, LM_TB = NEQ + 2, LM_F = LM_TB + NFA, LM_FCOL = LM_F + NFA, LM_ROW = LM_FCOL + 1, LM_HCHG = LM_ROW + 1,
+                  LM_WORDS = LM_HCHG + 1;
+    __shared__ double lane_f64[LM_WORDS][WAVE];   // [0, NEQ) f0 | h_ctl (0 unless the step was clipped) | t_end | tb[NF] | F[NF] | fcol, dense_row (as bits) | h_change
+    __shared__ int lane_i32[5][WAVE];             // n_attempt, n_accept, next_q, item, change_pending
 #define f0_(i) lane_f64[(i)][lane]
 #define h_ctl_ lane_f64[LM_HCTL][lane]
 #define t_end_ lane_f64[LM_TEND][lane]
@@ -426,6 +427,10 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #define n_accept_ reinterpret_cast<uint32_t*>(&lane_i32[1][0])[lane]
 #define next_q_ lane_i32[2][lane]
 #define item_ lane_i32[3][lane]
+    // step memory across forcing changes (oracle/hlm_oracle_radau.c "STEP MEMORY ..."): the first attempt after a change of
+    // a held sample starts from the step accepted first after the previous change (h_change; 0 = none yet)
+#define h_change_ lane_f64[LM_HCHG][lane]
+#define change_pending_ lane_i32[4][lane]
     auto held_forcing = [&]() -> typename Model::Forc {
         double F[NFA];
 #pragma unroll
@@ -468,9 +473,6 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     auto begin_item = [&](int sys) {
         P = Model::template load<MATH>(A.sp, sys);
         if constexpr (Model::NF > 0) fcol_ = A.forc_col ? (unsigned long long)A.forc_col[sys] : (unsigned long long)sys;
-#pragma unroll
-        for (int j = 0; j < NFA; ++j) { tb_(j) = -__builtin_inf(); F_(j) = 0.0; }   // (the first set-up samples at the lane's t: the held value is a function of t alone)
-        FV = held_forcing();
         dense_row_ = nullptr;
         if (A.nq > 0)
             dense_row_ = !tiled ? A.dense + (size_t)sys * (size_t)A.nq * (size_t)K
@@ -479,6 +481,12 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     };
     // the first item of a system: its start
     auto start_system = [&](int sys) {
+        // no sample held yet (tb = -inf: the first set-up samples at the lane's t and sees no change), no step remembered
+#pragma unroll
+        for (int j = 0; j < NFA; ++j) { tb_(j) = -__builtin_inf(); F_(j) = 0.0; }
+        FV = held_forcing();
+        h_change_ = 0.0;
+        change_pending_ = 0;
         t = A.t0;
         h = A.h0;
         int next_q = 0;
@@ -514,6 +522,16 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         n_attempt_ = (uint32_t)coherent_load(&Q.rec_i32[(size_t)0 * Q.cap + slot]);
         n_accept_ = (uint32_t)coherent_load(&Q.rec_i32[(size_t)1 * Q.cap + slot]);
         next_q_ = coherent_load(&Q.rec_i32[(size_t)2 * Q.cap + slot]);
+        // the samples the paused lane held (a pause is often ON a sample boundary: the first set-up of this piece must see
+        // whether the sample changes there) and its step memory; tb = the most negative finite number: "held, ends before any t"
+        h_change_ = coherent_load(&Q.rec_f64[(size_t)(NEQ + 2) * Q.cap + slot]);
+#pragma unroll
+        for (int j = 0; j < NFA; ++j) {
+            F_(j) = coherent_load(&Q.rec_f64[(size_t)(NEQ + 3 + j) * Q.cap + slot]);
+            tb_(j) = -1.7976931348623157e308;
+        }
+        FV = held_forcing();
+        change_pending_ = 0;   // (never pending at a pause: a lane pauses before an attempt, a change is noticed in one)
     };
     auto pause_system = [&](int slot) {
 #pragma unroll
@@ -523,6 +541,9 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         coherent_store(&Q.rec_i32[(size_t)0 * Q.cap + slot], (int)n_attempt_);
         coherent_store(&Q.rec_i32[(size_t)1 * Q.cap + slot], (int)n_accept_);
         coherent_store(&Q.rec_i32[(size_t)2 * Q.cap + slot], next_q_);
+        coherent_store(&Q.rec_f64[(size_t)(NEQ + 2) * Q.cap + slot], h_change_);
+#pragma unroll
+        for (int j = 0; j < NFA; ++j) coherent_store(&Q.rec_f64[(size_t)(NEQ + 3 + j) * Q.cap + slot], F_(j));
     };
     // the outputs of a finished system (capped: the attempt cap ended it before tf)
     auto store_system = [&](int sys, bool capped) {
@@ -725,6 +746,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                             for (int i = 0; i < NEQ; ++i) y[i] = y_new[i];
                             t = t_end;
                             ++n_accept_;
+                            if (change_pending_) { h_change_ = h; change_pending_ = 0; }   // the first step the new sample accepted
                             h *= vclamp_uniform(fac, A.min_scale, A.max_scale);
                             h = vmax(h, h_ctl_);   // (h_ctl_ = the controller's proposal if the step was clipped, else 0: "if (clipped && h < h_ctl) h = h_ctl")
                         } else {
@@ -741,16 +763,28 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                     HLM_RCOUNT(0);
                     double t_b = __builtin_inf();  // the next sample boundary of any stream
                     if constexpr (Model::NF > 0) {
-                        bool moved = false;
+                        bool moved = false, changed = false;
 #pragma unroll
                         for (int j = 0; j < Model::NF; ++j) {
                             if (j < A.nforc) {
                                 double tbj = tb_(j);
-                                if (!(t < tbj)) { F_(j) = sample(j, tbj); tb_(j) = tbj; moved = true; }
+                                if (!(t < tbj)) {
+                                    const bool held = tbj > -__builtin_inf();   // (else: the system's first attempt)
+                                    const double was = F_(j), now = sample(j, tbj);
+                                    F_(j) = now;
+                                    tb_(j) = tbj;
+                                    moved = true;
+                                    changed = changed || (held && now != was);
+                                }
                                 t_b = vmin(t_b, tbj);
                             }
                         }
                         if (moved) FV = held_forcing();
+                        if (changed) {
+                            const double hc = h_change_;
+                            if (hc > 0.0 && h > hc) h = hc;
+                            change_pending_ = 1;
+                        }
                     }
                     const double h_ctl = h;
                     double t_end = t + h;
@@ -932,6 +966,8 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #undef n_accept_
 #undef next_q_
 #undef item_
+#undef h_change_
+#undef change_pending_
 
 }
 
