@@ -1185,6 +1185,14 @@ def main():
             ca = copy.copy(args)
             ca.tmin, ca.group_tiles = -5.0, 8
             res["rk45"].update(_issue_fields(_per_gpu_key(ca, 0, e.ns)))   # active lanes per VALU instruction of the RK45 pass etc.
+            # ... and of the Radau pass's own kernel (per 64 implicit lane-attempts), restart and continue
+            ca.radau = True
+            for tag, cont in (("rk45_plus_radau", False), ("rk45_plus_radau_continue", True)):
+                ca.radau_continue = cont
+                res[tag]["radau_pass_ms"] = res[tag]["ms"] - res["rk45"]["ms"]
+                res[tag]["radau_kernel"] = _issue_fields(_per_gpu_key(ca, 0, e.ns))
+            res["radau_queue"] = {"pieces_restart": 16, "pieces_continue": 1, "note": "hlm_set_radau_pieces(0): (time piece, flagged hillslope) "
+                                  "items when every flagged hillslope restarts at t0, whole hillslopes (longest first) when they continue"}
             return res
         out["variant_survey_c3_cold_cells"] = _optional(_cold)
         torch.cuda.empty_cache()

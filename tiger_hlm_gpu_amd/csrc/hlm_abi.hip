@@ -751,6 +751,7 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     q.npieces = g_radau_pieces > 0 ? g_radau_pieces : (by_flag_time ? 1 : kRadauPieces);
     // "continue" mode in pieces: the list is ordered by the kRadauPieces bins of the flag time, so the queue's pieces are those
     if (by_flag_time && q.npieces > 1) q.npieces = kRadauPieces;
+    if ((long long)ns > (1ll << hlm::RADAU_ITEM_PIECE_SHIFT)) q.npieces = 1;   // (an item's slot has 26 bits beside its piece; 16 x ns items would not fit an int either)
     q.cum = by_flag_time && q.npieces > 1 ? cum : nullptr;
     q.rec_f64 = rec_f64;
     q.rec_i32 = rec_i32;

@@ -353,6 +353,7 @@ constexpr int RADAU_SETUP_NUM = HLM_RADAU_SETUP_NUM, RADAU_SETUP_DEN = HLM_RADAU
 // by the piece of the flag time, cum[p] = the entries flagged in pieces <= p exist in piece p, and a system's first
 // item starts it from its flag state.
 constexpr int RADAU_MAX_PIECES = 32;
+constexpr int RADAU_ITEM_PIECE_SHIFT = 26;   // a lane's item = list slot | piece << 26
 // The state machine is left for the queue (records out, the next items in: an atomic and three dependent loads with all
 // 64 lanes waiting, ~5 us) once this many lanes have ended their items, or one of them has waited this many trips
 #ifndef HLM_RADAU_BREAK_LANES
@@ -399,7 +400,9 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     // every lane evaluates the general RHS with its own forcing samples.
     // `item` = slot | piece << ITEM_PIECE_SHIFT is all the lane keeps of where its system came from (one register across
     // the state machine, where the system number was before the pieces: the list gives that back when the item ends)
-    constexpr int ITEM_PIECE_SHIFT = 26, ITEM_SLOT_MASK = (1 << ITEM_PIECE_SHIFT) - 1;
+    // (a launch of more than 2^26 systems runs in one piece -- launch_radau sees to it -- and the slot takes all the bits)
+    constexpr int ITEM_PIECE_SHIFT = RADAU_ITEM_PIECE_SHIFT;
+    const int ITEM_SLOT_MASK = Q.npieces > 1 ? (1 << ITEM_PIECE_SHIFT) - 1 : 0x7fffffff;
     typename Model::Local P{};
     double y[NEQ];
     typename Model::Forc FV{};
@@ -621,7 +624,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll 1
     while (true) {
     if (phase == PH_FINISHED) {
-        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = item >> ITEM_PIECE_SHIFT;
+        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = Q.npieces > 1 ? item >> ITEM_PIECE_SHIFT : 0;
         if (!(t < tf) || n_attempt_ >= A.cap) {
             store_system(list[slot], t < tf);   // the system is through (tf, or the attempt cap before it)
             if (piece + 1 < Q.npieces) coherent_store(&Q.done[slot], RADAU_ENDED);   // (the cap, in an earlier piece: its later items have nothing to do)
@@ -641,7 +644,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         phase = decode(drawn) ? PH_LOAD : PH_DONE;
     }
     if (phase == PH_LOAD) {
-        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = item >> ITEM_PIECE_SHIFT;
+        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = Q.npieces > 1 ? item >> ITEM_PIECE_SHIFT : 0;
         const int sys = list[slot];
         const bool first = piece == 0 || slot >= entries(piece - 1);   // no earlier piece held this list entry
         if (first) {
@@ -757,7 +760,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 ended = END_NONE;
                 // ---- the next attempt -- of this system, or (in the section after this one) of the next one ----------
                 const uint32_t n_attempt = n_attempt_;
-                if (!(t < piece_end(item_ >> ITEM_PIECE_SHIFT)) || n_attempt >= A.cap) {
+                if (!(t < piece_end(Q.npieces > 1 ? item_ >> ITEM_PIECE_SHIFT : 0)) || n_attempt >= A.cap) {
                     phase = PH_FINISHED;   // (the end of the piece -- tf in the last one -- or the attempt cap: the outer loop takes it from here)
                 } else {
                     HLM_RCOUNT(0);

@@ -72,6 +72,7 @@ struct Options {
     int gpus = 1;               // shard the hillslopes over this many GPUs (one host thread each)
     bool radau = false;         // re-integrate flagged systems with the Radau-IIA fallback
     bool radau_continue = false; // ... continuing from the state RK45 reached instead of restarting at t0
+    int radau_pieces = 0;       // time pieces of the Radau pass's work queue (0 = automatic; hlm_set_radau_pieces)
     int time_pieces = -1;        // launch shape of runs without dense output (-1 automatic, 0 one wave per tile)
     int run_pieces = 0, group_tiles = 0;   // what its queue hands out / tiles packed per item (hlm_set_queue_shape; 0 0 automatic)
     int hybrid = 0;              // hlm_set_queue_hybrid: 1 = waves holding saturated hillslopes run one block of general stages
@@ -88,7 +89,7 @@ struct Options {
     std::fprintf(stderr,
                  "usage: rk45_solver [--config run.yaml] [--init-file states.csv] [--model dummy|204|toy3] [--params file.csv] [--num-systems N] [--t0 T] [--tf T]\n"
                  "                   [--nq N | --query-stride MIN] [--rain M_PER_MIN] [--temp DEG_C]\n"
-                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau | --radau-continue] [--time-pieces P] [--run-pieces N] [--group-tiles G] [--hybrid]\n"
+                 "                   [--initial-step H | --scipy-h0] [--rtol R] [--atol A] [--math strict|fast] [--radau | --radau-continue] [--radau-pieces N] [--time-pieces P] [--run-pieces N] [--group-tiles G] [--hybrid]\n"
                  "                   [--forcing-nc FILE:VAR:DT_HOURS]... [--lookup CSV] [--expand-forcings] [--stream-forcings MIN]\n"
                  "                   [--out-final F] [--out-dense F] [--out-format csv|nc|both] [--nc-compression L] [--states I,J,..] [--stream-dense QUERIES_PER_WINDOW]\n"
                  "                   [--device D] [--gpus N [--oversubscribe] [--gather threads|rccl|host]] [--quiet]\n");
@@ -166,6 +167,7 @@ Options parse(int argc, char** argv)
         else if (a == "--math") o.math = val();
         else if (a == "--radau") o.radau = true;
         else if (a == "--radau-continue") o.radau = o.radau_continue = true;
+        else if (a == "--radau-pieces") o.radau_pieces = std::atoi(val());
         else if (a == "--time-pieces") o.time_pieces = std::atoi(val());
         else if (a == "--run-pieces") o.run_pieces = std::atoi(val());
         else if (a == "--group-tiles") o.group_tiles = std::atoi(val());
@@ -351,6 +353,7 @@ int run(const Options& o, hlm_io::CsvStyle style)
         rk45_api::detail::check(hlm_set_math_mode(o.math == "fast" ? HLM_MATH_FAST : HLM_MATH_STRICT), "hlm_set_math_mode");
     }
     rk45_api::set_radau_mode(o.radau_continue ? 2 : (o.radau ? 1 : 0));
+    rk45_api::set_radau_pieces(o.radau_pieces);
     rk45_api::set_time_pieces(o.time_pieces);
     rk45_api::set_queue_shape(o.run_pieces, o.group_tiles);
     rk45_api::set_queue_hybrid(o.hybrid);
