@@ -1191,8 +1191,9 @@ def main():
                 ca.radau_continue = cont
                 res[tag]["radau_pass_ms"] = res[tag]["ms"] - res["rk45"]["ms"]
                 res[tag]["radau_kernel"] = _issue_fields(_per_gpu_key(ca, 0, e.ns))
-            res["radau_queue"] = {"pieces_restart": 16, "pieces_continue": 1, "note": "hlm_set_radau_pieces(0): (time piece, flagged hillslope) "
-                                  "items when every flagged hillslope restarts at t0, whole hillslopes (longest first) when they continue"}
+            res["radau_queue"] = {"pieces_restart": 16, "pieces_continue": "first item through piece 10 of 16, the last six one by one",
+                                  "note": "hlm_set_radau_pieces(0): (time piece, flagged hillslope) items; continuing from the flag states the "
+                                          "list is ordered longest first and only the launch's end is handed out in pieces"}
             return res
         out["variant_survey_c3_cold_cells"] = _optional(_cold)
         torch.cuda.empty_cache()

@@ -124,8 +124,9 @@ int hlm_set_queue_hybrid(int mode);
  * observable behaviour. */
 int hlm_set_radau_fallback(int enabled);
 /* (ABI 5) The Radau pass's work queue hands out (time piece, flagged system) items: pieces = 1 ... 16 equal parts of
- * [t0, tf] (1: whole systems), 0 (default) = automatic -- 16 when the flagged systems restart at t0, whole systems when
- * they continue from their flag states ("continue" mode in pieces always takes 16, the bins its list is ordered by).  A system pauses before the first
+ * [t0, tf] (1: whole systems), 0 (default) = automatic -- 16 when the flagged systems restart at t0; when they continue
+ * from their flag states, whole systems up to the last six of 16 pieces and those one by one ("continue" mode in
+ * pieces always takes 16, the bins its list is ordered by).  A system pauses before the first
  * implicit attempt that starts at or after its piece's end and goes on from that state in the next one: no step is clipped to
  * a piece, results do not depend on the count.  (Why: hlm_radau_kernel.h "TIME PIECES".) */
 int hlm_set_radau_pieces(int pieces);

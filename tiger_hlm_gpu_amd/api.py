@@ -138,7 +138,8 @@ def set_radau_fallback(enabled):
 
 def set_radau_pieces(pieces=0):
     """hlm_set_radau_pieces: the Radau pass's work queue in `pieces` time pieces (1 = whole systems, at most 16); 0 =
-    automatic (16 restarting at t0, whole systems continuing from the flag states).  Results do not depend on it."""
+    automatic (16 restarting at t0; continuing from the flag states: whole systems up to the last six of 16 pieces).
+    Results do not depend on it."""
     check(lib().hlm_set_radau_pieces(int(pieces)))
 
 

@@ -744,14 +744,21 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     if (eq != hipSuccess) { (void)hipFreeAsync(scratch_raw, stream); return fail(HLM_ERR_HIP, "Radau launch set-up failed: %s", hipGetErrorString(eq)); }
     hlm::RadauQueue q{};
     // Automatic: 16 pieces when every flagged system restarts at t0 (all items are equally long: whole systems leave
-    // a fifth of the launch to its tail); whole systems when they continue from their flag states -- the list is then
-    // ordered longest job first, which has no tail to speak of, and a system stays in the lane, among the neighbours, it
-    // started with (measured with 16 pieces: 41 instead of 44 of 64 lanes per instruction, the late rounds' few items
-    // scatter over all waves).  hlm_set_radau_pieces() forces a count for both.
-    q.npieces = g_radau_pieces > 0 ? g_radau_pieces : (by_flag_time ? 1 : kRadauPieces);
-    // "continue" mode in pieces: the list is ordered by the kRadauPieces bins of the flag time, so the queue's pieces are those
+    // a fifth of the launch to its tail).  When they continue from their flag states the list is ordered longest job
+    // first and only the END of the launch needs small items: whole systems up to the last six of the 16 pieces, those
+    // one by one (hlm_radau_kernel.h: "merged_to"; measured on the cold C3, RK45 + pass: 1 piece at the end 170.5 ms, 2: 169.0,
+    // 3: 165.3, 4: 164.4, 6: 161.8, 9: 162.5, all 15: 169.6).  hlm_set_radau_pieces() forces a count for both: 1 = whole systems,
+    // n > 1 = every piece an item of its own ("continue" mode then always takes the 16 bins its list is ordered by).
+    static const int kRadauTailPieces = [] {   // (experiment knob: HLM_RADAU_TAIL_PIECES = 1 ... 15)
+        const char* e = std::getenv("HLM_RADAU_TAIL_PIECES");
+        const int v = e ? std::atoi(e) : 0;
+        return v >= 1 && v <= 15 ? v : 6;
+    }();
+    q.npieces = g_radau_pieces > 0 ? g_radau_pieces : kRadauPieces;
     if (by_flag_time && q.npieces > 1) q.npieces = kRadauPieces;
+    q.merged_to = by_flag_time && g_radau_pieces == 0 ? kRadauPieces - 1 - kRadauTailPieces : 0;
     if ((long long)ns > (1ll << hlm::RADAU_ITEM_PIECE_SHIFT)) q.npieces = 1;   // (an item's slot has 26 bits beside its piece; 16 x ns items would not fit an int either)
+    if (q.npieces == 1) q.merged_to = 0;
     q.cum = by_flag_time && q.npieces > 1 ? cum : nullptr;
     q.rec_f64 = rec_f64;
     q.rec_i32 = rec_i32;

@@ -353,7 +353,7 @@ constexpr int RADAU_SETUP_NUM = HLM_RADAU_SETUP_NUM, RADAU_SETUP_DEN = HLM_RADAU
 // by the piece of the flag time, cum[p] = the entries flagged in pieces <= p exist in piece p, and a system's first
 // item starts it from its flag state.
 constexpr int RADAU_MAX_PIECES = 32;
-constexpr int RADAU_ITEM_PIECE_SHIFT = 26;   // a lane's item = list slot | piece << 26
+constexpr int RADAU_ITEM_PIECE_SHIFT = 26;   // a lane's item = list slot | piece << 26 | "first item of its system" << 31
 // The state machine is left for the queue (records out, the next items in: an atomic and three dependent loads with all
 // 64 lanes waiting, ~5 us) once this many lanes have ended their items, or one of them has waited this many trips
 #ifndef HLM_RADAU_BREAK_LANES
@@ -365,6 +365,7 @@ constexpr int RADAU_ITEM_PIECE_SHIFT = 26;   // a lane's item = list slot | piec
 constexpr int RADAU_ENDED = 0x40000000;   // done[slot]: the system is through (the attempt cap, or a lost predecessor): later items skip it
 struct RadauQueue {
     int npieces;       // >= 1
+    int merged_to;     // E: a system's FIRST item runs through the pieces up to E in one go (0: every piece an item of its own)
     const int* cum;    // [npieces] list entries that exist in piece p; null: all of them in every piece (restart at t0)
     double* rec_f64;   // [N_EQ + 3 + max(NF, 1)][cap]: y, t, h, the step memory and the held samples of a system paused at a piece's end, by list slot
     int* rec_i32;      // [3][cap]: n_attempt, n_accept, next_q
@@ -401,8 +402,9 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     // `item` = slot | piece << ITEM_PIECE_SHIFT is all the lane keeps of where its system came from (one register across
     // the state machine, where the system number was before the pieces: the list gives that back when the item ends)
     // (a launch of more than 2^26 systems runs in one piece -- launch_radau sees to it -- and the slot takes all the bits)
-    constexpr int ITEM_PIECE_SHIFT = RADAU_ITEM_PIECE_SHIFT;
+    constexpr int ITEM_PIECE_SHIFT = RADAU_ITEM_PIECE_SHIFT, ITEM_FIRST = (int)0x80000000u;   // (sign bit: the system's first item)
     const int ITEM_SLOT_MASK = Q.npieces > 1 ? (1 << ITEM_PIECE_SHIFT) - 1 : 0x7fffffff;
+    auto piece_of = [&](int item) -> int { return Q.npieces > 1 ? (item >> ITEM_PIECE_SHIFT) & 31 : 0; };
     typename Model::Local P{};
     double y[NEQ];
     typename Model::Forc FV{};
@@ -441,11 +443,17 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         return Model::prep_forcing(P, F);
     };
 
-    // entries(p): the list entries that exist in piece p.  The queue numbers its items ROUND-major: round k holds the
-    // (k + 1)-th piece of every system that has one -- piece first(slot) + k of the entries below entries(P - 1 - k) --
-    // so round 0 starts every flagged system at once, each where its own integration starts, and the item a record waits
-    // for was drawn a whole round earlier.  (Restart at t0: round = piece.  Numbered piece-major, "continue" mode began
-    // with the few systems flagged in the first piece and left the machine waiting for their records.)
+    // entries(p): the list entries that exist in piece p.  The queue numbers its items ROUND-major: round 0 holds the first
+    // item of every system -- from its own start through the end of piece max(first piece, E), E = Q.merged_to -- and
+    // round k >= 1 piece max(first, E) + k of every system that has one, i.e. of the entries below entries(P - 1 - k).
+    // Round 0 starts every flagged system at once, each where its own integration starts, and the item a record waits
+    // for was drawn a whole round earlier.  (Restart at t0: E = 0, round = piece.  Numbered piece-major, "continue" mode
+    // began with the few systems flagged in the first piece and left the machine waiting for their records.)
+    // "Continue" mode takes E = P - 7: whole systems up to the last six pieces, which are handed out one by one.  Whole
+    // systems to the end (round 4) left the launch's last tenth to its tail -- a quarter of the cold C3's flags fall in
+    // the window's last eighth, and those systems, drawn last, are two pieces long; every piece an item (E = 0) balances
+    // as well, but scatters the late rounds' few items over all waves (41 instead of 44 lanes per instruction).  What
+    // removes a tail is the granularity of the LAST items only.
     // (the counts sit in LDS: a draw walks them, and from global memory that was up to 32 dependent loads -- 50 us with
     // the whole wave waiting -- per item in "continue" mode)
     __shared__ int q_entries[RADAU_MAX_PIECES];
@@ -456,13 +464,14 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
     auto entries = [&](int p) -> int { return q_entries[p]; };
     auto decode = [&](int i) -> bool {
         long long before = 0;
-        for (int k = 0; k < Q.npieces; ++k) {
+        for (int k = 0; k < Q.npieces - Q.merged_to; ++k) {
             const int c = entries(Q.npieces - 1 - k);
             if ((long long)i < before + (long long)c) {
                 const int slot = (int)((long long)i - before);
                 int first = 0;   // the piece the entry's system starts in
                 while (first + 1 < Q.npieces && slot >= entries(first)) ++first;
-                item_ = slot | (first + k) << ITEM_PIECE_SHIFT;
+                const int piece = (first > Q.merged_to ? first : Q.merged_to) + k;   // (the piece the item ends with)
+                item_ = slot | piece << ITEM_PIECE_SHIFT | (k == 0 ? ITEM_FIRST : 0);
                 return true;
             }
             before += (long long)c;
@@ -624,7 +633,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #pragma unroll 1
     while (true) {
     if (phase == PH_FINISHED) {
-        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = Q.npieces > 1 ? item >> ITEM_PIECE_SHIFT : 0;
+        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = piece_of(item);
         if (!(t < tf) || n_attempt_ >= A.cap) {
             store_system(list[slot], t < tf);   // the system is through (tf, or the attempt cap before it)
             if (piece + 1 < Q.npieces) coherent_store(&Q.done[slot], RADAU_ENDED);   // (the cap, in an earlier piece: its later items have nothing to do)
@@ -644,9 +653,9 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
         phase = decode(drawn) ? PH_LOAD : PH_DONE;
     }
     if (phase == PH_LOAD) {
-        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = Q.npieces > 1 ? item >> ITEM_PIECE_SHIFT : 0;
+        const int item = item_, slot = item & ITEM_SLOT_MASK, piece = piece_of(item);
         const int sys = list[slot];
-        const bool first = piece == 0 || slot >= entries(piece - 1);   // no earlier piece held this list entry
+        const bool first = Q.npieces == 1 || item < 0;   // (ITEM_FIRST) no earlier item held this list entry
         if (first) {
             begin_item(sys);
             start_system(sys);
@@ -760,7 +769,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                 ended = END_NONE;
                 // ---- the next attempt -- of this system, or (in the section after this one) of the next one ----------
                 const uint32_t n_attempt = n_attempt_;
-                if (!(t < piece_end(Q.npieces > 1 ? item_ >> ITEM_PIECE_SHIFT : 0)) || n_attempt >= A.cap) {
+                if (!(t < piece_end(piece_of(item_))) || n_attempt >= A.cap) {
                     phase = PH_FINISHED;   // (the end of the piece -- tf in the last one -- or the attempt cap: the outer loop takes it from here)
                 } else {
                     HLM_RCOUNT(0);
