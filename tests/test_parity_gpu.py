@@ -1860,7 +1860,7 @@ def test_radau_continue_from_the_flag_state_matches_oracle(gpu, oracle, layout):
 def test_radau_time_pieces_leave_every_result_as_it_is(gpu, layout):
     """The Radau pass's work queue hands out (time piece, flagged hillslope) items (hlm_set_radau_pieces; hlm_radau_kernel.h
     "TIME PIECES"): a hillslope pauses before the first implicit attempt at or after its piece's end and another lane --
-    of another wave, maybe another XCD -- continues from the 68-byte record.  No step is clipped to a piece, so finals,
+    of another wave, maybe another XCD -- continues from the record it left.  No step is clipped to a piece, so finals,
     dense rows, flags and both counters are the same bit for bit whatever the count: whole systems (1), 2, 5, 16 pieces,
     restart and continue mode (whose queue is ordered by rounds: the k-th piece of every system that has one)."""
     H = gpu

@@ -340,11 +340,11 @@ __device__ unsigned long long g_radau_ctr[8];
 constexpr int RADAU_SETUP_NUM = HLM_RADAU_SETUP_NUM, RADAU_SETUP_DEN = HLM_RADAU_SETUP_DEN;
 
 // TIME PIECES (round 5).  The window [t0, tf] is cut into npieces equal parts and what a lane draws from the device
-// counter is an ITEM (piece p, list slot): it integrates that system from where piece p - 1 left it until the first
+// counter is an ITEM (piece p, list slot): it integrates that system from where its previous item left it until the first
 // attempt that would start at or after the piece's end -- the pause protocol of the RK45 queue kernel: no step is
 // clipped to a piece's end, so every system's step sequence, and with it every result, is what it was -- leaves
-// {y, t, h, the two counters, the next query} in a 68-byte record by list slot and draws again.  Items are numbered
-// piece-major, so (p, slot) is drawn a whole piece of the list after (p - 1, slot).
+// {y, t, h, the step memory, the held samples | the two counters, the next query} in a record by list slot (92 bytes
+// for Model 204) and draws again.  The items' numbering: "entries(p)" below.
 // Why: a lane that takes whole systems (round 4's refill) holds its last one for a third of the launch -- 419 003
 // flagged systems on 131 072 lanes are 3.2 systems per lane, the lanes that finish their third first take a fourth, and
 // the launch ends ~3.9 system-times after it began with 3.2 of work per lane: a fifth of the machine idles in the
