@@ -1887,6 +1887,49 @@ def test_radau_time_pieces_leave_every_result_as_it_is(gpu, layout):
         H.api.set_radau_pieces(0)
 
 
+@pytest.mark.parametrize("mode", ["restart", "continue"])
+def test_radau_pass_at_the_headline_window_vs_oracle(gpu, oracle, mode):
+    """The Radau pass at the benchmark's window: 8 192 hillslopes of SURVEY's cold C3 x 30 days, no dense output, the
+    default work queue (restart: 16 time pieces; continue: whole systems up to the last six pieces) -- every hillslope the
+    GPU's RK45 pass flagged against the oracle's implicit pass over THE SAME hillslopes from the same starts (t0, or the
+    GPU's own flag states), so that marginal RK45 flags cannot blur the comparison: finals within 0.05 of the bound (0.02
+    where the step sequences agree), implicit attempts and accepted steps identical on at least 99 % of the hillslopes."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 8192, 30
+    tf = days * 1440.0
+    sp, y0, cells = synth.model204_params(0, ns), synth.model204_y0(ns), synth.cell_of_system(0, ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, queue_group_tiles=8)
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    radau = True if mode == "restart" else "continue"
+    eng.integrate(radau=radau)   # (continue: the flag states are recorded by a launch that carries d_flag_state)
+    eng.integrate()
+    base = eng.results()
+    fs = eng._flag_state.cpu().numpy().reshape(ns, 6) if mode == "continue" else None
+    eng.integrate(radau=radau)
+    got = eng.results()
+    idx = np.flatnonzero(base["stiff"] == 1)
+    assert 0.3 * ns < len(idx) < 0.6 * ns and np.array_equal(got["stiff"], base["stiff"])
+    kw = dict(sp=sp[idx], forc=np.ascontiguousarray(synth.expand_per_stream(pr, t2m, cells)[:, idx]), forc_dt_h=dt, forc_nT=nT, radau_only=True)
+    if mode == "continue":
+        kw["continue_from"] = (fs[idx, 5], fs[idx, :5])
+    ref = oracle.run(oracle.UID_204, y0[idx], 0.0, tf, **kw)
+    assert (ref["stiff"] == 1).all() and np.all(np.isfinite(got["y_final"]))
+    dev = _scaled_err(got["y_final"][idx], ref["y_final"])
+    att = got["n_attempt"][idx].astype(np.int64) - base["n_attempt"][idx]
+    acc = got["n_accept"][idx].astype(np.int64) - base["n_accept"][idx]
+    same = (att == ref["n_attempt"]) & (acc == ref["n_accept"])
+    worst, worst_same = dev.max(), dev.reshape(len(idx), -1).max(axis=1)[same].max()
+    print(f"radau {mode}, {len(idx)} flagged of {ns} x {days} days: worst final deviation {worst:.3g} of the bound ({worst_same:.3g} where "
+          f"the step sequences are identical: {same.mean():.4f} of the hillslopes), implicit attempts per hillslope {att.mean():.0f}")
+    # (measured: 0.0082 / 0.0080 of the bound at worst, with identical step sequences too: FAST arithmetic over 30 days)
+    assert worst <= 0.05 and worst_same <= 0.02 and same.mean() >= 0.99
+    for k in ("y_final", "n_attempt", "n_accept"):   # hillslopes RK45 finished: untouched
+        assert np.array_equal(got[k][base["stiff"] != 1], base[k][base["stiff"] != 1]), k
+
+
 def test_radau_attempt_cap_inside_an_early_piece(gpu, oracle):
     """A hillslope the attempt cap stops in an early piece is through: its later items find the ENDED mark and skip it,
     the outputs are the capped ones (flag 2, zero finals) whatever the piece count, as the oracle's."""
