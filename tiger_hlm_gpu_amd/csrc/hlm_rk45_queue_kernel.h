@@ -77,7 +77,8 @@ __device__ unsigned int* g_queue_marks = nullptr;
 #ifdef HLM_QUEUE_PROF
 // experiment builds: per-wave accounting of a queue launch in 100 MHz wall-clock ticks, [block * 8 + k]:
 // 0 first item drawn at, 1 last item finished at, 2 ticks inside item bodies, 3 ticks waiting for a predecessor,
-// 4 items drawn, 5 items with at least one running lane, 6 sum over items of the lanes that ran
+// 4 items drawn, 5 items with at least one running lane, 6 sum over items of the lanes that ran (high bits: trips with a
+// forcing refresh), 7 trips of the attempt loop << 40 | sum of the lanes in them
 __device__ unsigned long long* g_queue_prof = nullptr;
 #define HLM_QPROF(k, expr)                                                                \
     do {                                                                                  \
@@ -295,6 +296,15 @@ __global__ void __launch_bounds__(WAVE, (MATH == MATH_FAST && !HYBRID) ? HLM_MIN
                     for (unsigned c = c_begin; c < c_end; ++c) {
                         t_end = c + 1u < (unsigned)nchunk ? fmin(w_end, R.t_begin + (double)(c + 1u) * R.piece_len) : w_end;
                         while (t < t_end && status == HLM_SYS_OK && n_attempt < A.cap) {
+#ifdef HLM_QUEUE_PROF
+                            {   // [7]: trips of the attempt loop << 40 | lanes that took part in them; [6] high bits: trips in which a lane's held sample expired
+                                const unsigned long long m_ = __builtin_amdgcn_ballot_w64(true), x_ = __builtin_amdgcn_ballot_w64(!(t < held.tb_next));
+                                if (g_queue_prof && lane == (int)__builtin_ctzll(m_)) {
+                                    g_queue_prof[blockIdx.x * 8 + 7] += (1ull << 40) + (unsigned long long)__builtin_popcountll(m_);
+                                    if (x_ != 0ull) g_queue_prof[blockIdx.x * 8 + 6] += 1ull << 40;
+                                }
+                            }
+#endif
                             // rk45_kernel.cu:54 "if (t + h > tf) h = tf - t": only the last steps of the window are clipped, so the
                             // subtraction and the two selects wait behind a wave-uniform test (add + compare per attempt otherwise)
                             if (__builtin_amdgcn_ballot_w64(t + h > tf) != 0ull) {

@@ -64,6 +64,8 @@ for sched in a.sched:
     tail = (t1 - p[:, 1]) / 1e5
     print(f"sched {sched:>14s}: {np.mean(ms):8.3f} ms | waves {len(p)}, span {span:7.2f} ms, per wave: body {body.mean():7.2f} (min {body.min():.2f} max {body.max():.2f}) "
           f"wait {wait.mean():6.3f} (max {wait.max():.2f}) idle at end {tail.mean():5.2f} (max {tail.max():.2f}) | items/wave {p[:, 4].mean():.1f}, ran {p[:, 5].mean():.1f}, "
-          f"lanes per item that ran {p[:, 6].sum() / max(p[:, 5].sum(), 1):.1f}", flush=True)
+          f"lanes per item that ran {(p[:, 6] & ((1 << 40) - 1)).sum() / max(p[:, 5].sum(), 1):.1f}, lanes per trip of the attempt loop "
+          f"{(p[:, 7] & ((1 << 40) - 1)).sum() / max((p[:, 7] >> 40).sum(), 1):.1f}, trips with a forcing refresh "
+          f"{(p[:, 6] >> 40).sum() / max((p[:, 7] >> 40).sum(), 1):.3f}", flush=True)
     del eng
     torch.cuda.empty_cache()
