@@ -432,7 +432,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
 #define n_accept_ reinterpret_cast<uint32_t*>(&lane_i32[1][0])[lane]
 #define next_q_ lane_i32[2][lane]
 #define item_ lane_i32[3][lane]
-    // step memory across forcing changes (oracle/hlm_oracle_radau.c "STEP MEMORY ..."): the first attempt after a change of
+    // step memory across forcing changes (the rule and its reason: the CPU restatement under oracle/, "STEP MEMORY ..."): the first attempt after a change of
     // a held sample starts from the step accepted first after the previous change (h_change; 0 = none yet)
 #define h_change_ lane_f64[LM_HCHG][lane]
 #define change_pending_ lane_i32[4][lane]
