@@ -1930,6 +1930,51 @@ def test_radau_pass_at_the_headline_window_vs_oracle(gpu, oracle, mode):
         assert np.array_equal(got[k][base["stiff"] != 1], base[k][base["stiff"] != 1]), k
 
 
+def test_radau_queue_with_nothing_and_with_one_hillslope_to_do(gpu, oracle):
+    """The work queue's edges: a launch that flagged nothing (the pass draws no item and leaves every output as it is),
+    and launches of ONE flagged hillslope (its 16 items are drawn at once, by 16 lanes that wait for each other's records --
+    the polling path) at every piece count, restart and continue."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    sp, y0, cells, pr, t2m, dt, nT, q, tf = _cold_case()
+    warm = synth.forcing_tables(days=8, tmin=0.5)
+    eng = ShardEngine(H.Model204, y0[:100], 0.0, tf, sp=sp[:100], query=q)
+    eng.expand_forcings_on_device((warm[0], warm[1]), cells[:100], dt, nT)
+    eng.integrate()
+    base = eng.results()
+    assert not (base["stiff"] != 0).any()
+    eng.integrate(radau=True)
+    got = eng.results()
+    for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
+        assert np.array_equal(got[k], base[k]), k
+    # one hillslope, flagged
+    full = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp)
+    full.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    full.integrate()
+    s = int(np.flatnonzero(full.results()["stiff"] == 1)[0])
+    one = ShardEngine(H.Model204, y0[s:s + 1], 0.0, tf, sp=sp[s:s + 1], query=q)
+    one.expand_forcings_on_device((pr, t2m), cells[s:s + 1], dt, nT)
+    ref = oracle.run(oracle.UID_204, y0[s:s + 1], 0.0, tf, query=q, sp=sp[s:s + 1], forc=synth.expand_per_stream(pr, t2m, cells[s:s + 1]),
+                     forc_dt_h=dt, forc_nT=nT, radau=True)
+    try:
+        for mode in (True, "continue"):
+            first = None
+            for pieces in (0, 1, 16):
+                H.api.set_radau_pieces(pieces)
+                one.integrate(radau=mode)
+                r = one.results()
+                assert r["stiff"][0] == 1 and np.all(np.isfinite(r["y_final"])) and np.abs(r["y_final"]).sum() > 0
+                if first is None:
+                    first = r
+                for k in ("y_final", "dense", "n_attempt", "n_accept"):
+                    assert np.array_equal(r[k], first[k]), (mode, pieces, k)
+            if mode is True and ref["stiff"][0] == 1:
+                assert _scaled_err(first["y_final"], ref["y_final"]).max() <= 0.01 and first["n_attempt"][0] == ref["n_attempt"][0]
+    finally:
+        H.api.set_radau_pieces(0)
+
+
 def test_radau_attempt_cap_inside_an_early_piece(gpu, oracle):
     """A hillslope the attempt cap stops in an early piece is through: its later items find the ENDED mark and skip it,
     the outputs are the capped ones (flag 2, zero finals) whatever the piece count, as the oracle's."""
