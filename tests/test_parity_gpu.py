@@ -1975,6 +1975,41 @@ def test_radau_queue_with_nothing_and_with_one_hillslope_to_do(gpu, oracle):
         H.api.set_radau_pieces(0)
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_radau_queue_fuzz_whatever_the_pieces_the_same_bits(gpu, seed):
+    """Random launch sizes (1 ... 700 hillslopes, ragged last tiles), windows (2 ... 7 days: pieces that are no multiple of the
+    forcing hour), query grids, layouts, modes and piece counts against whole systems (hlm_set_radau_pieces(1)): a race in
+    the hand-over (a record read before it was complete, an item run twice or not at all) would show as a differing bit."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    rng = np.random.default_rng(1000 + seed)
+    ns, days = int(rng.integers(1, 700)), float(rng.uniform(2.0, 7.0))
+    start = int(rng.integers(0, 5000))
+    tf = days * 1440.0
+    sp, y0 = synth.model204_params(start, ns), synth.model204_y0(ns)
+    cells = synth.cell_of_system(start, ns, run_len=int(rng.integers(3, 90)))
+    pr, t2m, dt, nT = synth.forcing_tables(days=int(np.ceil(days)), tmin=-5.0, seed=40 + seed)
+    q = np.sort(rng.uniform(0.0, tf, size=int(rng.integers(1, 60)))) if rng.random() < 0.7 else None
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, dense_tiled=int(rng.choice([0, 2])))
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    try:
+        for mode in (True, "continue"):
+            H.api.set_radau_pieces(1)
+            eng.integrate(radau=mode)
+            ref = eng.results()
+            print(f"radau queue fuzz {seed}, {mode}: {ns} hillslopes x {days:.2f} days, {int((ref['stiff'] == 1).sum())} through the pass")
+            for pieces in (0, int(rng.integers(2, 17)), 16):
+                H.api.set_radau_pieces(pieces)
+                eng.integrate(radau=mode)
+                got = eng.results()
+                for k in ("y_final", "dense", "stiff", "n_attempt", "n_accept"):
+                    if ref[k] is not None:
+                        assert np.array_equal(got[k], ref[k]), (seed, mode, pieces, k, ns, days)
+    finally:
+        H.api.set_radau_pieces(0)
+
+
 def test_radau_attempt_cap_inside_an_early_piece(gpu, oracle):
     """A hillslope the attempt cap stops in an early piece is through: its later items find the ENDED mark and skip it,
     the outputs are the capped ones (flag 2, zero finals) whatever the piece count, as the oracle's."""
