@@ -2123,7 +2123,7 @@ def test_cpp_driver_radau_flag(gpu, golden, tmp_path):
     import subprocess
     exe = _driver_exe()
     outs, infos = {}, {}
-    for tag, extra in (("off", []), ("on", ["--radau"])):
+    for tag, extra in (("off", []), ("on", ["--radau"]), ("pieces", ["--radau", "--radau-pieces", "5"])):
         fin = str(tmp_path / f"final_{tag}.csv")
         # a freezing temperature stub (T = -4) makes the ET stub negative: RK45 flags these systems
         out = subprocess.run([exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "14400", "--temp", "-4",
@@ -2138,6 +2138,7 @@ def test_cpp_driver_radau_flag(gpu, golden, tmp_path):
     assert infos["on"]["radau"] is True and infos["on"]["unsolved"] == 0
     assert np.all(np.abs(on[flagged]).sum(axis=1) > 0)
     assert np.array_equal(on[~flagged], off[~flagged])
+    assert np.array_equal(outs["pieces"], on)   # (--radau-pieces: the pass's work queue, same file)
     # the implicit pass restarts from t0 and needs the whole forcing series in HBM
     r = subprocess.run([exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "14400", "--temp", "-4",
                         "--stream-forcings", "600", "--radau", "--out-final", str(tmp_path / "x.csv"),
