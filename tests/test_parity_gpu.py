@@ -2010,6 +2010,36 @@ def test_radau_queue_fuzz_whatever_the_pieces_the_same_bits(gpu, seed):
         H.api.set_radau_pieces(0)
 
 
+def test_radau_queue_at_the_benchmark_size_same_bits(gpu):
+    """BASELINE's size: 1 M hillslopes of SURVEY's cold C3 x 30 days (419 003 flagged on 131 072 lanes: every lane draws,
+    pauses, hands over and takes over dozens of times, records cross between XCDs) -- whole systems against the default
+    queues, restart and continue: every final state, flag and counter the same bit for bit."""
+    H = gpu
+    import torch
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 1_000_000, 30
+    sp, y0, cells = synth.model204_params(0, ns), synth.model204_y0(ns), synth.cell_of_system(0, ns)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    eng = ShardEngine(H.Model204, y0, 0.0, days * 1440.0, sp=sp, queue_group_tiles=8)
+    eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
+    try:
+        for mode in (True, "continue"):
+            keep = {}
+            for pieces in (1, 0):
+                H.api.set_radau_pieces(pieces)
+                eng.integrate(radau=mode)
+                torch.cuda.synchronize()
+                keep[pieces] = {k: getattr(eng, k).clone() for k in ("y_final", "stiff", "n_attempt", "n_accept")}
+            flagged = int((keep[0]["stiff"] == 1).sum().item())
+            assert 400_000 < flagged < 440_000 and int((keep[0]["stiff"] == 2).sum().item()) == 0
+            for k in keep[0]:
+                assert torch.equal(keep[0][k], keep[1][k]), (mode, k)
+            assert bool(torch.isfinite(keep[0]["y_final"]).all())
+    finally:
+        H.api.set_radau_pieces(0)
+
+
 def test_radau_attempt_cap_inside_an_early_piece(gpu, oracle):
     """A hillslope the attempt cap stops in an early piece is through: its later items find the ENDED mark and skip it,
     the outputs are the capped ones (flag 2, zero finals) whatever the piece count, as the oracle's."""
