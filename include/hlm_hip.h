@@ -515,7 +515,9 @@ int hlm_gather_plan(int num_systems, int num_shards, int num_devices, int neq, h
 
 /* devices == NULL: devices 0 .. num_devices - 1.  The devices must be distinct.  num_shards >= 1 (more shards than
  * devices rehearses a larger node's split on a smaller one).  h_stiff / h_n_attempt / h_n_accept / stats are optional.
- * Results are bit-identical to hlm_run_rk45 of the whole domain on one device, whatever the split. */
+ * Results are bit-identical to hlm_run_rk45 of the whole domain on one device, whatever the split.  hlm_set_radau_fallback
+ * applies: every shard's flagged systems go through the implicit pass on the shard's device before the gather (as each of
+ * the reference's ranks relaunches for its own, rk45_api.hpp:189-247). */
 int hlm_run_rk45_sharded(const hlm_sharded_run* run, int num_shards, const int* devices, int num_devices,
                          int gather_mode, double* h_y_final, int32_t* h_stiff, uint32_t* h_n_attempt,
                          uint32_t* h_n_accept, hlm_sharded_stats* stats);

@@ -60,6 +60,38 @@ def test_sharded_run_rccl_gather_equals_the_whole_domain_bitwise(gpu, layout):
               f"RCCL {st['rccl_version']}")
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_sharded_run_with_the_radau_pass_equals_the_whole_domain_bitwise(gpu, mode):
+    """hlm_set_radau_fallback applies to the sharded entry: every shard's flagged hillslopes go through the implicit pass on
+    the shard's device (restart at t0, or continuing from the shard's own flag states), and the gathered finals, flags and
+    counters are those of the whole domain integrated as one launch with the pass -- bit for bit, 1 / 3 / 8 shards."""
+    H = gpu
+    from tiger_hlm_gpu_amd import synth
+    from tiger_hlm_gpu_amd.engine import ShardEngine
+    ns, days = 9_001, 4
+    sp, y0 = synth.model204_params(0, ns), synth.model204_y0(ns)
+    cells = synth.cell_of_system(0, ns, run_len=64)
+    pr, t2m, dt, nT = synth.forcing_tables(days=days, tmin=-5.0)
+    tf = days * 1440.0
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp)
+    eng.set_forcings_per_cell((pr, t2m), cells, dt, nT)
+    eng.integrate()
+    plain = eng.results()
+    eng.integrate(radau=True if mode == 1 else "continue")
+    ref = eng.results()
+    fl = plain["stiff"] == 1
+    assert 50 < fl.sum() < ns and np.all(plain["y_final"][fl] == 0.0) and np.all(np.abs(ref["y_final"][fl]).sum(axis=1) > 0)
+    try:
+        H.api.set_radau_fallback(mode)
+        for shards, gather in ((1, "rccl"), (3, "host"), (8, "rccl")):
+            got, st = H.api.run_rk45_sharded(H.Model204, y0, 0.0, tf, sp=sp, tables=(pr, t2m), dt_hours=dt, cells=cells,
+                                             num_shards=shards, num_devices=1, gather=gather)
+            for k in ("y_final", "stiff", "n_attempt", "n_accept"):
+                assert np.array_equal(got[k], ref[k]), (mode, shards, gather, k)
+    finally:
+        H.api.set_radau_fallback(0)
+
+
 def test_sharded_upload_modes_hold_the_same_bits(gpu):
     """hlm_set_sharded_upload: one host thread per device (the default), round 4's single thread, and the threads packing
     through a pair of 16 MB pinned buffers each (the shard's columns of a per-stream forcing table row by row) -- same
@@ -179,6 +211,17 @@ def test_cpp_driver_gather_rccl_equals_host_threads(gpu, golden, tmp_path):
     assert lines["rccl3"]["attempted_steps"] == lines["one"]["attempted_steps"] > 0
     p = subprocess.run(base[:-6] + ["--tf", "2880", "--query-stride", "60", "--gather", "rccl"], capture_output=True, text=True)
     assert p.returncode == 2 and "--nq 0" in p.stderr
+    # the Radau pass through the sharded entry (freezing stub: hillslopes get flagged): one GPU, threads, RCCL gather -- one file
+    cold = [exe, "--model", "204", "--params", golden["small_test_csv"], "--tf", "14400", "--nq", "0", "--rain", "0.0001", "--temp", "-4", "--radau"]
+    files = {}
+    for tag, extra in (("one", []), ("threads3", ["--gpus", "3", "--oversubscribe"]), ("rccl3", ["--gpus", "3", "--oversubscribe", "--gather", "rccl"])):
+        f = str(tmp_path / f"radau_final_{tag}.csv")
+        q = subprocess.run(cold + ["--out-final", f, "--out-dense", str(tmp_path / f"radau_dense_{tag}.csv")] + extra, check=True, timeout=300,
+                           capture_output=True, text=True)
+        files[tag] = open(f).read()
+        info = json.loads(q.stdout.strip().splitlines()[-1])
+        assert info["radau"] is True and info["flagged"] > 0 and info["unsolved"] == 0, (tag, info)
+    assert files["threads3"] == files["one"] and files["rccl3"] == files["one"]
 
 
 def test_cpp_driver_dense_output_through_the_sharded_entry(gpu, golden, tmp_path):

@@ -2266,8 +2266,8 @@ int hlm_run_rk45_sharded(const hlm_sharded_run* run, int num_shards, const int* 
         for (int d = 0; d < num_devices; ++d) stats->device_ids[d] = S.devs[(size_t)d];
     }
     if (ns == 0) return HLM_SUCCESS;
-    int upload_mode;
-    { std::lock_guard<std::mutex> lk(g_mu); upload_mode = g_sharded_upload; }
+    int upload_mode, radau;
+    { std::lock_guard<std::mutex> lk(g_mu); upload_mode = g_sharded_upload; radau = g_radau; }
 
     double* g_y = nullptr;          // the gathered arrays on devices[0] (HLM_GATHER_RCCL)
     int32_t* g_stiff = nullptr;
@@ -2322,7 +2322,18 @@ int hlm_run_rk45_sharded(const hlm_sharded_run* run, int num_shards, const int* 
         HLM_SH_TRY(hipSetDevice(S.devs[(size_t)S.shards[(size_t)s].dev_rank]));
         hlm_device_job j;
         if (const int rc0 = S.job_for(s, &j); rc0 != HLM_SUCCESS) return cleanup(rc0);
-        if (const int rc1 = hlm_rk45_integrate_device(&j, S.dv[(size_t)S.shards[(size_t)s].dev_rank].stream); rc1 != HLM_SUCCESS) return cleanup(rc1);
+        hipStream_t st = S.dv[(size_t)S.shards[(size_t)s].dev_rank].stream;
+        // hlm_set_radau_fallback: every shard's flagged hillslopes go through the implicit pass on the shard's own device, as each of
+        // the reference's ranks relaunches for its own (rk45_api.hpp:189-247); mode 2: from the states its RK45 launch leaves
+        double* flag_state = nullptr;
+        if (radau == 2) {
+            HLM_SH_TRY(hipMallocAsync(reinterpret_cast<void**>(&flag_state), sizeof(double) * (size_t)j.num_systems * (size_t)(neq + 1), st));
+            j.d_flag_state = flag_state;
+        }
+        int rc1 = hlm_rk45_integrate_device(&j, st);
+        if (rc1 == HLM_SUCCESS && radau) rc1 = hlm_radau_fallback_device(&j, st);
+        if (flag_state) (void)hipFreeAsync(flag_state, st);   // (stream-ordered: after the pass)
+        if (rc1 != HLM_SUCCESS) return cleanup(rc1);
     }
     for (int d = 0; d < num_devices; ++d) {
         HLM_SH_TRY(hipSetDevice(S.devs[(size_t)d]));

@@ -546,8 +546,8 @@ int run(const Options& o, hlm_io::CsvStyle style)
         // end-of-run gather over RCCL (hlm_run_rk45_sharded) -- final states, flags and step counters only.
         // (dense output: --gather host -- every device streams the rows of its shards to the host through its own pinned
         // windows, hlm_run_rk45_sharded_streamed; nothing is gathered between the GPUs)
-        if ((nq > 0 && o.gather == "rccl") || o.radau || o.stream_forcings > 0 || stream_dense)
-            usage("--gather rccl gathers final states only: needs --nq 0 (dense output: --gather host) and none of --radau / --stream-forcings / --stream-dense");
+        if ((nq > 0 && o.gather == "rccl") || o.stream_forcings > 0 || stream_dense)
+            usage("--gather rccl gathers final states only: needs --nq 0 (dense output: --gather host) and neither --stream-forcings nor --stream-dense");
         const int nd = std::min(G, std::max(ndev, 1));
         std::vector<int> devices((size_t)nd);
         for (int i = 0; i < nd; ++i) devices[(size_t)i] = (o.device + i) % std::max(ndev, 1);
