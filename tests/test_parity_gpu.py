@@ -1991,7 +1991,8 @@ def test_radau_queue_fuzz_whatever_the_pieces_the_same_bits(gpu, seed):
     cells = synth.cell_of_system(start, ns, run_len=int(rng.integers(3, 90)))
     pr, t2m, dt, nT = synth.forcing_tables(days=int(np.ceil(days)), tmin=-5.0, seed=40 + seed)
     q = np.sort(rng.uniform(0.0, tf, size=int(rng.integers(1, 60)))) if rng.random() < 0.7 else None
-    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, dense_tiled=int(rng.choice([0, 2])))
+    eng = ShardEngine(H.Model204, y0, 0.0, tf, sp=sp, query=q, dense_tiled=int(rng.choice([0, 2])),
+                      math_mode=H.MATH_STRICT if seed % 2 == 0 else H.MATH_FAST)   # (both instances of the kernel)
     eng.expand_forcings_on_device((pr, t2m), cells, dt, nT)
     try:
         for mode in (True, "continue"):
