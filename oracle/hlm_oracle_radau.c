@@ -192,7 +192,7 @@ static void radau_one(const hlm_oracle_job* J, int sys)
         if (!J->forc_stub_f64) {
             int changed = 0;
             for (int j = 0; j < J->nforc; ++j) {
-                if (have_held && F[j] != F_held[j]) changed = 1;
+                if (have_held && memcmp(&F[j], &F_held[j], sizeof(double)) != 0) changed = 1; /* (by bits: a NaN sample that stays is no change) */
                 F_held[j] = F[j];
             }
             have_held = 1;

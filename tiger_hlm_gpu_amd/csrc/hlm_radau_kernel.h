@@ -786,7 +786,7 @@ __global__ void __launch_bounds__(WAVE, (Model::HAS_JACOBIAN && Model::JACOBIAN_
                                     F_(j) = now;
                                     tb_(j) = tbj;
                                     moved = true;
-                                    changed = changed || (held && now != was);
+                                    changed = changed || (held && __double_as_longlong(now) != __double_as_longlong(was));   // (by bits, as the CPU restatement: a NaN sample that stays is no change)
                                 }
                                 t_b = vmin(t_b, tbj);
                             }
