@@ -703,7 +703,10 @@ int launch_radau(const hlm_device_job* j, hipStream_t stream)
     int* const bin = rec_i32 + 3 * (size_t)ns;
     double* const rec_f64 = reinterpret_cast<double*>(scratch_raw + int_bytes);
     // count, base, next item, the entries per piece and every list entry's counter of finished pieces start at 0
-    HLM_HIP_TRY(hipMemsetAsync(count, 0, sizeof(int) * (3 + (size_t)kRadauPieces + (size_t)ns), stream));
+    if (const hipError_t ez = hipMemsetAsync(count, 0, sizeof(int) * (3 + (size_t)kRadauPieces + (size_t)ns), stream); ez != hipSuccess) {
+        (void)hipFreeAsync(scratch_raw, stream);
+        return fail(HLM_ERR_HIP, "Radau launch set-up failed: %s", hipGetErrorString(ez));
+    }
     if (!by_flag_time) {
         hipLaunchKernelGGL(hlm::compact_count_kernel, dim3((unsigned)nb), dim3(hlm::COMPACT_BLOCK), 0, stream, j->d_stiff, (int)HLM_SYS_STIFF, ns, block_count);
         hipLaunchKernelGGL(hlm::compact_scan_kernel, dim3(1), dim3(hlm::COMPACT_BLOCK), 0, stream, block_count, nb, count, (int*)nullptr, (int*)nullptr);
