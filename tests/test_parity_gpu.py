@@ -4,6 +4,8 @@ Stated tolerance: |d| <= 1e-9 + 1e-6*|y| on final states and dense o
 (= the solver's own atol/rtol; RK45 is adaptive and hipcc contracts FMAs like nvcc does,
 the gcc oracle does not).  Stiff flags must match; step counts may differ by a few.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -1975,7 +1977,8 @@ def test_radau_queue_with_nothing_and_with_one_hillslope_to_do(gpu, oracle):
         H.api.set_radau_pieces(0)
 
 
-@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+# (HLM_RADAU_FUZZ_SEEDS=N in the environment: N seeds instead of 6 -- a soak run, round 5: 300 seeds, no difference)
+@pytest.mark.parametrize("seed", list(range(1, 1 + int(os.environ.get("HLM_RADAU_FUZZ_SEEDS", "6")))))
 def test_radau_queue_fuzz_whatever_the_pieces_the_same_bits(gpu, seed):
     """Random launch sizes (1 ... 700 hillslopes, ragged last tiles), windows (2 ... 7 days: pieces that are no multiple of the
     forcing hour), query grids, layouts, modes and piece counts against whole systems (hlm_set_radau_pieces(1)): a race in
